@@ -1,0 +1,126 @@
+"""Deterministic synthetic SDSS-like frames and photoObj-like catalogues.
+
+Frame ``k`` is a pure function of ``k`` (numpy ``default_rng(PCG64)``, seed 20240000 + k), so
+the GPU box and the build container produce identical inputs.  There is no network for real
+SDSS data; shapes and statistics follow the reference's input contract: a float32
+(1489, 2048) nanomaggie image (detecttrails.py:113) and the eight photoObj columns that
+removestars.py:96-104 reads.
+"""
+import numpy as np
+
+SDSS_SHAPE = (1489, 2048)
+LSST_SHAPE = (4096, 4096)
+SEED0 = 20240000
+
+BRIGHT_PEAK = 5.0
+DIM_PEAK = 0.15
+
+
+def _add_stars(img, ys, xs, flux, sigma):
+    h, w = img.shape
+    rad = int(np.ceil(6 * sigma))
+    ax = np.arange(-rad, rad + 1, dtype=np.float64)
+    norm = 1.0 / (2 * np.pi * sigma * sigma)
+    for y, x, f in zip(ys, xs, flux):
+        iy, ix = int(np.floor(y)), int(np.floor(x))
+        gy = np.exp(-((ax + iy - y) ** 2) / (2 * sigma * sigma))
+        gx = np.exp(-((ax + ix - x) ** 2) / (2 * sigma * sigma))
+        y0, y1 = max(iy - rad, 0), min(iy + rad + 1, h)
+        x0, x1 = max(ix - rad, 0), min(ix + rad + 1, w)
+        if y0 >= y1 or x0 >= x1:
+            continue
+        stamp = (f * norm) * np.outer(gy[y0 - iy + rad:y1 - iy + rad], gx[x0 - ix + rad:x1 - ix + rad])
+        img[y0:y1, x0:x1] += stamp.astype(np.float32)
+
+
+def _add_streak(img, y0, x0, angle_deg, peak, sigma):
+    h, w = img.shape
+    phi = np.deg2rad(angle_deg)
+    yy = np.arange(h, dtype=np.float32)[:, None]
+    xx = np.arange(w, dtype=np.float32)[None, :]
+    d = (xx - np.float32(x0)) * np.float32(np.sin(phi)) - (yy - np.float32(y0)) * np.float32(np.cos(phi))
+    img += (np.float32(peak) * np.exp(-(d * d) / np.float32(2 * sigma * sigma))).astype(np.float32)
+
+
+def make_frame(k, shape=SDSS_SHAPE, n_star=None, with_catalog=True):
+    """Returns (float32 image, catalogue dict or None, truth dict)."""
+    h, w = shape
+    if n_star is None:
+        n_star = 400 if shape == SDSS_SHAPE else int(round(400 * (h * w) / (1489 * 2048)))
+    rng = np.random.default_rng(np.random.PCG64(SEED0 + int(k)))
+    img = rng.normal(0.0, 0.025, (h, w)).astype(np.float32)
+    ys = rng.uniform(0, h, n_star)
+    xs = rng.uniform(0, w, n_star)
+    flux = np.exp(rng.uniform(np.log(1.0), np.log(2000.0), n_star))
+    _add_stars(img, ys, xs, flux, 1.5)
+    has_streak = bool(rng.random() < 0.75)
+    sy = rng.uniform(0.2 * h, 0.8 * h)
+    sx = rng.uniform(0.2 * w, 0.8 * w)
+    ang = rng.uniform(5.0, 85.0)
+    if rng.random() < 0.5:
+        ang += 90.0
+    kind = "none"
+    if has_streak:
+        kind = "bright" if k % 2 == 0 else "dim"
+        _add_streak(img, sy, sx, ang, BRIGHT_PEAK if kind == "bright" else DIM_PEAK, 2.0)
+    truth = {"k": int(k), "streak": kind, "y0": float(sy), "x0": float(sx), "angle_deg": float(ang)}
+    cat = None
+    if with_catalog:
+        n_decoy = max(1, n_star // 20)
+        n = n_star + n_decoy
+        rowc = np.empty((n, 5), np.float32)
+        colc = np.empty((n, 5), np.float32)
+        rowc[:n_star] = ys[:, None]
+        colc[:n_star] = xs[:, None]
+        mag = (22.5 - 2.5 * np.log10(flux))[:, None] + rng.uniform(-0.2, 0.2, (n_star, 5))
+        psf = np.empty((n, 5), np.float32)
+        psf[:n_star] = mag
+        pet = rng.uniform(1.0, 8.0, (n, 5)).astype(np.float32)
+        nob = np.ones(n, np.int32)
+        nde = np.ones(n, np.int32)
+        # decoys: must NOT be masked (NOBSERVE != NDETECT, or one band at -9999)
+        dy = rng.uniform(0, h, n_decoy)
+        dx = rng.uniform(0, w, n_decoy)
+        rowc[n_star:] = dy[:, None]
+        colc[n_star:] = dx[:, None]
+        psf[n_star:] = rng.uniform(15.0, 21.0, (n_decoy, 1)) + rng.uniform(-0.2, 0.2, (n_decoy, 5))
+        for j in range(n_decoy):
+            if j % 2 == 0:
+                nob[n_star + j] = 2
+            else:
+                psf[n_star + j, int(rng.integers(0, 5))] = -9999.0
+        cat = {"ROWC": rowc, "COLC": colc, "PSFMAG": psf, "PETROTH90": pet, "NOBSERVE": nob,
+               "NDETECT": nde}
+    return img, cat, truth
+
+
+def make_config1_frame(shape=SDSS_SHAPE):
+    """BASELINE config 1: uint8 zeros + one 5-px-wide streak of value 200 + 50 salt pixels (255)."""
+    h, w = shape
+    rng = np.random.default_rng(np.random.PCG64(1))
+    img = np.zeros((h, w), np.uint8)
+    yy = np.arange(h, dtype=np.float32)[:, None]
+    xx = np.arange(w, dtype=np.float32)[None, :]
+    phi = np.deg2rad(35.0)
+    d = (xx - np.float32(w / 2)) * np.float32(np.sin(phi)) - (yy - np.float32(h / 2)) * np.float32(np.cos(phi))
+    img[np.abs(d) <= 2.5] = 200
+    sy = rng.integers(0, h, 50)
+    sx = rng.integers(0, w, 50)
+    img[sy, sx] = 255
+    return img
+
+
+def pack_catalogs(cats, filter_index=None):
+    """Stack per-frame catalogues into padded arrays [n_frames, max_obj, ...] + counts."""
+    n = len(cats)
+    m = max(len(c["NOBSERVE"]) for c in cats)
+    out = {"ROWC": np.zeros((n, m, 5), np.float32), "COLC": np.zeros((n, m, 5), np.float32),
+           "PSFMAG": np.zeros((n, m, 5), np.float32), "PETROTH90": np.zeros((n, m, 5), np.float32),
+           "NOBSERVE": np.zeros((n, m), np.int32), "NDETECT": np.ones((n, m), np.int32),
+           "count": np.zeros(n, np.int32)}
+    for i, c in enumerate(cats):
+        k = len(c["NOBSERVE"])
+        out["count"][i] = k
+        for key in ("ROWC", "COLC", "PSFMAG", "PETROTH90", "NOBSERVE", "NDETECT"):
+            out[key][i, :k] = c[key]
+    return out
