@@ -1,0 +1,183 @@
+/*
+ * lfdmi.h -- C-ABI of liblfdmi.so: the MI355X (gfx950) implementation of the per-frame hot
+ * path of lfd.detecttrails.  Plain pointers and sizes only; loaded with ctypes.CDLL by
+ * lfd_amd/_native.py (see INTEGRATION.md for the binding a maintainer of the reference adds).
+ *
+ * The reference has no FFI of its own: its seam is the Python call boundary of
+ * lfd/detecttrails/__init__.py:69-71.  Each entry point below names the reference interface
+ * it stands in for (file:line under /root/reference).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative lfdmi_status otherwise;
+ *     lfdmi_last_error(ctx) gives the text.  HIP errors never abort the process.
+ *   - images are row-major, C-contiguous, `n` images of h x w back to back.
+ *   - `loc` says where caller buffers live: LFDMI_HOST (the library stages them) or
+ *     LFDMI_DEVICE (hipMalloc'd / torch CUDA memory on ctx's device, used in place).
+ *   - a ctx is bound to one device, is not thread-safe, and runs everything on one HIP
+ *     stream (its own, or the caller's via lfdmi_set_stream).  Calls return after the
+ *     stream has drained (synchronous at the ABI), except lfdmi_detect_batch_async.
+ *   - the library never retains or frees caller pointers.
+ */
+#ifndef LFDMI_H
+#define LFDMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFDMI_VERSION 100
+
+enum lfdmi_status {
+    LFDMI_OK = 0,
+    LFDMI_ERR_ARG = -1,         /* bad argument (shape, dtype, NULL) */
+    LFDMI_ERR_DTYPE = -2,       /* dtype not valid for this operation (dim pass on uint8) */
+    LFDMI_ERR_HIP = -3,         /* HIP runtime error; see lfdmi_last_error */
+    LFDMI_ERR_UNSUPPORTED = -4, /* knob value not implemented (e.g. CHAIN_APPROX_TC89_*) */
+    LFDMI_ERR_CAPACITY = -5,    /* frame larger than the ctx was created for / workspace overflow */
+    LFDMI_ERR_NOLINES = -6      /* per-frame status: HoughLines returned no line although
+                                   fit_minAreaRect detected (reference: TypeError, logged) */
+};
+
+enum { LFDMI_HOST = 0, LFDMI_DEVICE = 1 };
+enum { LFDMI_U8 = 0, LFDMI_F32 = 1, LFDMI_F64 = 2 };
+/* numpy masking done before cv2.convertScaleAbs */
+enum { LFDMI_PREP_NONE = 0, LFDMI_PREP_BRIGHT = 1, LFDMI_PREP_DIM = 2, LFDMI_PREP_BRIGHT_THEN_DIM = 3 };
+/* cv2 constants re-exported by lfd/detecttrails/detecttrails.py:14-18 */
+enum { LFDMI_RETR_EXTERNAL = 0, LFDMI_RETR_LIST = 1, LFDMI_RETR_CCOMP = 2, LFDMI_RETR_TREE = 3 };
+enum { LFDMI_CHAIN_APPROX_NONE = 1, LFDMI_CHAIN_APPROX_SIMPLE = 2, LFDMI_CHAIN_APPROX_TC89_L1 = 3,
+       LFDMI_CHAIN_APPROX_TC89_KCOS = 4 };
+/* lfdmi_get_stage selectors (device images of the last process/detect call, per slot) */
+enum { LFDMI_STAGE_GRAY = 0, LFDMI_STAGE_EQU = 1, LFDMI_STAGE_CANNY = 2, LFDMI_STAGE_BOX = 3 };
+
+typedef struct lfdmi_ctx lfdmi_ctx;
+
+/* The keys of params_bright / params_dim (detecttrails.py:202-230); key names == argument
+ * names of process_field_bright/dim (processfield.py:291-293, :391-394).  Kernels are
+ * row-major 0/1 masks in HOST memory. */
+typedef struct {
+    double lwTresh, thetaTresh, lineSetTresh, dro;
+    double minAreaRectMinLen;
+    double houghMethod;           /* passed to HoughLines as rho (processfield.py:370,488) */
+    int32_t nlinesInSet;          /* 1..LFDMI_MAX_SET_LINES */
+    int32_t contoursMode, contoursMethod;
+    int32_t dilate_kh, dilate_kw;
+    const uint8_t *dilateKernel;
+    int32_t erode_kh, erode_kw;   /* dim only */
+    const uint8_t *erodeKernel;
+    double minFlux, addFlux;      /* dim only */
+} lfdmi_params;
+
+#define LFDMI_MAX_SET_LINES 64
+#define LFDMI_MAX_MORPH_K 31
+
+/* params_removestars (detecttrails.py:231-239) for one filter */
+typedef struct {
+    int32_t defaultxy, maxxy, magcount;
+    double pixscale, maxmagdiff;
+    double filter_cap;            /* filter_caps[filter] */
+    int32_t filter_index;         /* 0..4 = u g r i z */
+} lfdmi_rs_params;
+
+/* photoObj columns read by removestars.py:96-104, padded to max_obj rows per frame */
+typedef struct {
+    int32_t max_obj;
+    const int32_t *count;         /* [n] objects per frame */
+    const float *rowc, *colc, *psfmag, *petro90; /* [n][max_obj][5] */
+    const int32_t *nobserve, *ndetect;           /* [n][max_obj] */
+    int32_t loc;                  /* where these arrays live */
+} lfdmi_catalog;
+
+/* one record per frame; what process_field needs to write a results row */
+typedef struct {
+    int32_t status;               /* 0 or a negative lfdmi_status for this frame */
+    int32_t found;                /* 0 none, 1 bright pass, 2 dim pass */
+    float rho, theta;             /* equhough[0][0] (processfield.py:384,502) */
+    int32_t x1, y1, x2, y2;       /* dictify_hough, float32 evaluation (processfield.py:266-288) */
+    int32_t n_lines_equ, n_lines_box;
+    int32_t detection;            /* fit_minAreaRect's flag in the last pass that ran */
+    int32_t rejected_by_theta;    /* check_theta returned True in the last pass that ran */
+} lfdmi_result;
+
+int lfdmi_version(void);
+/* max_inflight = frames processed concurrently (workspace is sized for that many). */
+int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflight, lfdmi_ctx **out);
+void lfdmi_ctx_destroy(lfdmi_ctx *ctx);
+const char *lfdmi_last_error(lfdmi_ctx *ctx);
+/* run on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own */
+int lfdmi_set_stream(lfdmi_ctx *ctx, void *hip_stream);
+int lfdmi_max_inflight(lfdmi_ctx *ctx);
+
+/* ---- per-operator entry points (single images from processfield.py, and parity tests) ---- */
+
+/* img[img<0]=0 / img[img<minFlux]=0; img[img>0]+=addFlux, then cv2.convertScaleAbs
+ * (processfield.py:342,346 / :453-456), optionally after cv2.flip(img,0)
+ * (detecttrails.py:124).  hist (n x 256 int32) may be NULL. */
+int lfdmi_prep_u8(lfdmi_ctx *ctx, const void *src, int dtype, int n, int h, int w, int flip,
+                  int mode, double minFlux, double addFlux, uint8_t *gray, int32_t *hist, int loc);
+/* cv2.equalizeHist (processfield.py:347,457) */
+int lfdmi_equalize_hist(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, uint8_t *dst,
+                        int loc);
+/* cv2.dilate / cv2.erode(img, kernel) (processfield.py:354,464,471); kernel on the host */
+int lfdmi_dilate(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, const uint8_t *kernel,
+                 int kh, int kw, uint8_t *dst, int loc);
+int lfdmi_erode(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, const uint8_t *kernel,
+                int kh, int kw, uint8_t *dst, int loc);
+/* cv2.Canny(img, low, high) with aperture 3, L1 gradient (processfield.py:236) */
+int lfdmi_canny(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, double low, double high,
+                uint8_t *dst, int loc);
+/* fit_minAreaRect (processfield.py:201-263): Canny(0,255) -> contours -> minAreaRect ->
+ * side/elongation filter -> boxPoints -> int32 -> fillPoly.  box_img n*h*w u8 (may be NULL),
+ * detection / n_boxes n x int32 (may be NULL). */
+int lfdmi_fit_min_area_rect(lfdmi_ctx *ctx, const uint8_t *img, int n, int h, int w,
+                            int contoursMode, int contoursMethod, double minAreaRectMinLen,
+                            double lwTresh, uint8_t *box_img, int32_t *detection,
+                            int32_t *n_boxes, int loc);
+/* cv2.HoughLines(img, rho, theta, threshold) (processfield.py:370-371,488-489).
+ * lines: n x max_lines x 2 float32 (rho, theta), sorted by votes descending;
+ * n_lines: total number of lines found per image (may exceed max_lines). */
+int lfdmi_hough_lines(lfdmi_ctx *ctx, const uint8_t *img, int n, int h, int w, double rho,
+                      double theta, int threshold, int max_lines, float *lines, int32_t *n_lines,
+                      int loc);
+/* the raw (numangle+2) x (numrho+2) int32 vote accumulator of the same call */
+int lfdmi_hough_accum(lfdmi_ctx *ctx, const uint8_t *img, int n, int h, int w, double rho,
+                      double theta, int32_t *accum, int loc);
+void lfdmi_hough_dims(int h, int w, double rho, double theta, int *numangle, int *numrho);
+/* remove_stars (removestars.py:212-231) on float32 frames, in place */
+int lfdmi_remove_stars(lfdmi_ctx *ctx, float *img, int n, int h, int w, const lfdmi_catalog *cat,
+                       const lfdmi_rs_params *rs, int loc);
+
+/* ---- whole passes ---- */
+
+/* process_field_bright (processfield.py:291-388) on n images.  lines_equ / lines_box
+ * (n x nlinesInSet x 2 float32, may be NULL) receive the first nlinesInSet Hough lines of
+ * each set so the caller can run check_theta itself; results always filled. */
+int lfdmi_process_bright(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, int w, int flip,
+                         const lfdmi_params *p, lfdmi_result *results, float *lines_equ,
+                         float *lines_box, int loc);
+/* process_field_dim (processfield.py:391-506); after_bright = the array was already clamped
+ * by the bright pass (detecttrails.py:125,129 share one array) */
+int lfdmi_process_dim(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, int w, int flip,
+                      int after_bright, const lfdmi_params *p, lfdmi_result *results,
+                      float *lines_equ, float *lines_box, int loc);
+/* process_field's hot part (detecttrails.py:119-131) for n float32 frames:
+ * remove_stars (cat may be NULL) -> flip -> bright -> dim where bright found nothing.
+ * frames are mutated by remove_stars only, as in the reference.  results: n records in HOST
+ * memory. */
+int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w,
+                       const lfdmi_catalog *cat, const lfdmi_rs_params *rs,
+                       const lfdmi_params *bright, const lfdmi_params *dim, lfdmi_result *results,
+                       int loc);
+/* copy a stage image (u8, h x w) of in-flight slot `slot` of the LAST call to dst */
+int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, uint8_t *dst, int loc);
+/* dominant-kernel timing support for bench.py: HIP-event time (ms) spent in the kernel group
+ * `which` during the last detect/process call: 0 prep, 1 morph, 2 canny, 3 ccl, 4 rects+fill,
+ * 5 hough vote, 6 hough peaks, 7 removestars; only recorded when enabled. */
+int lfdmi_enable_timing(lfdmi_ctx *ctx, int on);
+int lfdmi_get_timing(lfdmi_ctx *ctx, float *ms /* [8] */, int32_t *launches /* [8] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,399 @@
+"""ctypes binding of liblfdmi.so (include/lfdmi.h): the only way Python reaches the GPU path.
+
+There is deliberately no CPU fallback: if the shared library is missing or no HIP device is
+usable, every entry point raises.  numpy arrays are passed as host pointers (the library
+stages them); objects exposing ``data_ptr()`` (torch CUDA tensors) are passed as device
+pointers and used in place.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblfdmi.so")
+
+HOST, DEVICE = 0, 1
+U8, F32, F64 = 0, 1, 2
+PREP_NONE, PREP_BRIGHT, PREP_DIM, PREP_BRIGHT_THEN_DIM = 0, 1, 2, 3
+STAGE_GRAY, STAGE_EQU, STAGE_CANNY, STAGE_BOX = 0, 1, 2, 3
+MAX_SET_LINES = 64
+MAX_MORPH_K = 31
+
+ERR_ARG, ERR_DTYPE, ERR_HIP, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_NOLINES = -1, -2, -3, -4, -5, -6
+
+TIMING_GROUPS = ("prep", "morph", "canny", "ccl", "rects", "hough_vote", "hough_peaks", "removestars")
+
+# every symbol include/lfdmi.h declares (checked by the CPU test-suite)
+SYMBOLS = (
+    "lfdmi_version", "lfdmi_ctx_create", "lfdmi_ctx_destroy", "lfdmi_last_error", "lfdmi_set_stream",
+    "lfdmi_max_inflight", "lfdmi_prep_u8", "lfdmi_equalize_hist", "lfdmi_dilate", "lfdmi_erode",
+    "lfdmi_canny", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
+    "lfdmi_hough_dims", "lfdmi_remove_stars", "lfdmi_process_bright", "lfdmi_process_dim",
+    "lfdmi_detect_batch", "lfdmi_get_stage", "lfdmi_enable_timing", "lfdmi_get_timing",
+)
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"liblfdmi error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("lwTresh", C.c_double), ("thetaTresh", C.c_double), ("lineSetTresh", C.c_double),
+                ("dro", C.c_double), ("minAreaRectMinLen", C.c_double), ("houghMethod", C.c_double),
+                ("nlinesInSet", C.c_int32), ("contoursMode", C.c_int32), ("contoursMethod", C.c_int32),
+                ("dilate_kh", C.c_int32), ("dilate_kw", C.c_int32), ("dilateKernel", C.c_void_p),
+                ("erode_kh", C.c_int32), ("erode_kw", C.c_int32), ("erodeKernel", C.c_void_p),
+                ("minFlux", C.c_double), ("addFlux", C.c_double)]
+
+
+class RsParams(C.Structure):
+    _fields_ = [("defaultxy", C.c_int32), ("maxxy", C.c_int32), ("magcount", C.c_int32),
+                ("pixscale", C.c_double), ("maxmagdiff", C.c_double), ("filter_cap", C.c_double),
+                ("filter_index", C.c_int32)]
+
+
+class Catalog(C.Structure):
+    _fields_ = [("max_obj", C.c_int32), ("count", C.c_void_p), ("rowc", C.c_void_p),
+                ("colc", C.c_void_p), ("psfmag", C.c_void_p), ("petro90", C.c_void_p),
+                ("nobserve", C.c_void_p), ("ndetect", C.c_void_p), ("loc", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_int32), ("found", C.c_int32), ("rho", C.c_float), ("theta", C.c_float),
+                ("x1", C.c_int32), ("y1", C.c_int32), ("x2", C.c_int32), ("y2", C.c_int32),
+                ("n_lines_equ", C.c_int32), ("n_lines_box", C.c_int32), ("detection", C.c_int32),
+                ("rejected_by_theta", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+RESULT_DTYPE = np.dtype([("status", "<i4"), ("found", "<i4"), ("rho", "<f4"), ("theta", "<f4"),
+                         ("x1", "<i4"), ("y1", "<i4"), ("x2", "<i4"), ("y2", "<i4"),
+                         ("n_lines_equ", "<i4"), ("n_lines_box", "<i4"), ("detection", "<i4"),
+                         ("rejected_by_theta", "<i4")])
+
+_lib = None
+
+
+def lib():
+    """Load liblfdmi.so or fail loudly (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C lfd_amd/csrc` "
+                              "(or `python -c 'import __graft_entry__ as g; g.build()'`)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.lfdmi_last_error.restype = C.c_char_p
+        _lib.lfdmi_last_error.argtypes = [C.c_void_p]
+        _lib.lfdmi_ctx_destroy.restype = None
+        _lib.lfdmi_ctx_destroy.argtypes = [C.c_void_p]
+        _lib.lfdmi_hough_dims.restype = None
+    return _lib
+
+
+def _is_dev(a):
+    return hasattr(a, "data_ptr")
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if _is_dev(a):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _dtype_code(a):
+    name = str(a.dtype).replace("torch.", "")
+    try:
+        return {"uint8": U8, "float32": F32, "float64": F64}[name]
+    except KeyError:
+        raise TypeError(f"unsupported image dtype {a.dtype}") from None
+
+
+def make_params(d, dim=False):
+    """dict with the reference's key names -> (Params struct, objects to keep alive)."""
+    dk = np.ascontiguousarray(d["dilateKernel"], np.uint8)
+    if dk.ndim != 2:
+        raise ValueError("dilateKernel must be a 2-d array")
+    keep = [dk]
+    p = Params()
+    p.lwTresh = float(d["lwTresh"])
+    p.thetaTresh = float(d["thetaTresh"])
+    p.lineSetTresh = float(d["lineSetTresh"])
+    p.dro = float(d["dro"])
+    p.minAreaRectMinLen = float(d["minAreaRectMinLen"])
+    p.houghMethod = float(d["houghMethod"])
+    p.nlinesInSet = int(d["nlinesInSet"])
+    p.contoursMode = int(d["contoursMode"])
+    p.contoursMethod = int(d["contoursMethod"])
+    p.dilate_kh, p.dilate_kw = dk.shape
+    p.dilateKernel = dk.ctypes.data
+    if dim:
+        ek = np.ascontiguousarray(d["erodeKernel"], np.uint8)
+        if ek.ndim != 2:
+            raise ValueError("erodeKernel must be a 2-d array")
+        keep.append(ek)
+        p.erode_kh, p.erode_kw = ek.shape
+        p.erodeKernel = ek.ctypes.data
+        p.minFlux = float(d["minFlux"])
+        p.addFlux = float(d["addFlux"])
+    return p, keep
+
+
+def make_rs_params(filter, defaultxy, filter_caps, maxxy, pixscale, magcount, maxmagdiff, **_):
+    return RsParams(int(defaultxy), int(maxxy), int(magcount), float(pixscale), float(maxmagdiff),
+                    float(filter_caps[filter]), "ugriz".index(filter))
+
+
+class Context:
+    """One GPU, one HIP stream, workspace for ``max_inflight`` frames of up to max_h x max_w."""
+
+    def __init__(self, device=0, max_h=1489, max_w=2048, max_inflight=8):
+        self._h = C.c_void_p()
+        self._lib = lib()
+        rc = self._lib.lfdmi_ctx_create(int(device), int(max_h), int(max_w), int(max_inflight),
+                                        C.byref(self._h))
+        if rc:
+            msg = self._lib.lfdmi_last_error(self._h).decode() if self._h else "context creation failed"
+            h, self._h = self._h, C.c_void_p()
+            if h:
+                self._lib.lfdmi_ctx_destroy(h)
+            raise NativeError(rc, msg)
+        self.device, self.max_h, self.max_w, self.max_inflight = device, max_h, max_w, max_inflight
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lfdmi_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc:
+            raise NativeError(rc, self._lib.lfdmi_last_error(self._h).decode())
+
+    def set_stream(self, stream_handle):
+        self._chk(self._lib.lfdmi_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+
+    def enable_timing(self, on=True):
+        self._chk(self._lib.lfdmi_enable_timing(self._h, int(on)))
+
+    def get_timing(self):
+        ms = (C.c_float * 8)()
+        n = (C.c_int32 * 8)()
+        self._chk(self._lib.lfdmi_get_timing(self._h, ms, n))
+        return {g: (float(ms[i]), int(n[i])) for i, g in enumerate(TIMING_GROUPS)}
+
+    # -- helpers --------------------------------------------------------------------------
+    @staticmethod
+    def _batch(img, ndim_item=2):
+        """-> (array with leading batch axis, n, h, w, squeeze?)"""
+        if _is_dev(img):
+            shp = tuple(img.shape)
+            if not img.is_contiguous():
+                raise ValueError("device tensors must be contiguous")
+        else:
+            img = np.ascontiguousarray(img)
+            shp = img.shape
+        if len(shp) == ndim_item:
+            return img, 1, shp[0], shp[1], True
+        if len(shp) == ndim_item + 1:
+            return img, shp[0], shp[1], shp[2], False
+        raise ValueError(f"expected a 2-d image or a 3-d batch, got shape {shp}")
+
+    @staticmethod
+    def _out_like(img, n, h, w, squeeze, dtype=np.uint8):
+        if _is_dev(img):
+            import torch
+            tdt = {np.uint8: torch.uint8, np.int32: torch.int32, np.float32: torch.float32}[dtype]
+            out = torch.empty((n, h, w), dtype=tdt, device=img.device)
+        else:
+            out = np.empty((n, h, w), dtype)
+        return out
+
+    # -- per-operator entry points ------------------------------------------------------------
+    def prep_u8(self, img, mode, flip=False, minFlux=0.0, addFlux=0.0, want_hist=False):
+        img, n, h, w, sq = self._batch(img)
+        loc = DEVICE if _is_dev(img) else HOST
+        out = self._out_like(img, n, h, w, sq)
+        hist = None
+        if want_hist:
+            if loc == DEVICE:
+                import torch
+                hist = torch.empty((n, 256), dtype=torch.int32, device=img.device)
+            else:
+                hist = np.empty((n, 256), np.int32)
+        self._chk(self._lib.lfdmi_prep_u8(self._h, _ptr(img), _dtype_code(img), n, h, w, int(flip),
+                                          int(mode), C.c_double(minFlux), C.c_double(addFlux),
+                                          _ptr(out), _ptr(hist), loc))
+        out = out[0] if sq else out
+        if want_hist:
+            return out, (hist[0] if sq else hist)
+        return out
+
+    def equalize_hist(self, img):
+        img, n, h, w, sq = self._batch(img)
+        loc = DEVICE if _is_dev(img) else HOST
+        out = self._out_like(img, n, h, w, sq)
+        self._chk(self._lib.lfdmi_equalize_hist(self._h, _ptr(img), n, h, w, _ptr(out), loc))
+        return out[0] if sq else out
+
+    def _morph(self, fn, img, kernel):
+        img, n, h, w, sq = self._batch(img)
+        loc = DEVICE if _is_dev(img) else HOST
+        k = np.ascontiguousarray(kernel, np.uint8)
+        if k.ndim != 2:
+            raise ValueError("kernel must be 2-d")
+        out = self._out_like(img, n, h, w, sq)
+        self._chk(fn(self._h, _ptr(img), n, h, w, _ptr(k), k.shape[0], k.shape[1], _ptr(out), loc))
+        return out[0] if sq else out
+
+    def dilate(self, img, kernel):
+        return self._morph(self._lib.lfdmi_dilate, img, kernel)
+
+    def erode(self, img, kernel):
+        return self._morph(self._lib.lfdmi_erode, img, kernel)
+
+    def canny(self, img, low=0.0, high=255.0):
+        img, n, h, w, sq = self._batch(img)
+        loc = DEVICE if _is_dev(img) else HOST
+        out = self._out_like(img, n, h, w, sq)
+        self._chk(self._lib.lfdmi_canny(self._h, _ptr(img), n, h, w, C.c_double(low), C.c_double(high),
+                                        _ptr(out), loc))
+        return out[0] if sq else out
+
+    def fit_min_area_rect(self, img, contoursMode=1, contoursMethod=1, minAreaRectMinLen=1, lwTresh=5,
+                          want_box=True):
+        """-> (detection bool(s), box_img(s), n_boxes)"""
+        img, n, h, w, sq = self._batch(img)
+        if _is_dev(img):
+            raise TypeError("fit_min_area_rect: pass numpy arrays (device outputs not wired in Python)")
+        box = np.empty((n, h, w), np.uint8) if want_box else None
+        det = np.zeros(n, np.int32)
+        nb = np.zeros(n, np.int32)
+        self._chk(self._lib.lfdmi_fit_min_area_rect(self._h, _ptr(img), n, h, w, int(contoursMode),
+                                                    int(contoursMethod), C.c_double(minAreaRectMinLen),
+                                                    C.c_double(lwTresh), _ptr(box), _ptr(det), _ptr(nb),
+                                                    HOST))
+        if sq:
+            return bool(det[0]), (box[0] if want_box else None), int(nb[0])
+        return det.astype(bool), box, nb
+
+    def hough_dims(self, h, w, rho, theta=np.pi / 180):
+        na, nr = C.c_int(), C.c_int()
+        self._lib.lfdmi_hough_dims(int(h), int(w), C.c_double(rho), C.c_double(theta), C.byref(na), C.byref(nr))
+        return na.value, nr.value
+
+    def hough_lines(self, img, rho, theta=np.pi / 180, threshold=1, max_lines=None):
+        """cv2.HoughLines layout per image: (n_lines, 1, 2) float32 or None; also total count."""
+        img, n, h, w, sq = self._batch(img)
+        if _is_dev(img):
+            raise TypeError("hough_lines: pass numpy arrays")
+        na, nr = self.hough_dims(h, w, rho, theta)
+        cap = na * nr if max_lines is None else int(max_lines)
+        lines = np.zeros((n, max(cap, 1), 2), np.float32)
+        cnt = np.zeros(n, np.int32)
+        self._chk(self._lib.lfdmi_hough_lines(self._h, _ptr(img), n, h, w, C.c_double(rho), C.c_double(theta),
+                                              int(threshold), cap, _ptr(lines), _ptr(cnt), HOST))
+        outs = []
+        for i in range(n):
+            k = min(int(cnt[i]), cap)
+            outs.append(lines[i, :k].reshape(k, 1, 2).copy() if k else None)
+        return (outs[0], int(cnt[0])) if sq else (outs, cnt)
+
+    def hough_accum(self, img, rho, theta=np.pi / 180):
+        img, n, h, w, sq = self._batch(img)
+        na, nr = self.hough_dims(h, w, rho, theta)
+        acc = np.zeros((n, na + 2, nr + 2), np.int32)
+        self._chk(self._lib.lfdmi_hough_accum(self._h, _ptr(img), n, h, w, C.c_double(rho), C.c_double(theta),
+                                              _ptr(acc), HOST))
+        return acc[0] if sq else acc
+
+    @staticmethod
+    def _catalog(cat):
+        """dict of stacked arrays (see synth.pack_catalogs) -> (Catalog struct, keep-alive list)"""
+        if cat is None:
+            return None, []
+        dev = _is_dev(cat["ROWC"])
+        if dev:
+            arrs = {k: cat[k] for k in ("count", "ROWC", "COLC", "PSFMAG", "PETROTH90", "NOBSERVE", "NDETECT")}
+        else:
+            arrs = {"count": np.ascontiguousarray(cat["count"], np.int32)}
+            for k in ("ROWC", "COLC", "PSFMAG", "PETROTH90"):
+                arrs[k] = np.ascontiguousarray(cat[k], np.float32)
+            for k in ("NOBSERVE", "NDETECT"):
+                arrs[k] = np.ascontiguousarray(cat[k], np.int32)
+        c = Catalog()
+        c.max_obj = int(arrs["NOBSERVE"].shape[1])
+        c.count = _ptr(arrs["count"]).value
+        c.rowc = _ptr(arrs["ROWC"]).value
+        c.colc = _ptr(arrs["COLC"]).value
+        c.psfmag = _ptr(arrs["PSFMAG"]).value
+        c.petro90 = _ptr(arrs["PETROTH90"]).value
+        c.nobserve = _ptr(arrs["NOBSERVE"]).value
+        c.ndetect = _ptr(arrs["NDETECT"]).value
+        c.loc = DEVICE if dev else HOST
+        return c, list(arrs.values())
+
+    def remove_stars(self, img, cat, rs):
+        """float32 frame(s), mutated in place like removestars.py:231."""
+        b, n, h, w, sq = self._batch(img)
+        if _dtype_code(b) != F32:
+            raise TypeError("remove_stars needs float32 frames")
+        if not _is_dev(img) and b is not img and not np.shares_memory(b, img):
+            raise ValueError("remove_stars needs a C-contiguous array (it is modified in place)")
+        c, keep = self._catalog(cat)
+        self._chk(self._lib.lfdmi_remove_stars(self._h, _ptr(b), n, h, w, C.byref(c), C.byref(rs),
+                                               DEVICE if _is_dev(b) else HOST))
+        return img
+
+    # -- whole passes -------------------------------------------------------------------------
+    def _pass(self, fn, img, params, dim, flip, extra):
+        img, n, h, w, sq = self._batch(img)
+        loc = DEVICE if _is_dev(img) else HOST
+        p, keep = make_params(params, dim=dim)
+        res = np.zeros(n, RESULT_DTYPE)
+        K = p.nlinesInSet
+        le = np.zeros((n, K, 2), np.float32)
+        lb = np.zeros((n, K, 2), np.float32)
+        self._chk(fn(self._h, _ptr(img), _dtype_code(img), n, h, w, int(flip), *extra, C.byref(p), _ptr(res),
+                     _ptr(le), _ptr(lb), loc))
+        return (res[0], le[0], lb[0]) if sq else (res, le, lb)
+
+    def process_bright(self, img, params, flip=False):
+        return self._pass(self._lib.lfdmi_process_bright, img, params, False, flip, ())
+
+    def process_dim(self, img, params, flip=False, after_bright=False):
+        return self._pass(self._lib.lfdmi_process_dim, img, params, True, flip, (int(after_bright),))
+
+    def detect_batch(self, frames, params_bright, params_dim, cat=None, rs=None):
+        """frames: float32 (n,h,w) numpy or torch-CUDA; returns a structured array of n results."""
+        frames, n, h, w, sq = self._batch(frames)
+        if _dtype_code(frames) != F32:
+            raise TypeError("detect_batch needs float32 frames")
+        pb, k1 = make_params(params_bright)
+        pd, k2 = make_params(params_dim, dim=True)
+        c, k3 = self._catalog(cat)
+        res = np.zeros(n, RESULT_DTYPE)
+        self._chk(self._lib.lfdmi_detect_batch(self._h, _ptr(frames), n, h, w,
+                                               C.byref(c) if c is not None else None,
+                                               C.byref(rs) if rs is not None else None,
+                                               C.byref(pb), C.byref(pd), _ptr(res),
+                                               DEVICE if _is_dev(frames) else HOST))
+        return res
+
+    def get_stage(self, slot, which, h, w):
+        out = np.empty((h, w), np.uint8)
+        self._chk(self._lib.lfdmi_get_stage(self._h, int(slot), int(which), _ptr(out), HOST))
+        return out

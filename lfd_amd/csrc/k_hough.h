@@ -1,0 +1,303 @@
+// k_hough.h -- cv2.HoughLines(img, rho, theta, threshold) (processfield.py:370-371,488-489):
+// pixel list from bit rows, the rho/theta vote accumulator in LDS, 4-neighbour local maxima,
+// ordering by (votes desc, index asc), and the check_theta tail (processfield.py:36-150).
+//
+// Vote kernel layout: one workgroup owns a slab of <= 64 angles of one image; lane == angle,
+// so every lane of a wave votes for the SAME pixel in a DIFFERENT accumulator row: no two
+// lanes ever hit the same LDS word, cos/sin live in registers, the pixel coordinates are
+// wave-uniform.  r = cvRound(j*tabCos[n] + i*tabSin[n]) is evaluated in float32 with separate
+// roundings (no FMA) exactly as OpenCV's scalar loop, so the accumulator is integer-exact.
+#pragma once
+#include "common.h"
+#include "../../include/lfdmi.h"
+
+// bit rows -> packed (y << 16 | x) list, order irrelevant (votes commute)
+__global__ void __launch_bounds__(256)
+k_pixlist(const u64 *bits, uint32_t *list, int *counters, int cidx, int h, int w, size_t list_cap,
+          const int *active, int need_detect) {
+    int g = blockIdx.y;
+    if (active && !active[g]) return;
+    int *cnt = counters + g * C_COUNT;
+    if (need_detect && !cnt[C_DETECT]) return;
+    int wq = LFD_WQ(w);
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    u64 c = 0;
+    int y = 0, q = 0;
+    if (idx < h * wq) {
+        y = idx / wq; q = idx - y * wq;
+        c = bits[(size_t)g * h * wq + idx] & valid_mask(q, w);
+    }
+    int n = __popcll(c);
+    // wave-aggregated allocation: inclusive scan of n, one atomic per wave
+    int lane = lfd_lane(), incl = n;
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    int total = __shfl(incl, 63);
+    int base = 0;
+    if (lane == 63 && total) base = atomicAdd(&cnt[cidx], total);
+    base = __shfl(base, 63);
+    int o = base + incl - n;
+    uint32_t *lg = list + (size_t)g * list_cap;
+    while (c) {
+        int b = __ffsll((long long)c) - 1;
+        c &= c - 1;
+        lg[o++] = ((uint32_t)y << 16) | (uint32_t)((q << 6) + b);
+    }
+}
+
+#define VOTE_THREADS 512
+
+// grid (nslabs, n_images_per_slot, G).  accum layout per (slot, image): (numangle+2) x (numrho+2).
+__global__ void __launch_bounds__(VOTE_THREADS)
+k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, const float *tab,
+             int *accum, int numangle, int numrho, int apb, size_t list_cap, size_t acc_cap,
+             const int *active, int need_detect) {
+    int g = blockIdx.z, im = blockIdx.y, slab = blockIdx.x;
+    if (active && !active[g]) return;
+    const int *cnt = counters + g * C_COUNT;
+    if (need_detect && !cnt[C_DETECT]) return;
+    extern __shared__ int acc[];
+    const int stride = numrho | 1; // odd row stride spreads the lanes over the LDS banks
+    int a0 = slab * apb;
+    int na = min(apb, numangle - a0);
+    for (int k = threadIdx.x; k < apb * stride; k += VOTE_THREADS) acc[k] = 0;
+    __syncthreads();
+    const uint32_t *list = (im ? list1 : list0) + (size_t)g * list_cap;
+    int n = cnt[im ? C_NPIX_BOX : C_NPIX_EQU];
+    if ((size_t)n > list_cap) n = (int)list_cap;
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool act = lane < na;
+    float c = 0.f, s = 0.f;
+    if (act) { c = tab[a0 + lane]; s = tab[numangle + a0 + lane]; }
+    int *myrow = acc + lane * stride;
+    const int roff = (numrho - 1) / 2;
+    for (int i0 = wv * 64; i0 < n; i0 += (VOTE_THREADS / 64) * 64) {
+        uint32_t pv = (i0 + lane < n) ? list[i0 + lane] : 0u;
+        int m = min(64, n - i0);
+        for (int k = 0; k < m; k++) {
+            uint32_t p = (uint32_t)__shfl((int)pv, k);
+            float fj = (float)(p & 0xffffu), fi = (float)(p >> 16);
+            int r = __float2int_rn(__fadd_rn(__fmul_rn(fj, c), __fmul_rn(fi, s))) + roff;
+            if (act && (unsigned)r < (unsigned)numrho) atomicAdd(&myrow[r], 1);
+        }
+    }
+    __syncthreads();
+    int *ag = accum + ((size_t)g * 2 + im) * acc_cap;
+    int rs = numrho + 2;
+    // rows of this slab, including the zero guard columns
+    for (int k = threadIdx.x; k < na * rs; k += VOTE_THREADS) {
+        int al = k / rs, rr = k - al * rs;
+        int v = (rr == 0 || rr == rs - 1) ? 0 : acc[al * stride + rr - 1];
+        ag[(size_t)(a0 + al + 1) * rs + rr] = v;
+    }
+    if (slab == 0) for (int k = threadIdx.x; k < rs; k += VOTE_THREADS) ag[k] = 0;
+    if (slab == gridDim.x - 1)
+        for (int k = threadIdx.x; k < rs; k += VOTE_THREADS) ag[(size_t)(numangle + 1) * rs + k] = 0;
+}
+
+// findLocalMaximums: key = votes << 32 | (0x7fffffff - base) so that a descending sort of the
+// keys is OpenCV's hough_cmp_gt order (votes desc, base asc).
+__global__ void __launch_bounds__(256)
+k_hough_peaks(const int *accum, u64 *peaks, int *counters, int numangle, int numrho, int threshold,
+              size_t acc_cap, size_t peak_cap, const int *active, int need_detect) {
+    int g = blockIdx.z, im = blockIdx.y;
+    if (active && !active[g]) return;
+    int *cnt = counters + g * C_COUNT;
+    if (need_detect && !cnt[C_DETECT]) return;
+    const int *ag = accum + ((size_t)g * 2 + im) * acc_cap;
+    u64 *pg = peaks + ((size_t)g * 2 + im) * peak_cap;
+    int rs = numrho + 2;
+    int total = numangle * numrho;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < total; k += gridDim.x * 256) {
+        int n = k / numrho, r = k - n * numrho;
+        int base = (n + 1) * rs + r + 1;
+        int v = ag[base];
+        if (v > threshold && v > ag[base - 1] && v >= ag[base + 1] && v > ag[base - rs] &&
+            v >= ag[base + rs]) {
+            int o = atomicAdd(&cnt[im ? C_NPEAK_BOX : C_NPEAK_EQU], 1);
+            if ((size_t)o < peak_cap) pg[o] = ((u64)(uint32_t)v << 32) | (u64)(uint32_t)(0x7fffffff - base);
+        }
+    }
+}
+
+__device__ __forceinline__ void key_to_line(u64 key, int numrho, float rho, float theta, float *orho,
+                                            float *otheta) {
+    int idx = 0x7fffffff - (int)(uint32_t)(key & 0xffffffffu);
+    float scale = __fdiv_rn(1.f, (float)(numrho + 2));
+    int n = (int)floorf(__fmul_rn((float)idx, scale)) - 1;
+    int r = idx - (n + 1) * (numrho + 2) - 1;
+    *orho = __fmul_rn(__fsub_rn((float)r, __fmul_rn((float)(numrho - 1), 0.5f)), rho);
+    *otheta = __fadd_rn(0.f, __fmul_rn((float)n, theta));
+}
+
+// top-K selection (K small): K rounds of "largest key below the previous one".
+// One workgroup per (image, slot).  lines: [G][2][K][2] floats.
+__global__ void __launch_bounds__(256)
+k_hough_topk(const u64 *peaks, const int *counters, float *lines, int K, int numrho, float rho,
+             float theta, size_t peak_cap, const int *active, int need_detect) {
+    int g = blockIdx.y, im = blockIdx.x;
+    if (active && !active[g]) return;
+    const int *cnt = counters + g * C_COUNT;
+    if (need_detect && !cnt[C_DETECT]) return;
+    const u64 *pg = peaks + ((size_t)g * 2 + im) * peak_cap;
+    int n = cnt[im ? C_NPEAK_BOX : C_NPEAK_EQU];
+    if ((size_t)n > peak_cap) n = (int)peak_cap;
+    __shared__ u64 red[4];
+    __shared__ u64 prev_s;
+    u64 prev = ~0ull;
+    float *lg = lines + ((size_t)g * 2 + im) * K * 2;
+    for (int round = 0; round < K; round++) {
+        u64 best = 0;
+        for (int k = threadIdx.x; k < n; k += 256) {
+            u64 v = pg[k];
+            if (v < prev && v > best) best = v;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            u64 o = __shfl_down(best, off);
+            if (o > best) best = o;
+        }
+        if (lfd_lane() == 0) red[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u64 b = red[0];
+            for (int k = 1; k < 4; k++) if (red[k] > b) b = red[k];
+            prev_s = b;
+            float ro = 0.f, th = 0.f;
+            if (b) key_to_line(b, numrho, rho, theta, &ro, &th);
+            lg[2 * round] = ro;
+            lg[2 * round + 1] = th;
+        }
+        __syncthreads();
+        prev = prev_s;
+        if (!prev) { // fewer than K lines: zero-fill the rest
+            if (threadIdx.x == 0)
+                for (int r2 = round + 1; r2 < K; r2++) { lg[2 * r2] = 0.f; lg[2 * r2 + 1] = 0.f; }
+            break;
+        }
+    }
+}
+
+// full ordering for the standalone HoughLines entry point: single-workgroup bitonic sort
+// (descending) of the peak keys in global memory, then conversion of the first max_lines.
+__global__ void __launch_bounds__(1024)
+k_hough_sort(u64 *peaks, const int *counters, float *lines, int max_lines, int numrho, float rho,
+             float theta, size_t peak_cap) {
+    int g = blockIdx.y, im = blockIdx.x;
+    const int *cnt = counters + g * C_COUNT;
+    u64 *pg = peaks + ((size_t)g * 2 + im) * peak_cap;
+    int n = cnt[im ? C_NPEAK_BOX : C_NPEAK_EQU];
+    if ((size_t)n > peak_cap) n = (int)peak_cap;
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int k = n + threadIdx.x; k < np2; k += 1024) pg[k] = 0;
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < (np2 >> 1); t += 1024) {
+                int lo = 2 * t - (t & (stride - 1)); // index with bit `stride` clear
+                int hi = lo + stride;
+                bool desc = ((lo & size) == 0);
+                u64 a = pg[lo], b = pg[hi];
+                if (desc ? (a < b) : (a > b)) { pg[lo] = b; pg[hi] = a; }
+            }
+            __syncthreads();
+        }
+    int m = min(n, max_lines);
+    float *lg = lines + (size_t)g * max_lines * 2;
+    for (int k = threadIdx.x; k < m; k += 1024) key_to_line(pg[k], numrho, rho, theta, &lg[2 * k], &lg[2 * k + 1]);
+}
+
+// ---- numpy add.reduce on a short float64 vector: first + pairwise(rest) -------------------
+__device__ double np_pairwise_dev(const double *a, int n) {
+    if (n < 8) {
+        double res = 0.;
+        for (int i = 0; i < n; i++) res = __dadd_rn(res, a[i]);
+        return res;
+    }
+    // n <= LFDMI_MAX_SET_LINES - 1 < 128: the 8-accumulator block of numpy's pairwise sum
+    double r[8], res;
+    int i;
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] = __dadd_rn(r[j], a[i + j]);
+    res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
+                    __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+    for (; i < n; i++) res = __dadd_rn(res, a[i]);
+    return res;
+}
+__device__ double np_mean_dev(const double *a, int n) {
+    return __ddiv_rn(__dadd_rn(a[0], np_pairwise_dev(a + 1, n - 1)), (double)n);
+}
+
+struct TailParams {
+    int navg;
+    double dro, thetaTresh, lineSetTresh;
+    int which; // 1 bright, 2 dim
+};
+
+// One thread per slot: check_theta on the first navg lines of both sets, result record,
+// and the "dim pass needed" flag (detecttrails.py:125-131).
+__global__ void k_finalize(const float *lines, const int *counters, lfdmi_result *res, int *need_dim,
+                           const int *active, TailParams tp, int G) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    if (active && !active[g]) { if (need_dim) need_dim[g] = 0; return; }
+    const int *cnt = counters + g * C_COUNT;
+    lfdmi_result r = res[g];
+    r.detection = cnt[C_DETECT];
+    r.rejected_by_theta = 0;
+    r.n_lines_equ = r.n_lines_box = 0;
+    if (cnt[C_OVERFLOW]) r.status = LFDMI_ERR_CAPACITY;
+    if (r.detection && r.status == 0) {
+        int n1 = cnt[C_NPEAK_EQU], n2 = cnt[C_NPEAK_BOX];
+        r.n_lines_equ = n1; r.n_lines_box = n2;
+        if (n1 == 0 || n2 == 0) {
+            r.status = LFDMI_ERR_NOLINES;
+        } else {
+            int K = tp.navg;
+            const float *l1 = lines + ((size_t)g * 2 + 0) * K * 2, *l2 = lines + ((size_t)g * 2 + 1) * K * 2;
+            double ro1[LFDMI_MAX_SET_LINES], ro2[LFDMI_MAX_SET_LINES], t1[LFDMI_MAX_SET_LINES],
+                t2[LFDMI_MAX_SET_LINES];
+            for (int i = 0; i < K; i++) {
+                ro1[i] = ro2[i] = t1[i] = t2[i] = 0.;
+                if (i >= n1) continue;
+                ro1[i] = l1[2 * i];
+                if (i >= n2) continue;
+                ro2[i] = l2[2 * i];
+                t1[i] = l1[2 * i + 1];
+                t2[i] = l2[2 * i + 1];
+            }
+            bool rej = fabs(__dsub_rn(np_mean_dev(ro1, K), np_mean_dev(ro2, K))) > tp.dro;
+            if (!rej) {
+                double mx = t1[0], mn = t1[0];
+                for (int i = 1; i < K; i++) { mx = fmax(mx, t1[i]); mn = fmin(mn, t1[i]); }
+                rej = fabs(__dsub_rn(mx, mn)) > tp.thetaTresh;
+            }
+            if (!rej) {
+                double mx = t2[0], mn = t2[0];
+                for (int i = 1; i < K; i++) { mx = fmax(mx, t2[i]); mn = fmin(mn, t2[i]); }
+                rej = fabs(__dsub_rn(mx, mn)) > tp.thetaTresh;
+            }
+            if (!rej) {
+                for (int i = 0; i < K; i++) ro1[i] = fabs(__dsub_rn(t1[i], t2[i]));
+                rej = np_mean_dev(ro1, K) > tp.lineSetTresh;
+            }
+            if (rej) r.rejected_by_theta = 1;
+            else { r.found = tp.which; r.rho = l1[0]; r.theta = l1[1]; }
+        }
+    }
+    res[g] = r;
+    if (need_dim) need_dim[g] = (r.found == 0 && r.status == 0) ? 1 : 0;
+}
+
+__global__ void k_init_results(lfdmi_result *res, int G) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    lfdmi_result r;
+    r.status = 0; r.found = 0; r.rho = 0.f; r.theta = 0.f;
+    r.x1 = r.y1 = r.x2 = r.y2 = 0;
+    r.n_lines_equ = r.n_lines_box = 0; r.detection = 0; r.rejected_by_theta = 0;
+    res[g] = r;
+}

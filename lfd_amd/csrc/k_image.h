@@ -1,0 +1,407 @@
+// k_image.h -- dense image stages: remove_stars fill, prep (flip + mask + convertScaleAbs +
+// histogram), equalisation LUT, rectangular / generic erode-dilate, Sobel+NMS.
+// Reference call sites: removestars.py:212-231, detecttrails.py:124, processfield.py:342-354,
+// :453-471, :236 (Canny's first half).  All HBM-bound; algorithmic bytes in DESIGN.md.
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// remove_stars: one workgroup per catalogue object; lane 0 evaluates the catalogue tests of
+// removestars.py:213-230 (math.ceil of every column, cap test, pairwise-difference count,
+// Petrosian square size, NOBSERVE == NDETECT), all lanes zero-fill the axis-swapped,
+// Python-slice-clipped square img[x-d:x+d, y-d:y+d] (x = COLC on axis 0).
+// ------------------------------------------------------------------------------------------
+struct RsDev {
+    int defaultxy, maxxy, magcount, filter_index;
+    double pixscale, maxmagdiff, filter_cap;
+};
+
+__device__ __forceinline__ void py_slice(long start, long stop, long len, int *a, int *b) {
+    if (start < 0) { start += len; if (start < 0) start = 0; } else if (start > len) start = len;
+    if (stop < 0) { stop += len; if (stop < 0) stop = 0; } else if (stop > len) stop = len;
+    *a = (int)start; *b = (int)stop;
+}
+
+__global__ void __launch_bounds__(256)
+k_removestars(float *frames, int h, int w, int max_obj, const int *count, const float *rowc,
+              const float *colc, const float *psfmag, const float *petro90, const int *nobserve,
+              const int *ndetect, RsDev p) {
+    int f = blockIdx.y, i = blockIdx.x;
+    if (i >= count[f]) return;
+    __shared__ int box[4];
+    if (threadIdx.x == 0) {
+        size_t o5 = ((size_t)f * max_obj + i) * 5, o1 = (size_t)f * max_obj + i;
+        int fi = p.filter_index;
+        long x = (long)ceil((double)colc[o5 + fi]);
+        long y = (long)ceil((double)rowc[o5 + fi]);
+        long mags[5];
+        for (int k = 0; k < 5; k++) mags[k] = (long)ceil((double)psfmag[o5 + k]);
+        bool ok = (double)mags[fi] < p.filter_cap;
+        int cnt = 0;
+        for (int j = 0; j < 5; j++)
+            for (int k = j + 1; k < 5; k++) {
+                long d = mags[j] - mags[k];
+                if (d < 0) d = -d;
+                if ((double)d > p.maxmagdiff) cnt++;
+            }
+        ok = ok && (p.magcount >= cnt);
+        long dxy = p.defaultxy;
+        long pet = (long)ceil((double)petro90[o5 + fi]);
+        if (pet > 0) dxy = (long)((double)pet / p.pixscale) + 10;
+        if (dxy > p.maxxy) dxy = p.defaultxy;
+        ok = ok && (nobserve[o1] == ndetect[o1]);
+        int r0 = 0, r1 = 0, c0 = 0, c1 = 0;
+        if (ok) {
+            py_slice(x - dxy, x + dxy, h, &r0, &r1);
+            py_slice(y - dxy, y + dxy, w, &c0, &c1);
+        }
+        box[0] = r0; box[1] = r1; box[2] = c0; box[3] = c1;
+    }
+    __syncthreads();
+    int r0 = box[0], r1 = box[1], c0 = box[2], c1 = box[3];
+    int nr = r1 - r0, nc = c1 - c0;
+    if (nr <= 0 || nc <= 0) return;
+    float *img = frames + (size_t)f * h * w;
+    for (int k = threadIdx.x; k < nr * nc; k += blockDim.x) {
+        int r = r0 + k / nc, c = c0 + k % nc;
+        img[(size_t)r * w + c] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// prep: gray = saturate_u8(round_half_even(|mask(x)|)), rows optionally flipped, plus the
+// 256-bin histogram equalizeHist needs.  16 B per lane loads (4 x f32), packed 4 x u8 stores.
+// mode bit 0: x<0 -> 0 (bright); bit 1: x<minFlux -> 0, x>0 -> x+addFlux (dim).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned sat_u8_f32(float x) {
+    float a = fabsf(x);
+    if (a != a) return 0u;
+    if (a >= 255.5f) return 255u;
+    return (unsigned)__float2int_rn(a);
+}
+__device__ __forceinline__ unsigned sat_u8_f64(double x) {
+    double a = fabs(x);
+    if (a != a) return 0u;
+    if (a >= 255.5) return 255u;
+    return (unsigned)__double2int_rn(a);
+}
+__device__ __forceinline__ unsigned prep_f32(float x, int mode, float mf, float af) {
+    if (mode & 1) { if (x < 0.0f) x = 0.0f; }
+    if (mode & 2) { if (x < mf) x = 0.0f; if (x > 0.0f) x = __fadd_rn(x, af); }
+    return sat_u8_f32(x);
+}
+__device__ __forceinline__ unsigned prep_f64(double x, int mode, double mf, double af) {
+    if (mode & 1) { if (x < 0.0) x = 0.0; }
+    if (mode & 2) { if (x < mf) x = 0.0; if (x > 0.0) x = __dadd_rn(x, af); }
+    return sat_u8_f64(x);
+}
+
+#define PREP_ROWS 4
+
+__global__ void __launch_bounds__(256)
+k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double minFlux,
+            double addFlux, uint8_t *gray, int *hist, const int *active) {
+    int g = blockIdx.y;
+    if (active && !active[g]) return;
+    __shared__ int sh[4][256];
+    for (int k = threadIdx.x; k < 1024; k += 256) ((int *)sh)[k] = 0;
+    __syncthreads();
+    int wv = threadIdx.x >> 6;
+    size_t N = (size_t)h * w;
+    uint8_t *gout = gray + (size_t)g * N;
+    int zeros = 0;
+    int r0 = blockIdx.x * PREP_ROWS;
+    float mf = (float)minFlux, af = (float)addFlux;
+    for (int r = r0; r < r0 + PREP_ROWS && r < h; r++) {
+        int sr = flip ? (h - 1 - r) : r;
+        if (dtype == 1 && (w & 3) == 0) {
+            const float4 *s = (const float4 *)((const float *)src + (size_t)g * N + (size_t)sr * w);
+            uchar4 *d = (uchar4 *)(gout + (size_t)r * w);
+            for (int x4 = threadIdx.x; x4 < (w >> 2); x4 += 256) {
+                float4 v = s[x4];
+                unsigned a = prep_f32(v.x, mode, mf, af), b = prep_f32(v.y, mode, mf, af),
+                         c = prep_f32(v.z, mode, mf, af), e = prep_f32(v.w, mode, mf, af);
+                d[x4] = make_uchar4((unsigned char)a, (unsigned char)b, (unsigned char)c, (unsigned char)e);
+                if (a) atomicAdd(&sh[wv][a], 1); else zeros++;
+                if (b) atomicAdd(&sh[wv][b], 1); else zeros++;
+                if (c) atomicAdd(&sh[wv][c], 1); else zeros++;
+                if (e) atomicAdd(&sh[wv][e], 1); else zeros++;
+            }
+        } else {
+            for (int x = threadIdx.x; x < w; x += 256) {
+                unsigned a;
+                size_t k = (size_t)g * N + (size_t)sr * w + x;
+                if (dtype == 0) a = ((const uint8_t *)src)[k];
+                else if (dtype == 1) a = prep_f32(((const float *)src)[k], mode, mf, af);
+                else a = prep_f64(((const double *)src)[k], mode, minFlux, addFlux);
+                gout[(size_t)r * w + x] = (uint8_t)a;
+                if (a) atomicAdd(&sh[wv][a], 1); else zeros++;
+            }
+        }
+    }
+    // zeros dominate sky frames: count them in registers, one LDS add per wave
+    for (int off = 32; off > 0; off >>= 1) zeros += __shfl_down(zeros, off);
+    if (lfd_lane() == 0 && zeros) atomicAdd(&sh[wv][0], zeros);
+    __syncthreads();
+    int b = threadIdx.x;
+    int s = sh[0][b] + sh[1][b] + sh[2][b] + sh[3][b];
+    if (s) atomicAdd(&hist[g * 256 + b], s);
+}
+
+// histogram only (for lfdmi_equalize_hist on an existing u8 image)
+__global__ void __launch_bounds__(256)
+k_hist_u8(const uint8_t *src, size_t N, int *hist) {
+    int g = blockIdx.y;
+    __shared__ int sh[256];
+    sh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint8_t *s = src + (size_t)g * N;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < N; k += (size_t)gridDim.x * 256)
+        atomicAdd(&sh[s[k]], 1);
+    __syncthreads();
+    if (sh[threadIdx.x]) atomicAdd(&hist[g * 256 + threadIdx.x], sh[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------
+// equalizeHist LUT (OpenCV: first non-empty bin i, scale = 255.f/(total-hist[i]),
+// lut[b] = saturate(round(float(sum_{i<k<=b} hist[k]) * scale))).  One workgroup per frame.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_lut(const int *hist, int total, uint8_t *lut, const int *active) {
+    int g = blockIdx.x, t = threadIdx.x;
+    if (active && !active[g]) return;
+    __shared__ int cum[256];
+    __shared__ int first;
+    int hv = hist[g * 256 + t];
+    cum[t] = hv;
+    if (t == 0) first = 256;
+    __syncthreads();
+    if (hv) atomicMin(&first, t);
+    for (int off = 1; off < 256; off <<= 1) {
+        int v = (t >= off) ? cum[t - off] : 0;
+        __syncthreads();
+        cum[t] += v;
+        __syncthreads();
+    }
+    int f = first;
+    if (f >= 256) { lut[g * 256 + t] = 0; return; }
+    int hf = hist[g * 256 + f];
+    unsigned out;
+    if (hf == total) out = (unsigned)f;
+    else if (t <= f) out = 0;
+    else {
+        float scale = __fdiv_rn(255.f, (float)(total - hf));
+        out = sat_u8_f32(__fmul_rn((float)(cum[t] - cum[f]), scale));
+    }
+    lut[g * 256 + t] = (uint8_t)out;
+}
+
+__global__ void __launch_bounds__(256)
+k_apply_lut(const uint8_t *src, const uint8_t *lut, uint8_t *dst, size_t N) {
+    int g = blockIdx.y;
+    __shared__ uint8_t l[256];
+    l[threadIdx.x] = lut[g * 256 + threadIdx.x];
+    __syncthreads();
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < N; k += (size_t)gridDim.x * 256)
+        dst[(size_t)g * N + k] = l[src[(size_t)g * N + k]];
+}
+
+// ------------------------------------------------------------------------------------------
+// erode / dilate with an all-ones kh x kw kernel: separable running min/max staged in LDS.
+// dst(y,x) = op over dy<kh, dx<kw of src(y+dy-kh/2, x+dx-kw/2), out-of-image samples ignored.
+// Optional monotone LUT applied on the way out (equalizeHist commutes with min/max because
+// the LUT is non-decreasing), and optional "!= 0" bit-mask for the Hough pixel list.
+// ------------------------------------------------------------------------------------------
+#define MORPH_TW 64
+#define MORPH_TH 32
+
+template <int OP> // 0 dilate (max), 1 erode (min)
+__global__ void __launch_bounds__(256)
+k_morph_rect(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, int h, int w, int kh,
+             int kw, const int *active) {
+    int g = blockIdx.z;
+    if (active && !active[g]) return;
+    extern __shared__ uint8_t sm[];
+    const int IH = MORPH_TH + kh - 1, IW = MORPH_TW + kw - 1;
+    uint8_t *tin = sm;                     // IH x IW
+    uint8_t *tmp = sm + ((IH * IW + 15) & ~15); // IH x MORPH_TW
+    __shared__ uint8_t slut[256];
+    const int fill = OP ? 255 : 0;
+    int x0 = blockIdx.x * MORPH_TW, y0 = blockIdx.y * MORPH_TH;
+    int ay = kh / 2, ax = kw / 2;
+    size_t N = (size_t)h * w;
+    const uint8_t *s = src + (size_t)g * N;
+    if (lut) slut[threadIdx.x] = lut[g * 256 + threadIdx.x];
+    for (int idx = threadIdx.x; idx < IH * IW; idx += 256) {
+        int iy = idx / IW, ix = idx - iy * IW;
+        int gy = y0 + iy - ay, gx = x0 + ix - ax;
+        int v = fill;
+        if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = s[(size_t)gy * w + gx];
+        tin[idx] = (uint8_t)v;
+    }
+    __syncthreads();
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int ry = wv; ry < IH; ry += 4) {
+        int m = fill;
+        const uint8_t *row = tin + ry * IW + lane;
+        for (int dx = 0; dx < kw; dx++) {
+            int v = row[dx];
+            m = OP ? min(m, v) : max(m, v);
+        }
+        tmp[ry * MORPH_TW + lane] = (uint8_t)m;
+    }
+    __syncthreads();
+    int wq = LFD_WQ(w);
+    for (int oy = wv; oy < MORPH_TH; oy += 4) {
+        int m = fill;
+        for (int dy = 0; dy < kh; dy++) {
+            int v = tmp[(oy + dy) * MORPH_TW + lane];
+            m = OP ? min(m, v) : max(m, v);
+        }
+        int gy = y0 + oy, gx = x0 + lane;
+        bool valid = gy < h && gx < w;
+        int out = lut ? slut[m] : m;
+        if (valid) dst[(size_t)g * N + (size_t)gy * w + gx] = (uint8_t)out;
+        if (bits) {
+            u64 bal = __ballot(valid && out != 0);
+            if (lane == 0 && gy < h) bits[(size_t)g * h * wq + (size_t)gy * wq + blockIdx.x] = bal;
+        }
+    }
+}
+
+// arbitrary 0/1 structuring element (the knob is an array: detecttrails.py:205,220-221)
+template <int OP>
+__global__ void __launch_bounds__(256)
+k_morph_generic(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut,
+                const uint8_t *kernel, int h, int w, int kh, int kw, const int *active) {
+    int g = blockIdx.z;
+    if (active && !active[g]) return;
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int gx = blockIdx.x * 64 + lane, gy = blockIdx.y * 4 + wv;
+    size_t N = (size_t)h * w;
+    const uint8_t *s = src + (size_t)g * N;
+    int ay = kh / 2, ax = kw / 2;
+    int m = OP ? 255 : 0;
+    bool valid = gx < w && gy < h;
+    if (valid)
+        for (int dy = 0; dy < kh; dy++) {
+            int yy = gy + dy - ay;
+            if (yy < 0 || yy >= h) continue;
+            for (int dx = 0; dx < kw; dx++) {
+                if (!kernel[dy * kw + dx]) continue;
+                int xx = gx + dx - ax;
+                if (xx < 0 || xx >= w) continue;
+                int v = s[(size_t)yy * w + xx];
+                m = OP ? min(m, v) : max(m, v);
+            }
+        }
+    int out = lut ? lut[g * 256 + m] : m;
+    if (valid) dst[(size_t)g * N + (size_t)gy * w + gx] = (uint8_t)out;
+    if (bits) {
+        int wq = LFD_WQ(w);
+        u64 bal = __ballot(valid && out != 0);
+        if (lane == 0 && gy < h) bits[(size_t)g * h * wq + (size_t)gy * wq + blockIdx.x] = bal;
+    }
+}
+
+// u8 image -> "!= 0" bit rows (standalone HoughLines entry point)
+__global__ void __launch_bounds__(256)
+k_bits_from_u8(const uint8_t *src, u64 *bits, int h, int w) {
+    int g = blockIdx.z;
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int gx = blockIdx.x * 64 + lane, gy = blockIdx.y * 4 + wv;
+    bool valid = gx < w && gy < h;
+    int v = valid ? src[(size_t)g * h * w + (size_t)gy * w + gx] : 0;
+    u64 bal = __ballot(v != 0);
+    int wq = LFD_WQ(w);
+    if (lane == 0 && gy < h) bits[(size_t)g * h * wq + (size_t)gy * wq + blockIdx.x] = bal;
+}
+
+// bit rows -> 0/255 u8 image
+__global__ void __launch_bounds__(256)
+k_u8_from_bits(const u64 *bits, uint8_t *dst, int h, int w) {
+    int g = blockIdx.z;
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int gx = blockIdx.x * 64 + lane, gy = blockIdx.y * 4 + wv;
+    int wq = LFD_WQ(w);
+    if (gx < w && gy < h) {
+        u64 b = bits[(size_t)g * h * wq + (size_t)gy * wq + blockIdx.x];
+        dst[(size_t)g * h * w + (size_t)gy * w + gx] = ((b >> lane) & 1ull) ? 255 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Canny, first half: Sobel 3x3 (replicate border) -> L1 magnitude -> non-maximum suppression
+// with OpenCV's fixed-point tan(22.5 deg) sector test -> two bit rows per image row:
+// cand (passes NMS and mag > low) and strong (cand and mag > high).  64 x 16 tile per
+// workgroup staged in LDS with a 2-px halo; one wave == 64 consecutive columns so a
+// __ballot is exactly one output word.
+// ------------------------------------------------------------------------------------------
+#define CANNY_TW 64
+#define CANNY_TH 16
+
+__global__ void __launch_bounds__(256)
+k_canny_nms(const uint8_t *img, u64 *cand, u64 *strong, int h, int w, int low, int high,
+            const int *active) {
+    int g = blockIdx.z;
+    if (active && !active[g]) return;
+    const int PW = CANNY_TW + 4, PH = CANNY_TH + 4, MW = CANNY_TW + 2, MH = CANNY_TH + 2;
+    __shared__ uint8_t px[PH * PW];
+    __shared__ int mg[MH * MW];
+    int x0 = blockIdx.x * CANNY_TW, y0 = blockIdx.y * CANNY_TH;
+    const uint8_t *s = img + (size_t)g * h * w;
+    for (int idx = threadIdx.x; idx < PH * PW; idx += 256) {
+        int ty = idx / PW, tx = idx - ty * PW;
+        int gy = min(max(y0 - 2 + ty, 0), h - 1), gx = min(max(x0 - 2 + tx, 0), w - 1);
+        px[idx] = s[(size_t)gy * w + gx];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < MH * MW; idx += 256) {
+        int my = idx / MW, mx = idx - my * MW;
+        int gy = y0 - 1 + my, gx = x0 - 1 + mx;
+        int m = 0;
+        if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
+            const uint8_t *p = px + my * PW + mx; // top-left of the 3x3 window
+            int dx = (p[2] - p[0]) + 2 * (p[PW + 2] - p[PW]) + (p[2 * PW + 2] - p[2 * PW]);
+            int dy = (p[2 * PW] - p[0]) + 2 * (p[2 * PW + 1] - p[1]) + (p[2 * PW + 2] - p[2]);
+            m = abs(dx) + abs(dy);
+        }
+        mg[idx] = m;
+    }
+    __syncthreads();
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int wq = LFD_WQ(w);
+    for (int oy = wv; oy < CANNY_TH; oy += 4) {
+        int gy = y0 + oy, gx = x0 + lane;
+        bool keep = false, str = false;
+        if (gy < h && gx < w) {
+            const int *mc = mg + (oy + 1) * MW + (lane + 1);
+            int m = mc[0];
+            if (m > low) {
+                const uint8_t *p = px + (oy + 1) * PW + (lane + 1);
+                int xs = (p[2] - p[0]) + 2 * (p[PW + 2] - p[PW]) + (p[2 * PW + 2] - p[2 * PW]);
+                int ys = (p[2 * PW] - p[0]) + 2 * (p[2 * PW + 1] - p[1]) + (p[2 * PW + 2] - p[2]);
+                int ax = abs(xs), ay = abs(ys) << 15;
+                int tg22x = ax * 13573;
+                if (ay < tg22x) {
+                    keep = (m > mc[-1]) && (m >= mc[1]);
+                } else {
+                    int tg67x = tg22x + (ax << 16);
+                    if (ay > tg67x) {
+                        keep = (m > mc[-MW]) && (m >= mc[MW]);
+                    } else {
+                        int sgn = ((xs ^ ys) < 0) ? -1 : 1;
+                        keep = (m > mc[-MW - sgn]) && (m > mc[MW + sgn]);
+                    }
+                }
+                str = keep && (m > high);
+            }
+        }
+        u64 bc = __ballot(keep), bs = __ballot(str);
+        if (lane == 0 && gy < h) {
+            size_t o = (size_t)g * h * wq + (size_t)gy * wq + blockIdx.x;
+            cand[o] = bc;
+            strong[o] = bs;
+        }
+    }
+}

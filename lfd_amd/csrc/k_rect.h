@@ -1,0 +1,468 @@
+// k_rect.h -- contour keys -> per-row extremes -> convex hull -> rotating calipers
+// (cv2.minAreaRect) -> lfd's side / elongation filter -> cv2.boxPoints -> int32 truncation ->
+// cv2.fillPoly into a bit-row box image.  Reference: processfield.py:248-261.
+//
+// A "key" is one contour of cv2.findContours(RETR_LIST): an 8-connected edge component
+// (its outer border) or a hole (its hole border), see k_ccl.h.  Only the strictly convex hull
+// of a contour matters downstream, and a hull vertex is always the left-most or right-most
+// contour point of its row, so each key keeps (xmin, xmax) per row ("slots") and the hull is
+// two monotone chains over those.  Float arithmetic restates OpenCV's rotcalipers.cpp in
+// float32 evaluation order (compile with -ffp-contract=off).
+#pragma once
+#include "common.h"
+
+#define KEY_HOLE_BIT (1 << 30)
+
+__global__ void __launch_bounds__(256)
+k_keys(const u64 *edge, const int *Lf, const int *YMf, const int *Lb, const int *YMb,
+       const int *FLb, int *SBf, int *SBb, int *PAb, int4 *keys, int2 *rowext, int *counters,
+       int h, int w, int key_cap, int slot_cap, const int *active) {
+    int g = blockIdx.y;
+    if (active && !active[g]) return;
+    int wq = LFD_WQ(w);
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= h * wq) return;
+    int y = idx / wq, q = idx - y * wq;
+    const u64 *row = edge + (size_t)g * h * wq + (size_t)y * wq;
+    size_t N = (size_t)h * w;
+    int *cnt = counters + g * C_COUNT;
+    int4 *kg = keys + (size_t)g * key_cap;
+    int2 *re = rowext + (size_t)g * slot_cap;
+    for (int val = 1; val >= 0; val--) {
+        u64 s = start_bits(row, q, val, w);
+        while (s) {
+            int b = __ffsll((long long)s) - 1;
+            s &= s - 1;
+            int x = (q << 6) + b;
+            int p = y * w + x;
+            int ymin, extent, parent = -1;
+            if (val) {
+                if (Lf[g * N + p] != p) continue;
+                ymin = y;
+                extent = YMf[g * N + p] - y + 1;
+            } else {
+                if (Lb[g * N + p] != p || FLb[g * N + p]) continue;
+                // hole: border rows run from the row above its first pixel to the row below its last
+                ymin = y - 1;
+                extent = YMb[g * N + p] - y + 3;
+                parent = Lf[g * N + (size_t)(y - 1) * w + run_start(row - wq, x, 1)];
+            }
+            int base = atomicAdd(&cnt[C_NSLOTS], extent);
+            int ki = atomicAdd(&cnt[C_NKEYS], 1);
+            if (base + extent > slot_cap || ki >= key_cap) {
+                cnt[C_OVERFLOW] = 1;
+                if (val) SBf[g * N + p] = -1; else SBb[g * N + p] = -1;
+                continue;
+            }
+            if (val) SBf[g * N + p] = base;
+            else { SBb[g * N + p] = base; PAb[g * N + p] = parent; }
+            kg[ki] = make_int4(p, extent | (val ? 0 : KEY_HOLE_BIT), ymin, base);
+            for (int r = 0; r < extent; r++) re[base + r] = make_int2(0x7fffffff, -1);
+        }
+    }
+}
+
+__device__ __forceinline__ void slot_update(int2 *re, int slot, int xa, int xb) {
+    atomicMin(&re[slot].x, xa);
+    atomicMax(&re[slot].y, xb);
+}
+
+// Every edge run contributes to the outer-border key of its component, and to the hole-border
+// key of every hole it is 4-adjacent to (if its component is that hole's surrounding one).
+__global__ void __launch_bounds__(256)
+k_extremes(const u64 *edge, const int *Lf, const int *Lb, const int *FLb, const int *SBf,
+           const int *SBb, const int *PAb, int2 *rowext, int h, int w, int slot_cap,
+           const int *active) {
+    int g = blockIdx.y;
+    if (active && !active[g]) return;
+    int wq = LFD_WQ(w);
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= h * wq) return;
+    int y = idx / wq, q = idx - y * wq;
+    const u64 *row = edge + (size_t)g * h * wq + (size_t)y * wq;
+    size_t N = (size_t)h * w;
+    const int *Lfg = Lf + g * N, *Lbg = Lb + g * N, *FLbg = FLb + g * N, *SBfg = SBf + g * N,
+              *SBbg = SBb + g * N, *PAbg = PAb + g * N;
+    int2 *re = rowext + (size_t)g * slot_cap;
+    u64 s = start_bits(row, q, 1, w);
+    while (s) {
+        int b = __ffsll((long long)s) - 1;
+        s &= s - 1;
+        int xs = (q << 6) + b;
+        int xe = run_end(row, xs, 1, w);
+        int A = Lfg[y * w + xs];
+        int baseA = SBfg[A];
+        if (baseA >= 0) slot_update(re, baseA + (y - A / w), xs, xe);
+        // same-row neighbours
+        if (xs > 0) {
+            int B = Lbg[y * w + run_start(row, xs - 1, 0)];
+            if (!FLbg[B] && PAbg[B] == A && SBbg[B] >= 0) slot_update(re, SBbg[B] + (y - (B / w - 1)), xs, xs);
+        }
+        if (xe < w - 1) {
+            int B = Lbg[y * w + xe + 1];
+            if (!FLbg[B] && PAbg[B] == A && SBbg[B] >= 0) slot_update(re, SBbg[B] + (y - (B / w - 1)), xe, xe);
+        }
+        // rows above and below: 0-runs overlapping [xs, xe]
+        for (int dy = -1; dy <= 1; dy += 2) {
+            int yy = y + dy;
+            if (yy < 0 || yy >= h) continue;
+            const u64 *orow = row + dy * wq;
+            int x = xs;
+            while (x <= xe) {
+                if (get_bit(orow, x)) { x = run_end(orow, x, 1, w) + 1; continue; }
+                int ge = run_end(orow, x, 0, w);
+                int gs0 = run_start(orow, x, 0);
+                if (ge > xe) ge = xe;
+                int B = Lbg[yy * w + gs0];
+                if (!FLbg[B] && PAbg[B] == A && SBbg[B] >= 0)
+                    slot_update(re, SBbg[B] + (y - (B / w - 1)), x, ge);
+                x = ge + 1;
+            }
+        }
+    }
+}
+
+// ---- minAreaRect on a hull given through an accessor -------------------------------------
+struct HullView {
+    const int2 *c1; // chain 1 (left side, rows increasing)
+    const int2 *c2; // chain 2 (right side, rows decreasing), already trimmed
+    int n1, n, s0;  // n = total vertices, s0 = rotation so that vertex 0 is (min x, then min y)
+    __device__ __forceinline__ int2 raw(int i) const { return i < n1 ? c1[i] : c2[i - n1]; }
+    __device__ __forceinline__ int2 at(int i) const {
+        int k = i + s0;
+        if (k >= n) k -= n;
+        return raw(k);
+    }
+    __device__ __forceinline__ float px(int i) const { return (float)at(i).x; }
+    __device__ __forceinline__ float py(int i) const { return (float)at(i).y; }
+};
+
+__device__ __forceinline__ void hv_vect(const HullView &hv, int i, float *vx, float *vy, float *inv) {
+    int j = (i + 1 < hv.n) ? i + 1 : 0;
+    int2 a = hv.at(i), b = hv.at(j);
+    double dx = (double)__fsub_rn((float)b.x, (float)a.x);
+    double dy = (double)__fsub_rn((float)b.y, (float)a.y);
+    *vx = (float)dx;
+    *vy = (float)dy;
+    *inv = (float)(1. / sqrt(dx * dx + dy * dy));
+}
+
+// rotcalipers.cpp CALIPERS_MINAREARECT, n > 2.  out = corner, vec1, vec2 (6 floats).
+__device__ void rotating_calipers_dev(const HullView &hv, float *out) {
+    int n = hv.n;
+    float minarea = 3.402823466e+38f;
+    int buf_i0 = 0, buf_i5 = 0;
+    float buf1 = 0, buf2 = 0, buf3 = 0, buf4 = 0;
+    int left = 0, bottom = 0, right = 0, top = 0;
+    int seq[4];
+    float orientation = 0, base_a, base_b = 0;
+    float left_x, right_x, top_y, bottom_y;
+    left_x = right_x = hv.px(0);
+    top_y = bottom_y = hv.py(0);
+    for (int i = 0; i < n; i++) {
+        float x = hv.px(i), y = hv.py(i);
+        if (x < left_x) { left_x = x; left = i; }
+        if (x > right_x) { right_x = x; right = i; }
+        if (y > top_y) { top_y = y; top = i; }
+        if (y < bottom_y) { bottom_y = y; bottom = i; }
+    }
+    {
+        float vx, vy, il;
+        hv_vect(hv, n - 1, &vx, &vy, &il);
+        double ax = vx, ay = vy;
+        for (int i = 0; i < n; i++) {
+            hv_vect(hv, i, &vx, &vy, &il);
+            double bx = vx, by = vy;
+            double convexity = ax * by - ay * bx;
+            if (convexity != 0) { orientation = (convexity > 0) ? 1.f : (-1.f); break; }
+            ax = bx; ay = by;
+        }
+    }
+    base_a = orientation;
+    seq[0] = bottom; seq[1] = right; seq[2] = top; seq[3] = left;
+    float vx[4], vy[4], il[4];
+    for (int i = 0; i < 4; i++) hv_vect(hv, seq[i], &vx[i], &vy[i], &il[i]);
+    for (int k = 0; k < n; k++) {
+        float dp[4];
+        dp[0] = __fadd_rn(__fmul_rn(+base_a, vx[0]), __fmul_rn(base_b, vy[0]));
+        dp[1] = __fadd_rn(__fmul_rn(-base_b, vx[1]), __fmul_rn(base_a, vy[1]));
+        dp[2] = __fsub_rn(__fmul_rn(-base_a, vx[2]), __fmul_rn(base_b, vy[2]));
+        dp[3] = __fsub_rn(__fmul_rn(+base_b, vx[3]), __fmul_rn(base_a, vy[3]));
+        float maxcos = __fmul_rn(dp[0], il[0]);
+        int main_element = 0;
+        for (int i = 1; i < 4; ++i) {
+            float cosalpha = __fmul_rn(dp[i], il[i]);
+            if (cosalpha > maxcos) { main_element = i; maxcos = cosalpha; }
+        }
+        {
+            float lead_x = __fmul_rn(vx[main_element], il[main_element]);
+            float lead_y = __fmul_rn(vy[main_element], il[main_element]);
+            switch (main_element) {
+            case 0: base_a = lead_x; base_b = lead_y; break;
+            case 1: base_a = lead_y; base_b = -lead_x; break;
+            case 2: base_a = -lead_x; base_b = -lead_y; break;
+            default: base_a = -lead_y; base_b = lead_x; break;
+            }
+        }
+        // unrolled select keeps seq/vx/vy/il in registers (no dynamically indexed arrays)
+        for (int i = 0; i < 4; i++)
+            if (i == main_element) {
+                int sidx = seq[i] + 1;
+                if (sidx == n) sidx = 0;
+                seq[i] = sidx;
+                hv_vect(hv, sidx, &vx[i], &vy[i], &il[i]);
+            }
+        {
+            float dx = __fsub_rn(hv.px(seq[1]), hv.px(seq[3]));
+            float dy = __fsub_rn(hv.py(seq[1]), hv.py(seq[3]));
+            float width = __fadd_rn(__fmul_rn(dx, base_a), __fmul_rn(dy, base_b));
+            dx = __fsub_rn(hv.px(seq[2]), hv.px(seq[0]));
+            dy = __fsub_rn(hv.py(seq[2]), hv.py(seq[0]));
+            float height = __fadd_rn(__fmul_rn(-dx, base_b), __fmul_rn(dy, base_a));
+            float area = __fmul_rn(width, height);
+            if (area <= minarea) {
+                minarea = area;
+                buf_i0 = seq[3]; buf1 = base_a; buf2 = width; buf3 = base_b; buf4 = height;
+                buf_i5 = seq[0];
+            }
+        }
+    }
+    {
+        float A1 = buf1, B1 = buf3, A2 = -buf3, B2 = buf1;
+        float C1 = __fadd_rn(__fmul_rn(A1, hv.px(buf_i0)), __fmul_rn(hv.py(buf_i0), B1));
+        float C2 = __fadd_rn(__fmul_rn(A2, hv.px(buf_i5)), __fmul_rn(hv.py(buf_i5), B2));
+        float idet = __fdiv_rn(1.f, __fsub_rn(__fmul_rn(A1, B2), __fmul_rn(A2, B1)));
+        float px = __fmul_rn(__fsub_rn(__fmul_rn(C1, B2), __fmul_rn(C2, B1)), idet);
+        float py = __fmul_rn(__fsub_rn(__fmul_rn(A1, C2), __fmul_rn(A2, C1)), idet);
+        out[0] = px; out[1] = py;
+        out[2] = __fmul_rn(A1, buf2); out[3] = __fmul_rn(B1, buf2);
+        out[4] = __fmul_rn(A2, buf4); out[5] = __fmul_rn(B2, buf4);
+    }
+}
+
+__device__ __forceinline__ long long cross_i(int2 o, int2 a, int2 b) {
+    return (long long)(a.x - o.x) * (b.y - o.y) - (long long)(a.y - o.y) * (b.x - o.x);
+}
+
+// One thread per key (grid-stride): hull -> minAreaRect -> filter -> boxPoints -> quad.
+// rects (optional, 5 floats per key in key order) is for the per-operator parity test.
+__global__ void __launch_bounds__(64)
+k_rects(const int4 *keys, const int2 *rowext, int2 *hullbuf, int *quads, int *counters, int h,
+        int w, int key_cap, int slot_cap, double minLen, double lwTresh, const int *active) {
+    int g = blockIdx.y;
+    if (active && !active[g]) return;
+    int *cnt = counters + g * C_COUNT;
+    int nkeys = min(cnt[C_NKEYS], key_cap);
+    const int4 *kg = keys + (size_t)g * key_cap;
+    const int2 *re = rowext + (size_t)g * slot_cap;
+    int2 *hb = hullbuf + (size_t)g * slot_cap * 2;
+    for (int ki = blockIdx.x * blockDim.x + threadIdx.x; ki < nkeys; ki += gridDim.x * blockDim.x) {
+        int4 key = kg[ki];
+        int extent = key.y & ~KEY_HOLE_BIT, ymin = key.z, base = key.w;
+        int2 *c1 = hb + 2 * (size_t)base, *c2 = c1 + extent;
+        int n1 = 0, n2 = 0;
+        for (int r = 0; r < extent; r++) {
+            int2 e = re[base + r];
+            if (e.x > e.y) continue;
+            int2 p = make_int2(e.x, ymin + r);
+            while (n1 >= 2 && cross_i(c1[n1 - 2], c1[n1 - 1], p) >= 0) n1--;
+            c1[n1++] = p;
+        }
+        for (int r = extent - 1; r >= 0; r--) {
+            int2 e = re[base + r];
+            if (e.x > e.y) continue;
+            int2 p = make_int2(e.y, ymin + r);
+            while (n2 >= 2 && cross_i(c2[n2 - 2], c2[n2 - 1], p) >= 0) n2--;
+            c2[n2++] = p;
+        }
+        if (n1 == 0) continue;
+        // drop the vertices the two chains share at the bottom and at the top
+        int a = 0, bnd = n2;
+        if (c2[0].x == c1[n1 - 1].x && c2[0].y == c1[n1 - 1].y) a = 1;
+        if (bnd > a && c2[bnd - 1].x == c1[0].x && c2[bnd - 1].y == c1[0].y) bnd--;
+        HullView hv;
+        hv.c1 = c1; hv.c2 = c2 + a; hv.n1 = n1; hv.n = n1 + (bnd - a); hv.s0 = 0;
+        if (hv.n < 1) continue;
+        int s0 = 0;
+        int2 best = hv.raw(0);
+        for (int i = 1; i < hv.n; i++) {
+            int2 v = hv.raw(i);
+            if (v.x < best.x || (v.x == best.x && v.y < best.y)) { best = v; s0 = i; }
+        }
+        hv.s0 = s0;
+        float cx = 0, cy = 0, sw = 0, sh = 0, angle = 0;
+        if (hv.n > 2) {
+            float out[6];
+            rotating_calipers_dev(hv, out);
+            cx = __fadd_rn(out[0], __fmul_rn(__fadd_rn(out[2], out[4]), 0.5f));
+            cy = __fadd_rn(out[1], __fmul_rn(__fadd_rn(out[3], out[5]), 0.5f));
+            sw = (float)sqrt((double)out[2] * out[2] + (double)out[3] * out[3]);
+            sh = (float)sqrt((double)out[4] * out[4] + (double)out[5] * out[5]);
+            angle = (float)atan2((double)out[3], (double)out[2]);
+        } else if (hv.n == 2) {
+            float x0 = hv.px(0), y0 = hv.py(0), x1 = hv.px(1), y1 = hv.py(1);
+            cx = __fmul_rn(__fadd_rn(x0, x1), 0.5f);
+            cy = __fmul_rn(__fadd_rn(y0, y1), 0.5f);
+            double dx = (double)__fsub_rn(x1, x0), dy = (double)__fsub_rn(y1, y0);
+            sw = (float)sqrt(dx * dx + dy * dy);
+            sh = 0;
+            angle = (float)atan2(dy, dx);
+        } else {
+            cx = hv.px(0); cy = hv.py(0);
+        }
+        angle = (float)((double)__fmul_rn(angle, 180.0f) / 3.1415926535897932384626433832795);
+        double length, width;
+        if (sw > sh) { length = sw; width = sh; } else { width = sw; length = sh; }
+        if (!(length > minLen && width > minLen)) continue;
+        if (!(length / width > lwTresh)) continue;
+        // RotatedRect::points
+        double ang = (double)angle * 3.1415926535897932384626433832795 / 180.;
+        float b = __fmul_rn((float)cos(ang), 0.5f);
+        float a_ = __fmul_rn((float)sin(ang), 0.5f);
+        float bx[8];
+        bx[0] = __fsub_rn(__fsub_rn(cx, __fmul_rn(a_, sh)), __fmul_rn(b, sw));
+        bx[1] = __fsub_rn(__fadd_rn(cy, __fmul_rn(b, sh)), __fmul_rn(a_, sw));
+        bx[2] = __fsub_rn(__fadd_rn(cx, __fmul_rn(a_, sh)), __fmul_rn(b, sw));
+        bx[3] = __fsub_rn(__fsub_rn(cy, __fmul_rn(b, sh)), __fmul_rn(a_, sw));
+        bx[4] = __fsub_rn(__fmul_rn(2.f, cx), bx[0]);
+        bx[5] = __fsub_rn(__fmul_rn(2.f, cy), bx[1]);
+        bx[6] = __fsub_rn(__fmul_rn(2.f, cx), bx[2]);
+        bx[7] = __fsub_rn(__fmul_rn(2.f, cy), bx[3]);
+        int qi = atomicAdd(&cnt[C_NQUADS], 1);
+        cnt[C_DETECT] = 1;
+        int *qd = quads + ((size_t)g * key_cap + qi) * 8;
+        for (int k = 0; k < 8; k++) qd[k] = (int)bx[k]; // np.int32: truncation toward zero
+    }
+}
+
+// ---- cv2.fillPoly of one quad into bit rows ----------------------------------------------
+__device__ __forceinline__ void set_span(u64 *rowbits, int xa, int xb) {
+    for (int k = xa >> 6; k <= (xb >> 6); k++) {
+        int lo = (k == (xa >> 6)) ? (xa & 63) : 0, hi = (k == (xb >> 6)) ? (xb & 63) : 63;
+        u64 msk = (~0ull << lo) & (~0ull >> (63 - hi));
+        atomicOr(&rowbits[k], msk);
+    }
+}
+
+__device__ bool clip_line_dev(long long width, long long height, long long *x1, long long *y1,
+                              long long *x2, long long *y2) {
+    int c1, c2;
+    long long right = width - 1, bottom = height - 1;
+    if (width <= 0 || height <= 0) return false;
+    c1 = (*x1 < 0) + (*x1 > right) * 2 + (*y1 < 0) * 4 + (*y1 > bottom) * 8;
+    c2 = (*x2 < 0) + (*x2 > right) * 2 + (*y2 < 0) * 4 + (*y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long long a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            *x1 += (long long)((double)(a - *y1) * (double)(*x2 - *x1) / (double)(*y2 - *y1));
+            *y1 = a;
+            c1 = (*x1 < 0) + (*x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            *x2 += (long long)((double)(a - *y2) * (double)(*x2 - *x1) / (double)(*y2 - *y1));
+            *y2 = a;
+            c2 = (*x2 < 0) + (*x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                *y1 += (long long)((double)(a - *x1) * (double)(*y2 - *y1) / (double)(*x2 - *x1));
+                *x1 = a;
+                c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                *y2 += (long long)((double)(a - *x2) * (double)(*y2 - *y1) / (double)(*x2 - *x1));
+                *x2 = a;
+                c2 = 0;
+            }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+
+#define FILL_BLOCKS 64
+
+__global__ void __launch_bounds__(256)
+k_fill_quads(const int *quads, const int *counters, u64 *box, int h, int w, int key_cap,
+             const int *active) {
+    int g = blockIdx.y;
+    if (active && !active[g]) return;
+    const int *cnt = counters + g * C_COUNT;
+    int nq = min(cnt[C_NQUADS], key_cap);
+    int wq = LFD_WQ(w);
+    u64 *bg = box + (size_t)g * h * wq;
+    for (int qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+        const int *v = quads + ((size_t)g * key_cap + qi) * 8;
+        long long vx[4], vy[4];
+        for (int k = 0; k < 4; k++) { vx[k] = v[2 * k]; vy[k] = v[2 * k + 1]; }
+        // outline: Line() = 8-connected Bresenham after clipLine, closed form per step
+        for (int e = 0; e < 4; e++) {
+            int e0 = (e + 3) & 3;
+            long long x1 = vx[e0], y1 = vy[e0], x2 = vx[e], y2 = vy[e];
+            bool ok = true;
+            if ((unsigned long long)x1 >= (unsigned long long)w || (unsigned long long)x2 >= (unsigned long long)w ||
+                (unsigned long long)y1 >= (unsigned long long)h || (unsigned long long)y2 >= (unsigned long long)h)
+                ok = clip_line_dev(w, h, &x1, &y1, &x2, &y2);
+            if (!ok) continue;
+            int dx = (int)(x2 - x1), dy = (int)(y2 - y1);
+            int px = (int)x1, py = (int)y1;
+            if (dx < 0) { dx = -dx; dy = -dy; px = (int)x2; py = (int)y2; }
+            int sy = dy < 0 ? -1 : 1;
+            if (dy < 0) dy = -dy;
+            bool steep = dy > dx;
+            if (steep) { int t = dx; dx = dy; dy = t; }
+            int count = dx + 1;
+            for (int i = threadIdx.x; i < count; i += 256) {
+                // number of minor steps before point i: ceil((2*dy*i - dx) / (2*dx)), >= 0
+                int minor = dx ? (int)((2ll * dy * i + dx - 1) / (2ll * dx)) : 0;
+                int x = steep ? px + minor : px + i;
+                int y = steep ? py + sy * i : py + sy * minor;
+                atomicOr(&bg[(size_t)y * wq + (x >> 6)], 1ull << (x & 63));
+            }
+        }
+        // interior: even-odd scan conversion, 16.16 fixed point (FillEdgeCollection)
+        int ey0[4], ey1[4], ne = 0;
+        long long ex[4], edx[4];
+        int ymin = 0x7fffffff, ymax = -0x7fffffff - 1;
+        long long xmin = 0x7fffffffffffffffLL, xmax = -1;
+        for (int e = 0; e < 4; e++) {
+            int e0 = (e + 3) & 3;
+            long long p0x = vx[e0] << 16, p0y = vy[e0], p1x = vx[e] << 16, p1y = vy[e];
+            if (p0y == p1y) continue;
+            if (p0y < p1y) { ey0[ne] = (int)p0y; ey1[ne] = (int)p1y; ex[ne] = p0x; }
+            else { ey0[ne] = (int)p1y; ey1[ne] = (int)p0y; ex[ne] = p1x; }
+            edx[ne] = (p1x - p0x) / (p1y - p0y);
+            long long xe = ex[ne] + (long long)(ey1[ne] - ey0[ne]) * edx[ne];
+            ymin = min(ymin, ey0[ne]); ymax = max(ymax, ey1[ne]);
+            xmin = min(xmin, min(ex[ne], xe)); xmax = max(xmax, max(ex[ne], xe));
+            ne++;
+        }
+        if (ne < 2) continue;
+        if (ymax < 0 || ymin >= h || xmax < 0 || xmin >= ((long long)w << 16)) continue;
+        if (ymax > h) ymax = h;
+        int ystart = ymin < 0 ? 0 : ymin;
+        for (int y = ystart + threadIdx.x; y < ymax; y += 256) {
+            long long xs[4];
+            int na = 0;
+            for (int e = 0; e < 4; e++)
+                if (e < ne && ey0[e] <= y && y < ey1[e]) {
+                    long long xv = ex[e] + (long long)(y - ey0[e]) * edx[e];
+                    int k = na++;
+                    while (k > 0 && xs[k - 1] > xv) { xs[k] = xs[k - 1]; k--; }
+                    xs[k] = xv;
+                }
+            for (int k = 0; k + 1 < na; k += 2) {
+                int xa = (int)((xs[k] + 65535) >> 16);
+                int xb = (int)(xs[k + 1] >> 16);
+                if (xa < w && xb >= 0) {
+                    if (xa < 0) xa = 0;
+                    if (xb >= w) xb = w - 1;
+                    if (xa <= xb) set_span(bg + (size_t)y * wq, xa, xb);
+                }
+            }
+        }
+    }
+}

@@ -1,0 +1,812 @@
+// lfdmi.hip -- host side of liblfdmi.so: context/workspace, launch sequencing, C-ABI.
+// Device code lives in k_image.h (dense image stages), k_ccl.h (hysteresis + contour
+// topology), k_rect.h (minAreaRect / fillPoly), k_hough.h (HoughLines + check_theta).
+// Written for gfx950 only; build with -ffp-contract=off (float32 evaluation order is part of
+// the result: Hough vote bins, rotating calipers).
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lfdmi.h"
+#include "common.h"
+#include "k_ccl.h"
+#include "k_hough.h"
+#include "k_image.h"
+#include "k_rect.h"
+
+#define LFD_PI 3.1415926535897932384626433832795
+
+enum { TG_PREP = 0, TG_MORPH, TG_CANNY, TG_CCL, TG_RECT, TG_VOTE, TG_PEAKS, TG_RS, TG_COUNT };
+
+struct TimedSpan { hipEvent_t a, b; int group; };
+
+struct lfdmi_ctx {
+    int device = 0, H = 0, W = 0, G = 0, wq = 0;
+    size_t N = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::string err;
+    // dense images
+    uint8_t *gray = nullptr, *tmp = nullptr, *equ = nullptr, *lut = nullptr, *mask = nullptr;
+    int *hist = nullptr;
+    u64 *candb = nullptr, *strongb = nullptr, *edgeb = nullptr, *equb = nullptr, *boxb = nullptr;
+    // run labels (indexed by pixel index of a run start)
+    int *Lf = nullptr, *YMf = nullptr, *FLf = nullptr, *Lb = nullptr, *YMb = nullptr, *FLb = nullptr;
+    int *SBf = nullptr, *SBb = nullptr, *PAb = nullptr;
+    int4 *keys = nullptr;
+    int2 *rowext = nullptr, *hullbuf = nullptr;
+    int *quads = nullptr;
+    uint32_t *pix_equ = nullptr, *pix_box = nullptr;
+    int *accum = nullptr;
+    u64 *peaks = nullptr;
+    float *lines = nullptr, *tab = nullptr;
+    int *counters = nullptr, *need_dim = nullptr;
+    lfdmi_result *res_dev = nullptr;
+    void *stage = nullptr;
+    size_t stage_bytes = 0;
+    void *cat_dev = nullptr;
+    size_t cat_bytes = 0;
+    int key_cap = 0, slot_cap = 0;
+    size_t acc_cap = 0, peak_cap = 0, list_cap = 0;
+    // cached Hough tables
+    double tab_rho = -1, tab_theta = -1;
+    int tab_h = 0, tab_w = 0, numangle = 0, numrho = 0;
+    // timing
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> ev_pool;
+    float t_ms[TG_COUNT] = {0};
+    int t_n[TG_COUNT] = {0};
+    std::vector<void *> allocs;
+};
+
+static int fail(lfdmi_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(ctx, LFDMI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define KCHK(name)                                                                             \
+    do {                                                                                       \
+        hipError_t e_ = hipGetLastError();                                                     \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctx, LFDMI_ERR_HIP, std::string("launch ") + name + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define RET(expr)                   \
+    do {                            \
+        int rc_ = (expr);           \
+        if (rc_) return rc_;        \
+    } while (0)
+
+struct Span {
+    lfdmi_ctx *c;
+    int idx = -1;
+    Span(lfdmi_ctx *ctx, int group) : c(ctx) {
+        if (!c->timing) return;
+        TimedSpan s;
+        s.group = group;
+        for (hipEvent_t *e : {&s.a, &s.b}) {
+            if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+            else hipEventCreate(e);
+        }
+        hipEventRecord(s.a, c->stream);
+        c->spans.push_back(s);
+        idx = (int)c->spans.size() - 1;
+    }
+    ~Span() {
+        if (idx >= 0) hipEventRecord(c->spans[idx].b, c->stream);
+    }
+};
+
+static void collect_spans(lfdmi_ctx *c) {
+    for (auto &s : c->spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->t_ms[s.group] += ms; c->t_n[s.group]++; }
+        c->ev_pool.push_back(s.a);
+        c->ev_pool.push_back(s.b);
+    }
+    c->spans.clear();
+}
+
+template <typename T> static int dmalloc(lfdmi_ctx *ctx, T **p, size_t count) {
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, count * sizeof(T)));
+    ctx->allocs.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+
+static size_t next_pow2(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
+
+extern "C" int lfdmi_version(void) { return LFDMI_VERSION; }
+
+extern "C" void lfdmi_hough_dims(int h, int w, double rho_d, double theta_d, int *numangle, int *numrho) {
+    float rho = (float)rho_d, theta = (float)theta_d;
+    *numangle = (int)lrint((LFD_PI - 0.0) / theta);
+    *numrho = (int)lrint(((w + h) * 2 + 1) / rho);
+}
+
+extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflight, lfdmi_ctx **out) {
+    if (!out || max_h <= 0 || max_w <= 0 || max_inflight <= 0 || max_h > 65535 || max_w > 65535) return LFDMI_ERR_ARG;
+    lfdmi_ctx *ctx = new lfdmi_ctx();
+    *out = ctx;
+    ctx->device = device; ctx->H = max_h; ctx->W = max_w; ctx->G = max_inflight;
+    ctx->N = (size_t)max_h * max_w;
+    ctx->wq = LFD_WQ(max_w);
+    size_t N = ctx->N, G = (size_t)max_inflight, BW = (size_t)max_h * ctx->wq;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->key_cap = (int)(N / 2 + 16);
+    ctx->slot_cap = (int)(2 * N + 4 * (size_t)max_h + 16);
+    int na, nr;
+    lfdmi_hough_dims(max_h, max_w, 1.0, LFD_PI / 180, &na, &nr);
+    ctx->acc_cap = (size_t)(na + 2) * (nr + 2);
+    ctx->peak_cap = next_pow2((size_t)na * nr);
+    ctx->list_cap = N;
+    RET(dmalloc(ctx, &ctx->gray, G * N));
+    RET(dmalloc(ctx, &ctx->tmp, G * N));
+    RET(dmalloc(ctx, &ctx->equ, G * N));
+    RET(dmalloc(ctx, &ctx->lut, G * 256));
+    RET(dmalloc(ctx, &ctx->mask, (size_t)LFDMI_MAX_MORPH_K * LFDMI_MAX_MORPH_K * 2));
+    RET(dmalloc(ctx, &ctx->hist, G * 256));
+    RET(dmalloc(ctx, &ctx->candb, G * BW));
+    RET(dmalloc(ctx, &ctx->strongb, G * BW));
+    RET(dmalloc(ctx, &ctx->edgeb, G * BW));
+    RET(dmalloc(ctx, &ctx->equb, G * BW));
+    RET(dmalloc(ctx, &ctx->boxb, G * BW));
+    for (int **p : {&ctx->Lf, &ctx->YMf, &ctx->FLf, &ctx->Lb, &ctx->YMb, &ctx->FLb, &ctx->SBf, &ctx->SBb, &ctx->PAb})
+        RET(dmalloc(ctx, p, G * N));
+    RET(dmalloc(ctx, &ctx->keys, G * ctx->key_cap));
+    RET(dmalloc(ctx, &ctx->rowext, G * ctx->slot_cap));
+    RET(dmalloc(ctx, &ctx->hullbuf, G * ctx->slot_cap * 2));
+    RET(dmalloc(ctx, &ctx->quads, G * ctx->key_cap * 8));
+    RET(dmalloc(ctx, &ctx->pix_equ, G * ctx->list_cap));
+    RET(dmalloc(ctx, &ctx->pix_box, G * ctx->list_cap));
+    RET(dmalloc(ctx, &ctx->accum, G * 2 * ctx->acc_cap));
+    RET(dmalloc(ctx, &ctx->peaks, G * 2 * ctx->peak_cap));
+    RET(dmalloc(ctx, &ctx->lines, G * 2 * LFDMI_MAX_SET_LINES * 2));
+    RET(dmalloc(ctx, &ctx->tab, (size_t)2 * (na + 8)));
+    RET(dmalloc(ctx, &ctx->counters, G * C_COUNT));
+    RET(dmalloc(ctx, &ctx->need_dim, G));
+    RET(dmalloc(ctx, &ctx->res_dev, G));
+    HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    return 0;
+}
+
+extern "C" void lfdmi_ctx_destroy(lfdmi_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (void *p : ctx->allocs) hipFree(p);
+    if (ctx->stage) hipFree(ctx->stage);
+    if (ctx->cat_dev) hipFree(ctx->cat_dev);
+    for (auto e : ctx->ev_pool) hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char *lfdmi_last_error(lfdmi_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+extern "C" int lfdmi_max_inflight(lfdmi_ctx *ctx) { return ctx ? ctx->G : 0; }
+
+extern "C" int lfdmi_set_stream(lfdmi_ctx *ctx, void *hip_stream) {
+    if (!ctx) return LFDMI_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->own_stream && ctx->stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); }
+    if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    return 0;
+}
+
+extern "C" int lfdmi_enable_timing(lfdmi_ctx *ctx, int on) {
+    if (!ctx) return LFDMI_ERR_ARG;
+    ctx->timing = on != 0;
+    memset(ctx->t_ms, 0, sizeof ctx->t_ms);
+    memset(ctx->t_n, 0, sizeof ctx->t_n);
+    return 0;
+}
+extern "C" int lfdmi_get_timing(lfdmi_ctx *ctx, float *ms, int32_t *launches) {
+    if (!ctx) return LFDMI_ERR_ARG;
+    for (int i = 0; i < TG_COUNT; i++) { if (ms) ms[i] = ctx->t_ms[i]; if (launches) launches[i] = ctx->t_n[i]; }
+    return 0;
+}
+
+// ---- helpers ------------------------------------------------------------------------------
+static int check_shape(lfdmi_ctx *ctx, int n, int h, int w) {
+    if (!ctx) return LFDMI_ERR_ARG;
+    if (n < 0 || h <= 0 || w <= 0) return fail(ctx, LFDMI_ERR_ARG, "bad shape");
+    if ((size_t)h * w > ctx->N || h > 65535 || w > 65535 || LFD_WQ(w) * (size_t)h > (size_t)ctx->wq * ctx->H)
+        return fail(ctx, LFDMI_ERR_CAPACITY, "frame larger than the context was created for");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, LFDMI_ERR_HIP, "hipSetDevice");
+    return 0;
+}
+
+static int ensure_stage(lfdmi_ctx *ctx, size_t bytes) {
+    if (ctx->stage_bytes >= bytes) return 0;
+    if (ctx->stage) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(ctx->stage)); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+    HIPCHK(hipMalloc(&ctx->stage, bytes));
+    ctx->stage_bytes = bytes;
+    return 0;
+}
+
+static size_t dtype_size(int dtype) { return dtype == LFDMI_U8 ? 1 : (dtype == LFDMI_F32 ? 4 : 8); }
+
+// returns a device pointer for `count` input bytes starting at src (+ offset), staging if needed
+static int in_ptr(lfdmi_ctx *ctx, const void *src, size_t offset, size_t bytes, int loc, const void **out) {
+    if (loc == LFDMI_DEVICE) { *out = (const char *)src + offset; return 0; }
+    RET(ensure_stage(ctx, bytes));
+    HIPCHK(hipMemcpyAsync(ctx->stage, (const char *)src + offset, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *out = ctx->stage;
+    return 0;
+}
+
+static int out_copy(lfdmi_ctx *ctx, void *dst, size_t offset, const void *dev_src, size_t bytes, int loc) {
+    if (!dst) return 0;
+    HIPCHK(hipMemcpyAsync((char *)dst + offset, dev_src, bytes,
+                          loc == LFDMI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+static int sync(lfdmi_ctx *ctx) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->timing) collect_spans(ctx);
+    return 0;
+}
+
+static dim3 word_grid(int h, int w, int n) { return dim3((unsigned)((h * LFD_WQ(w) + 255) / 256), (unsigned)n); }
+
+// ---- stage runners (device pointers only, nc <= G images in workspace slots 0..nc-1) --------
+static int run_prep(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int mode,
+                    double minFlux, double addFlux, const int *active) {
+    Span sp(ctx, TG_PREP);
+    HIPCHK(hipMemsetAsync(ctx->hist, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
+    k_prep_hist<<<dim3((h + PREP_ROWS - 1) / PREP_ROWS, nc), 256, 0, ctx->stream>>>(
+        src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist, active);
+    KCHK("k_prep_hist");
+    k_lut<<<nc, 256, 0, ctx->stream>>>(ctx->hist, h * w, ctx->lut, active);
+    KCHK("k_lut");
+    return 0;
+}
+
+static bool all_ones(const uint8_t *k, int kh, int kw) {
+    for (int i = 0; i < kh * kw; i++) if (!k[i]) return false;
+    return true;
+}
+
+// dst = op(src) with optional LUT / bit rows; kernel mask on the host
+static int run_morph(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, const uint8_t *kernel,
+                     int kh, int kw, int op, int nc, int h, int w, const int *active) {
+    if (!kernel || kh <= 0 || kw <= 0 || kh > LFDMI_MAX_MORPH_K || kw > LFDMI_MAX_MORPH_K)
+        return fail(ctx, LFDMI_ERR_UNSUPPORTED, "structuring element must be 1..31 on both sides");
+    Span sp(ctx, TG_MORPH);
+    if (all_ones(kernel, kh, kw)) {
+        int IH = MORPH_TH + kh - 1, IW = MORPH_TW + kw - 1;
+        size_t lds = ((size_t)(IH * IW + 15) & ~(size_t)15) + (size_t)IH * MORPH_TW;
+        dim3 grid((w + MORPH_TW - 1) / MORPH_TW, (h + MORPH_TH - 1) / MORPH_TH, nc);
+        if (op == 0) k_morph_rect<0><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active);
+        else k_morph_rect<1><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active);
+        KCHK("k_morph_rect");
+    } else {
+        uint8_t *m = ctx->mask + (op ? LFDMI_MAX_MORPH_K * LFDMI_MAX_MORPH_K : 0);
+        HIPCHK(hipMemcpyAsync(m, kernel, (size_t)kh * kw, hipMemcpyHostToDevice, ctx->stream));
+        dim3 grid((w + 63) / 64, (h + 3) / 4, nc);
+        if (op == 0) k_morph_generic<0><<<grid, 256, 0, ctx->stream>>>(src, dst, bits, lut, m, h, w, kh, kw, active);
+        else k_morph_generic<1><<<grid, 256, 0, ctx->stream>>>(src, dst, bits, lut, m, h, w, kh, kw, active);
+        KCHK("k_morph_generic");
+    }
+    return 0;
+}
+
+// Canny = NMS bit rows + hysteresis by run labelling; leaves edge bits in ctx->edgeb and the
+// 8-connected labels of the surviving components in ctx->Lf
+static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, double low_d, double high_d, const int *active) {
+    if (low_d > high_d) { double t = low_d; low_d = high_d; high_d = t; }
+    int low = (int)floor(low_d), high = (int)floor(high_d);
+    {
+        Span sp(ctx, TG_CANNY);
+        dim3 grid((w + CANNY_TW - 1) / CANNY_TW, (h + CANNY_TH - 1) / CANNY_TH, nc);
+        k_canny_nms<<<grid, 256, 0, ctx->stream>>>(img, ctx->candb, ctx->strongb, h, w, low, high, active);
+        KCHK("k_canny_nms");
+    }
+    Span sp(ctx, TG_CCL);
+    dim3 wg = word_grid(h, w, nc);
+    k_runs_init<<<wg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->Lf, ctx->YMf, ctx->FLf, h, w, active);
+    KCHK("k_runs_init");
+    k_runs_merge8<<<wg, 256, 0, ctx->stream>>>(ctx->candb, ctx->Lf, h, w, active);
+    KCHK("k_runs_merge8");
+    k_runs_flatten<<<wg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->strongb, ctx->Lf, ctx->YMf, ctx->FLf, h, w, active);
+    KCHK("k_runs_flatten");
+    k_edge_from_cand<<<wg, 256, 0, ctx->stream>>>(ctx->candb, ctx->Lf, ctx->FLf, ctx->edgeb, h, w, active);
+    KCHK("k_edge_from_cand");
+    return 0;
+}
+
+static int zero_counters(lfdmi_ctx *ctx, int nc) {
+    HIPCHK(hipMemsetAsync(ctx->counters, 0, (size_t)nc * C_COUNT * sizeof(int), ctx->stream));
+    return 0;
+}
+
+// contours -> rectangles -> box bit rows (needs run_canny's outputs)
+static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method, double minLen, double lwTresh, const int *active) {
+    if (method != LFDMI_CHAIN_APPROX_NONE && method != LFDMI_CHAIN_APPROX_SIMPLE)
+        return fail(ctx, LFDMI_ERR_UNSUPPORTED, "contoursMethod: only CHAIN_APPROX_NONE / CHAIN_APPROX_SIMPLE");
+    if (mode != LFDMI_RETR_LIST && mode != LFDMI_RETR_CCOMP && mode != LFDMI_RETR_TREE)
+        return fail(ctx, LFDMI_ERR_UNSUPPORTED, "contoursMode: only RETR_LIST / RETR_CCOMP / RETR_TREE");
+    dim3 wg = word_grid(h, w, nc);
+    size_t BW = (size_t)h * LFD_WQ(w);
+    {
+        Span sp(ctx, TG_CCL);
+        k_runs_init<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->Lb, ctx->YMb, ctx->FLb, h, w, active);
+        KCHK("k_runs_init(bg)");
+        k_runs_merge4_bg<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lb, h, w, active);
+        KCHK("k_runs_merge4_bg");
+        k_runs_flatten<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, nullptr, ctx->Lb, ctx->YMb, ctx->FLb, h, w, active);
+        KCHK("k_runs_flatten(bg)");
+    }
+    Span sp(ctx, TG_RECT);
+    HIPCHK(hipMemsetAsync(ctx->boxb, 0, (size_t)nc * BW * sizeof(u64), ctx->stream));
+    k_keys<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lf, ctx->YMf, ctx->Lb, ctx->YMb, ctx->FLb, ctx->SBf, ctx->SBb,
+                                         ctx->PAb, ctx->keys, ctx->rowext, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, active);
+    KCHK("k_keys");
+    k_extremes<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lf, ctx->Lb, ctx->FLb, ctx->SBf, ctx->SBb, ctx->PAb, ctx->rowext,
+                                             h, w, ctx->slot_cap, active);
+    KCHK("k_extremes");
+    k_rects<<<dim3(256, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, ctx->hullbuf, ctx->quads, ctx->counters, h, w,
+                                                    ctx->key_cap, ctx->slot_cap, minLen, lwTresh, active);
+    KCHK("k_rects");
+    k_fill_quads<<<dim3(FILL_BLOCKS, nc), 256, 0, ctx->stream>>>(ctx->quads, ctx->counters, ctx->boxb, h, w, ctx->key_cap, active);
+    KCHK("k_fill_quads");
+    return 0;
+}
+
+static int ensure_tables(lfdmi_ctx *ctx, int h, int w, double rho_d, double theta_d) {
+    if (ctx->tab_rho == rho_d && ctx->tab_theta == theta_d && ctx->tab_h == h && ctx->tab_w == w) return 0;
+    float rho = (float)rho_d, theta = (float)theta_d;
+    if (!(rho > 0) || !(theta > 0)) return fail(ctx, LFDMI_ERR_ARG, "rho and theta must be positive");
+    int na, nr;
+    lfdmi_hough_dims(h, w, rho_d, theta_d, &na, &nr);
+    if (na <= 0 || nr <= 0 || (size_t)(na + 2) * (nr + 2) > ctx->acc_cap || (size_t)na * nr > ctx->peak_cap)
+        return fail(ctx, LFDMI_ERR_CAPACITY, "Hough accumulator larger than the workspace (rho < 1 px or theta < 1 deg)");
+    std::vector<float> t((size_t)2 * na);
+    float irho = 1 / rho;
+    float ang = 0.f;
+    for (int n = 0; n < na; ang += theta, n++) { // createTrigTable: float accumulation of the angle
+        t[n] = (float)(cos((double)ang) * irho);
+        t[na + n] = (float)(sin((double)ang) * irho);
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(ctx->tab, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->tab_rho = rho_d; ctx->tab_theta = theta_d; ctx->tab_h = h; ctx->tab_w = w;
+    ctx->numangle = na; ctx->numrho = nr;
+    return 0;
+}
+
+// HoughLines on equ bits (image 0) and optionally box bits (image 1); leaves accumulators and
+// unsorted peak keys in the workspace; top-K lines in ctx->lines when K > 0
+static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double theta, int threshold, int n_img, int K,
+                     int need_detect, const int *active) {
+    RET(ensure_tables(ctx, h, w, rho, theta));
+    int na = ctx->numangle, nr = ctx->numrho;
+    int stride = nr | 1;
+    int apb = (int)((152 * 1024) / ((size_t)stride * 4));
+    if (apb > 64) apb = 64;
+    if (apb < 1) return fail(ctx, LFDMI_ERR_CAPACITY, "numrho too large for one LDS row");
+    int nslabs = (na + apb - 1) / apb;
+    dim3 wg = word_grid(h, w, nc);
+    {
+        Span sp(ctx, TG_VOTE);
+        k_pixlist<<<wg, 256, 0, ctx->stream>>>(ctx->equb, ctx->pix_equ, ctx->counters, C_NPIX_EQU, h, w, ctx->list_cap, active, need_detect);
+        KCHK("k_pixlist(equ)");
+        if (n_img > 1) {
+            k_pixlist<<<wg, 256, 0, ctx->stream>>>(ctx->boxb, ctx->pix_box, ctx->counters, C_NPIX_BOX, h, w, ctx->list_cap, active, need_detect);
+            KCHK("k_pixlist(box)");
+        }
+        k_hough_vote<<<dim3(nslabs, n_img, nc), VOTE_THREADS, (size_t)apb * stride * 4, ctx->stream>>>(
+            ctx->pix_equ, ctx->pix_box, ctx->counters, ctx->tab, ctx->accum, na, nr, apb, ctx->list_cap, ctx->acc_cap, active, need_detect);
+        KCHK("k_hough_vote");
+    }
+    Span sp(ctx, TG_PEAKS);
+    k_hough_peaks<<<dim3(32, n_img, nc), 256, 0, ctx->stream>>>(ctx->accum, ctx->peaks, ctx->counters, na, nr, threshold,
+                                                                ctx->acc_cap, ctx->peak_cap, active, need_detect);
+    KCHK("k_hough_peaks");
+    if (K > 0) {
+        k_hough_topk<<<dim3(n_img, nc), 256, 0, ctx->stream>>>(ctx->peaks, ctx->counters, ctx->lines, K, nr, (float)rho, (float)theta,
+                                                               ctx->peak_cap, active, need_detect);
+        KCHK("k_hough_topk");
+    }
+    return 0;
+}
+
+static int check_params(lfdmi_ctx *ctx, const lfdmi_params *p, bool dim) {
+    if (!p) return fail(ctx, LFDMI_ERR_ARG, "params NULL");
+    if (p->nlinesInSet < 1 || p->nlinesInSet > LFDMI_MAX_SET_LINES) return fail(ctx, LFDMI_ERR_ARG, "nlinesInSet out of range");
+    if (!p->dilateKernel) return fail(ctx, LFDMI_ERR_ARG, "dilateKernel NULL");
+    if (dim && !p->erodeKernel) return fail(ctx, LFDMI_ERR_ARG, "erodeKernel NULL");
+    return 0;
+}
+
+// one detection pass on nc images already resident at src (device): fills ctx->res_dev
+static int run_pass(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int prep_mode, bool dim,
+                    const lfdmi_params *p, const int *active, int *need_dim) {
+    RET(zero_counters(ctx, nc));
+    RET(run_prep(ctx, src, dtype, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, active));
+    if (dim) {
+        RET(run_morph(ctx, ctx->gray, ctx->tmp, nullptr, nullptr, p->erodeKernel, p->erode_kh, p->erode_kw, 1, nc, h, w, active));
+        RET(run_morph(ctx, ctx->tmp, ctx->equ, ctx->equb, ctx->lut, p->dilateKernel, p->dilate_kh, p->dilate_kw, 0, nc, h, w, active));
+    } else {
+        RET(run_morph(ctx, ctx->gray, ctx->equ, ctx->equb, ctx->lut, p->dilateKernel, p->dilate_kh, p->dilate_kw, 0, nc, h, w, active));
+    }
+    RET(run_canny(ctx, ctx->equ, nc, h, w, 0, 255, active));
+    RET(run_rects(ctx, nc, h, w, p->contoursMode, p->contoursMethod, p->minAreaRectMinLen, p->lwTresh, active));
+    RET(run_hough(ctx, nc, h, w, p->houghMethod, LFD_PI / 180, 1, 2, p->nlinesInSet, 1, active));
+    TailParams tp;
+    tp.navg = p->nlinesInSet; tp.dro = p->dro; tp.thetaTresh = p->thetaTresh; tp.lineSetTresh = p->lineSetTresh;
+    tp.which = dim ? 2 : 1;
+    k_finalize<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->lines, ctx->counters, ctx->res_dev, need_dim, active, tp, nc);
+    KCHK("k_finalize");
+    return 0;
+}
+
+static void dictify(int h, int w, lfdmi_result *r) { // processfield.py:266-288, float32 scalars
+    if (!r->found) return;
+    float c = cosf(r->theta), s = sinf(r->theta);
+    float x0 = c * r->rho, y0 = s * r->rho;
+    float L = (float)(h + w);
+    r->x1 = (int32_t)(x0 - L * s);
+    r->y1 = (int32_t)(y0 + L * c);
+    r->x2 = (int32_t)(x0 + L * s);
+    r->y2 = (int32_t)(y0 - L * c);
+}
+
+// ---- C-ABI: per-operator entry points -------------------------------------------------------
+extern "C" int lfdmi_prep_u8(lfdmi_ctx *ctx, const void *src, int dtype, int n, int h, int w, int flip, int mode,
+                             double minFlux, double addFlux, uint8_t *gray, int32_t *hist, int loc) {
+    RET(check_shape(ctx, n, h, w));
+    if (!src || dtype < 0 || dtype > 2 || mode < 0 || mode > 3) return fail(ctx, LFDMI_ERR_ARG, "lfdmi_prep_u8: bad argument");
+    if (dtype == LFDMI_U8 && (mode & 2)) return fail(ctx, LFDMI_ERR_DTYPE, "dim masking needs a float image (numpy refuses uint8 += float)");
+    size_t N = (size_t)h * w, es = dtype_size(dtype);
+    for (int c0 = 0; c0 < n; c0 += ctx->G) {
+        int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
+        const void *d;
+        RET(in_ptr(ctx, src, (size_t)c0 * N * es, (size_t)nc * N * es, loc, &d));
+        RET(run_prep(ctx, d, dtype, nc, h, w, flip, mode, minFlux, addFlux, nullptr));
+        RET(out_copy(ctx, gray, (size_t)c0 * N, ctx->gray, (size_t)nc * N, loc));
+        RET(out_copy(ctx, hist, (size_t)c0 * 256 * 4, ctx->hist, (size_t)nc * 256 * 4, loc));
+        RET(sync(ctx));
+    }
+    return 0;
+}
+
+extern "C" int lfdmi_equalize_hist(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, uint8_t *dst, int loc) {
+    RET(check_shape(ctx, n, h, w));
+    if (!src || !dst) return fail(ctx, LFDMI_ERR_ARG, "NULL image");
+    size_t N = (size_t)h * w;
+    for (int c0 = 0; c0 < n; c0 += ctx->G) {
+        int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
+        const void *d;
+        RET(in_ptr(ctx, src, (size_t)c0 * N, (size_t)nc * N, loc, &d));
+        {
+            Span sp(ctx, TG_PREP);
+            HIPCHK(hipMemsetAsync(ctx->hist, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
+            k_hist_u8<<<dim3(256, nc), 256, 0, ctx->stream>>>((const uint8_t *)d, N, ctx->hist);
+            KCHK("k_hist_u8");
+            k_lut<<<nc, 256, 0, ctx->stream>>>(ctx->hist, h * w, ctx->lut, nullptr);
+            KCHK("k_lut");
+            k_apply_lut<<<dim3(512, nc), 256, 0, ctx->stream>>>((const uint8_t *)d, ctx->lut, ctx->equ, N);
+            KCHK("k_apply_lut");
+        }
+        RET(out_copy(ctx, dst, (size_t)c0 * N, ctx->equ, (size_t)nc * N, loc));
+        RET(sync(ctx));
+    }
+    return 0;
+}
+
+static int morph_api(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, const uint8_t *kernel, int kh, int kw,
+                     uint8_t *dst, int loc, int op) {
+    RET(check_shape(ctx, n, h, w));
+    if (!src || !dst) return fail(ctx, LFDMI_ERR_ARG, "NULL image");
+    size_t N = (size_t)h * w;
+    for (int c0 = 0; c0 < n; c0 += ctx->G) {
+        int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
+        const void *d;
+        RET(in_ptr(ctx, src, (size_t)c0 * N, (size_t)nc * N, loc, &d));
+        RET(run_morph(ctx, (const uint8_t *)d, ctx->equ, nullptr, nullptr, kernel, kh, kw, op, nc, h, w, nullptr));
+        RET(out_copy(ctx, dst, (size_t)c0 * N, ctx->equ, (size_t)nc * N, loc));
+        RET(sync(ctx));
+    }
+    return 0;
+}
+extern "C" int lfdmi_dilate(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, const uint8_t *kernel, int kh, int kw,
+                            uint8_t *dst, int loc) { return morph_api(ctx, src, n, h, w, kernel, kh, kw, dst, loc, 0); }
+extern "C" int lfdmi_erode(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, const uint8_t *kernel, int kh, int kw,
+                           uint8_t *dst, int loc) { return morph_api(ctx, src, n, h, w, kernel, kh, kw, dst, loc, 1); }
+
+static int expand_bits(lfdmi_ctx *ctx, const u64 *bits, uint8_t *dev_dst, int nc, int h, int w) {
+    k_u8_from_bits<<<dim3((w + 63) / 64, (h + 3) / 4, nc), 256, 0, ctx->stream>>>(bits, dev_dst, h, w);
+    KCHK("k_u8_from_bits");
+    return 0;
+}
+
+extern "C" int lfdmi_canny(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, double low, double high, uint8_t *dst, int loc) {
+    RET(check_shape(ctx, n, h, w));
+    if (!src || !dst) return fail(ctx, LFDMI_ERR_ARG, "NULL image");
+    size_t N = (size_t)h * w;
+    for (int c0 = 0; c0 < n; c0 += ctx->G) {
+        int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
+        const void *d;
+        RET(in_ptr(ctx, src, (size_t)c0 * N, (size_t)nc * N, loc, &d));
+        RET(run_canny(ctx, (const uint8_t *)d, nc, h, w, low, high, nullptr));
+        RET(expand_bits(ctx, ctx->edgeb, ctx->tmp, nc, h, w));
+        RET(out_copy(ctx, dst, (size_t)c0 * N, ctx->tmp, (size_t)nc * N, loc));
+        RET(sync(ctx));
+    }
+    return 0;
+}
+
+extern "C" int lfdmi_fit_min_area_rect(lfdmi_ctx *ctx, const uint8_t *img, int n, int h, int w, int contoursMode,
+                                       int contoursMethod, double minAreaRectMinLen, double lwTresh, uint8_t *box_img,
+                                       int32_t *detection, int32_t *n_boxes, int loc) {
+    RET(check_shape(ctx, n, h, w));
+    if (!img) return fail(ctx, LFDMI_ERR_ARG, "NULL image");
+    size_t N = (size_t)h * w;
+    std::vector<int> cnt((size_t)ctx->G * C_COUNT);
+    for (int c0 = 0; c0 < n; c0 += ctx->G) {
+        int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
+        const void *d;
+        RET(in_ptr(ctx, img, (size_t)c0 * N, (size_t)nc * N, loc, &d));
+        RET(zero_counters(ctx, nc));
+        RET(run_canny(ctx, (const uint8_t *)d, nc, h, w, 0, 255, nullptr));
+        RET(run_rects(ctx, nc, h, w, contoursMode, contoursMethod, minAreaRectMinLen, lwTresh, nullptr));
+        if (box_img) {
+            RET(expand_bits(ctx, ctx->boxb, ctx->tmp, nc, h, w));
+            RET(out_copy(ctx, box_img, (size_t)c0 * N, ctx->tmp, (size_t)nc * N, loc));
+        }
+        HIPCHK(hipMemcpyAsync(cnt.data(), ctx->counters, (size_t)nc * C_COUNT * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        RET(sync(ctx));
+        for (int i = 0; i < nc; i++) {
+            if (cnt[(size_t)i * C_COUNT + C_OVERFLOW]) return fail(ctx, LFDMI_ERR_CAPACITY, "contour workspace overflow");
+            int det = cnt[(size_t)i * C_COUNT + C_DETECT], nb = cnt[(size_t)i * C_COUNT + C_NQUADS];
+            if (loc == LFDMI_DEVICE) {
+                if (detection) HIPCHK(hipMemcpy(detection + c0 + i, &det, 4, hipMemcpyHostToDevice));
+                if (n_boxes) HIPCHK(hipMemcpy(n_boxes + c0 + i, &nb, 4, hipMemcpyHostToDevice));
+            } else {
+                if (detection) detection[c0 + i] = det;
+                if (n_boxes) n_boxes[c0 + i] = nb;
+            }
+        }
+    }
+    return 0;
+}
+
+static int hough_api(lfdmi_ctx *ctx, const uint8_t *img, int n, int h, int w, double rho, double theta, int threshold,
+                     int max_lines, float *lines, int32_t *n_lines, int32_t *accum, int loc) {
+    RET(check_shape(ctx, n, h, w));
+    if (!img) return fail(ctx, LFDMI_ERR_ARG, "NULL image");
+    RET(ensure_tables(ctx, h, w, rho, theta));
+    size_t N = (size_t)h * w;
+    int na = ctx->numangle, nr = ctx->numrho;
+    size_t acc_n = (size_t)(na + 2) * (nr + 2);
+    std::vector<int> cnt((size_t)ctx->G * C_COUNT);
+    float *lines_dev = nullptr;
+    if (lines && max_lines > 0) {
+        // device scratch for sorted lines: reuse the hull buffer (unused by this entry point)
+        if ((size_t)ctx->G * max_lines * 2 * sizeof(float) > (size_t)ctx->G * ctx->slot_cap * 2 * sizeof(int2))
+            return fail(ctx, LFDMI_ERR_CAPACITY, "max_lines too large");
+        lines_dev = (float *)ctx->hullbuf;
+    }
+    for (int c0 = 0; c0 < n; c0 += ctx->G) {
+        int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
+        const void *d;
+        RET(in_ptr(ctx, img, (size_t)c0 * N, (size_t)nc * N, loc, &d));
+        RET(zero_counters(ctx, nc));
+        k_bits_from_u8<<<dim3((w + 63) / 64, (h + 3) / 4, nc), 256, 0, ctx->stream>>>((const uint8_t *)d, ctx->equb, h, w);
+        KCHK("k_bits_from_u8");
+        RET(run_hough(ctx, nc, h, w, rho, theta, threshold, 1, 0, 0, nullptr));
+        if (accum)
+            for (int i = 0; i < nc; i++)
+                RET(out_copy(ctx, accum, (size_t)(c0 + i) * acc_n * 4, ctx->accum + (size_t)i * 2 * ctx->acc_cap, acc_n * 4, loc));
+        if (lines_dev) {
+            Span sp(ctx, TG_PEAKS);
+            k_hough_sort<<<dim3(1, nc), 1024, 0, ctx->stream>>>(ctx->peaks, ctx->counters, lines_dev, max_lines, nr, (float)rho,
+                                                               (float)theta, ctx->peak_cap);
+            KCHK("k_hough_sort");
+        }
+        HIPCHK(hipMemcpyAsync(cnt.data(), ctx->counters, (size_t)nc * C_COUNT * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        RET(sync(ctx));
+        for (int i = 0; i < nc; i++) {
+            int total = cnt[(size_t)i * C_COUNT + C_NPEAK_EQU];
+            if (n_lines) {
+                if (loc == LFDMI_DEVICE) HIPCHK(hipMemcpy(n_lines + c0 + i, &total, 4, hipMemcpyHostToDevice));
+                else n_lines[c0 + i] = total;
+            }
+            if (lines_dev) {
+                int m = total < max_lines ? total : max_lines;
+                if (m > 0)
+                    HIPCHK(hipMemcpy((char *)lines + (size_t)(c0 + i) * max_lines * 8, lines_dev + (size_t)i * max_lines * 2, (size_t)m * 8,
+                                     loc == LFDMI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+            }
+        }
+    }
+    return 0;
+}
+
+extern "C" int lfdmi_hough_lines(lfdmi_ctx *ctx, const uint8_t *img, int n, int h, int w, double rho, double theta, int threshold,
+                                 int max_lines, float *lines, int32_t *n_lines, int loc) {
+    return hough_api(ctx, img, n, h, w, rho, theta, threshold, max_lines, lines, n_lines, nullptr, loc);
+}
+extern "C" int lfdmi_hough_accum(lfdmi_ctx *ctx, const uint8_t *img, int n, int h, int w, double rho, double theta, int32_t *accum, int loc) {
+    return hough_api(ctx, img, n, h, w, rho, theta, 1, 0, nullptr, nullptr, accum, loc);
+}
+
+// catalogue arrays -> device; returns device pointers in *dev (struct copy)
+static int stage_catalog(lfdmi_ctx *ctx, const lfdmi_catalog *cat, int f0, int nc, lfdmi_catalog *dev) {
+    size_t m = (size_t)cat->max_obj;
+    *dev = *cat;
+    if (cat->loc == LFDMI_DEVICE) {
+        dev->count = cat->count + f0;
+        dev->rowc = cat->rowc + f0 * m * 5; dev->colc = cat->colc + f0 * m * 5;
+        dev->psfmag = cat->psfmag + f0 * m * 5; dev->petro90 = cat->petro90 + f0 * m * 5;
+        dev->nobserve = cat->nobserve + f0 * m; dev->ndetect = cat->ndetect + f0 * m;
+        return 0;
+    }
+    size_t b5 = (size_t)nc * m * 5 * 4, b1 = (size_t)nc * m * 4, bc = (size_t)nc * 4;
+    size_t total = 4 * b5 + 2 * b1 + bc + 256;
+    if (ctx->cat_bytes < total) {
+        if (ctx->cat_dev) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(ctx->cat_dev)); ctx->cat_dev = nullptr; ctx->cat_bytes = 0; }
+        HIPCHK(hipMalloc(&ctx->cat_dev, total));
+        ctx->cat_bytes = total;
+    }
+    char *p = (char *)ctx->cat_dev;
+    auto up = [&](const void *src, size_t off_elems_bytes, size_t bytes, const void **out) -> int {
+        HIPCHK(hipMemcpyAsync(p, (const char *)src + off_elems_bytes, bytes, hipMemcpyHostToDevice, ctx->stream));
+        *out = p;
+        p += (bytes + 15) & ~(size_t)15;
+        return 0;
+    };
+    RET(up(cat->count, (size_t)f0 * 4, bc, (const void **)&dev->count));
+    RET(up(cat->rowc, f0 * m * 20, b5, (const void **)&dev->rowc));
+    RET(up(cat->colc, f0 * m * 20, b5, (const void **)&dev->colc));
+    RET(up(cat->psfmag, f0 * m * 20, b5, (const void **)&dev->psfmag));
+    RET(up(cat->petro90, f0 * m * 20, b5, (const void **)&dev->petro90));
+    RET(up(cat->nobserve, f0 * m * 4, b1, (const void **)&dev->nobserve));
+    RET(up(cat->ndetect, f0 * m * 4, b1, (const void **)&dev->ndetect));
+    return 0;
+}
+
+static int run_removestars(lfdmi_ctx *ctx, float *frames_dev, int f0, int nc, int h, int w, const lfdmi_catalog *cat,
+                           const lfdmi_rs_params *rs) {
+    if (!cat || cat->max_obj <= 0) return 0;
+    if (!rs || rs->filter_index < 0 || rs->filter_index > 4) return fail(ctx, LFDMI_ERR_ARG, "removestars params");
+    lfdmi_catalog dev;
+    RET(stage_catalog(ctx, cat, f0, nc, &dev));
+    RsDev p;
+    p.defaultxy = rs->defaultxy; p.maxxy = rs->maxxy; p.magcount = rs->magcount; p.filter_index = rs->filter_index;
+    p.pixscale = rs->pixscale; p.maxmagdiff = rs->maxmagdiff; p.filter_cap = rs->filter_cap;
+    Span sp(ctx, TG_RS);
+    k_removestars<<<dim3(cat->max_obj, nc), 256, 0, ctx->stream>>>(frames_dev, h, w, cat->max_obj, dev.count, dev.rowc, dev.colc,
+                                                                   dev.psfmag, dev.petro90, dev.nobserve, dev.ndetect, p);
+    KCHK("k_removestars");
+    return 0;
+}
+
+extern "C" int lfdmi_remove_stars(lfdmi_ctx *ctx, float *img, int n, int h, int w, const lfdmi_catalog *cat,
+                                  const lfdmi_rs_params *rs, int loc) {
+    RET(check_shape(ctx, n, h, w));
+    if (!img || !cat) return fail(ctx, LFDMI_ERR_ARG, "NULL argument");
+    size_t N = (size_t)h * w;
+    for (int c0 = 0; c0 < n; c0 += ctx->G) {
+        int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
+        const void *d;
+        RET(in_ptr(ctx, img, (size_t)c0 * N * 4, (size_t)nc * N * 4, loc, &d));
+        RET(run_removestars(ctx, (float *)d, c0, nc, h, w, cat, rs));
+        if (loc == LFDMI_HOST) RET(out_copy(ctx, img, (size_t)c0 * N * 4, d, (size_t)nc * N * 4, loc));
+        RET(sync(ctx));
+    }
+    return 0;
+}
+
+// ---- C-ABI: whole passes ------------------------------------------------------------------
+static int pass_api(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, int w, int flip, int prep_mode, bool dim,
+                    const lfdmi_params *p, lfdmi_result *results, float *lines_equ, float *lines_box, int loc) {
+    RET(check_shape(ctx, n, h, w));
+    RET(check_params(ctx, p, dim));
+    if (!img || !results || dtype < 0 || dtype > 2) return fail(ctx, LFDMI_ERR_ARG, "bad argument");
+    if (dtype == LFDMI_U8 && dim) return fail(ctx, LFDMI_ERR_DTYPE, "dim pass needs a float image (numpy refuses uint8 += float)");
+    size_t N = (size_t)h * w, es = dtype_size(dtype);
+    int K = p->nlinesInSet;
+    std::vector<lfdmi_result> host((size_t)ctx->G);
+    std::vector<float> hl((size_t)ctx->G * 2 * K * 2);
+    for (int c0 = 0; c0 < n; c0 += ctx->G) {
+        int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
+        const void *d;
+        RET(in_ptr(ctx, img, (size_t)c0 * N * es, (size_t)nc * N * es, loc, &d));
+        k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, nc);
+        KCHK("k_init_results");
+        RET(run_pass(ctx, d, dtype, nc, h, w, flip, prep_mode, dim, p, nullptr, nullptr));
+        HIPCHK(hipMemcpyAsync(host.data(), ctx->res_dev, (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(hl.data(), ctx->lines, (size_t)nc * 2 * K * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        RET(sync(ctx));
+        for (int i = 0; i < nc; i++) {
+            dictify(h, w, &host[i]);
+            results[c0 + i] = host[i];
+            bool have = host[i].detection && host[i].status == 0;
+            for (int s = 0; s < 2; s++) {
+                float *dst = s ? lines_box : lines_equ;
+                if (!dst) continue;
+                for (int k = 0; k < 2 * K; k++) dst[(size_t)(c0 + i) * 2 * K + k] = have ? hl[((size_t)i * 2 + s) * 2 * K + k] : 0.f;
+            }
+        }
+    }
+    return 0;
+}
+
+extern "C" int lfdmi_process_bright(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, int w, int flip,
+                                    const lfdmi_params *p, lfdmi_result *results, float *lines_equ, float *lines_box, int loc) {
+    return pass_api(ctx, img, dtype, n, h, w, flip, LFDMI_PREP_BRIGHT, false, p, results, lines_equ, lines_box, loc);
+}
+
+extern "C" int lfdmi_process_dim(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, int w, int flip, int after_bright,
+                                 const lfdmi_params *p, lfdmi_result *results, float *lines_equ, float *lines_box, int loc) {
+    return pass_api(ctx, img, dtype, n, h, w, flip, after_bright ? LFDMI_PREP_BRIGHT_THEN_DIM : LFDMI_PREP_DIM, true, p, results,
+                    lines_equ, lines_box, loc);
+}
+
+extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w, const lfdmi_catalog *cat,
+                                  const lfdmi_rs_params *rs, const lfdmi_params *bright, const lfdmi_params *dim,
+                                  lfdmi_result *results, int loc) {
+    RET(check_shape(ctx, n, h, w));
+    RET(check_params(ctx, bright, false));
+    RET(check_params(ctx, dim, true));
+    if (!frames || !results) return fail(ctx, LFDMI_ERR_ARG, "NULL argument");
+    size_t N = (size_t)h * w;
+    std::vector<lfdmi_result> host((size_t)ctx->G);
+    for (int c0 = 0; c0 < n; c0 += ctx->G) {
+        int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
+        const void *d;
+        RET(in_ptr(ctx, frames, (size_t)c0 * N * 4, (size_t)nc * N * 4, loc, &d));
+        k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, nc);
+        KCHK("k_init_results");
+        if (cat) {
+            RET(run_removestars(ctx, (float *)d, c0, nc, h, w, cat, rs));
+            if (loc == LFDMI_HOST) RET(out_copy(ctx, frames, (size_t)c0 * N * 4, d, (size_t)nc * N * 4, loc));
+        }
+        RET(run_pass(ctx, d, LFDMI_F32, nc, h, w, 1, LFDMI_PREP_BRIGHT, false, bright, nullptr, ctx->need_dim));
+        RET(run_pass(ctx, d, LFDMI_F32, nc, h, w, 1, LFDMI_PREP_BRIGHT_THEN_DIM, true, dim, ctx->need_dim, nullptr));
+        HIPCHK(hipMemcpyAsync(host.data(), ctx->res_dev, (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
+        RET(sync(ctx));
+        for (int i = 0; i < nc; i++) {
+            dictify(h, w, &host[i]);
+            results[c0 + i] = host[i];
+        }
+    }
+    return 0;
+}
+
+extern "C" int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, uint8_t *dst, int loc) {
+    if (!ctx || !dst || slot < 0 || slot >= ctx->G) return LFDMI_ERR_ARG;
+    if (ctx->tab_h <= 0) return fail(ctx, LFDMI_ERR_ARG, "no pass has run yet");
+    int h = ctx->tab_h, w = ctx->tab_w;
+    size_t N = (size_t)h * w, BW = (size_t)h * LFD_WQ(w);
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint8_t *src = nullptr;
+    if (which == LFDMI_STAGE_GRAY) src = ctx->gray + slot * N;
+    else if (which == LFDMI_STAGE_EQU) src = ctx->equ + slot * N;
+    else if (which == LFDMI_STAGE_CANNY || which == LFDMI_STAGE_BOX) {
+        const u64 *bits = (which == LFDMI_STAGE_CANNY ? ctx->edgeb : ctx->boxb) + slot * BW;
+        RET(expand_bits(ctx, bits, ctx->tmp, 1, h, w));
+        src = ctx->tmp;
+    } else return fail(ctx, LFDMI_ERR_ARG, "unknown stage");
+    RET(out_copy(ctx, dst, 0, src, N, loc));
+    return sync(ctx);
+}
