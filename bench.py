@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SDSS frames/s of the full detecttrails pipe on N MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (remove_stars -> flip -> bright pass -> dim pass where
+the bright pass found nothing; detecttrails.py:119-131) over this rank's batch of synthetic
+2048x1489 float32 frames (BASELINE.json configs[2]: batch = 256 per GPU),
+already resident in HBM.  Weak scaling: every rank owns --frames-per-gpu frames, no data-path
+collective; one barrier-bracketed timed region, max over ranks.  Rank 0 prints ONE JSON line.
+
+roofline: per-kernel HIP-event times come from the library (events on the launch stream, live
+during the timed region); the dominant kernel is priced with SURVEY.md 8(d)'s algorithmic
+bytes of its stage x the frames its launches worked on.  cpu_baseline: the C oracle
+(oracle/, a port of the reference's algorithm; the reference's own OpenCV path cannot run
+here or on the GPU box) on a bounded sample of the same frames, one host thread.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# SURVEY.md 8(d) algorithmic bytes per pixel of the stage each kernel belongs to
+STAGE_BYTES_PER_PX = {
+    "k_removestars": 0.0, "k_prep_hist": 5.0, "k_lut": 0.0, "k_morph(erode)": 2.0, "k_morph(dilate)": 2.0,
+    # Canny stage (u8 in, u8 out) = NMS + hysteresis kernels
+    "k_canny_nms": 2.0, "k_runs_init(fg)": 2.0, "k_runs_merge8": 2.0, "k_runs_flatten(fg)": 2.0, "k_edge_from_cand": 2.0,
+    # contours + minAreaRect + fillPoly stage (edges in, box_img out)
+    "k_runs_init(bg)": 2.0, "k_runs_merge4_bg": 2.0, "k_runs_flatten(bg)": 2.0, "k_keys": 2.0, "k_extremes": 2.0,
+    "k_rects": 2.0, "k_fill_quads": 2.0,
+    # HoughLines reads each of the two images once
+    "k_pixlist": 2.0, "k_hough_vote": 2.0, "k_hough_peaks": 2.0, "k_hough_topk": 2.0, "k_hough_sort": 1.0,
+    "k_finalize": 0.0, "misc": 0.0,
+}
+
+
+def _gen(k):
+    from lfd_amd import synth
+    img, cat, _ = synth.make_frame(k)
+    return img, cat
+
+
+def make_frames(k0, n, workers):
+    if workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            out = pool.map(_gen, range(k0, k0 + n), chunksize=max(1, n // (workers * 4)))
+    else:
+        out = [_gen(k) for k in range(k0, k0 + n)]
+    return [o[0] for o in out], [o[1] for o in out]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames-per-gpu", type=int, default=256)
+    ap.add_argument("--inflight", type=int, default=32)
+    ap.add_argument("--cpu-sample", type=int, default=24, help="frames timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--gen-workers", type=int, default=-1)
+    ap.add_argument("--no-removestars", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+
+    n = args.frames_per_gpu
+    k0 = rank * n
+    workers = args.gen_workers
+    if workers < 0:
+        workers = max(1, min(16, (os.cpu_count() or 8) // max(1, world)))
+    t0 = time.time()
+    frames, cats = make_frames(k0, n, workers)  # before anything touches the GPU (fork-safe)
+    t_gen = time.time() - t0
+
+    import torch
+    import torch.distributed as dist
+    from lfd_amd import _native, synth
+    from lfd_amd.batch import BatchDetector
+    from lfd_amd.detecttrails import default_params
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    pb, pd, prs = default_params()
+    rs = _native.make_rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
+    h, w = frames[0].shape
+    host = np.stack(frames)
+    dframes = torch.from_numpy(host).to(dev)
+    cat = None
+    if not args.no_removestars:
+        packed = synth.pack_catalogs(cats)
+        cat = {k: torch.from_numpy(v).to(dev) for k, v in packed.items()}
+    stream = torch.cuda.current_stream().cuda_stream
+    det = BatchDetector(local_rank, (h, w), args.inflight, stream=stream)
+
+    def step():
+        return det.detect(dframes, pb, pd, cat, rs)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    det.ctx.enable_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timing = det.ctx.get_timing()
+    det.ctx.enable_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    found_b = int((res["found"] == 1).sum())
+    found_d = int((res["found"] == 2).sum())
+    errors = int((res["status"] != 0).sum())
+
+    if rank == 0:
+        total_frames = world * n * args.steps
+        value = total_frames / elapsed
+        # dominant kernel by device time inside the timed region
+        name, (ms, launches, units) = max(timing.items(), key=lambda kv: kv[1][0])
+        bytes_per_frame = STAGE_BYTES_PER_PX[name] * h * w
+        achieved = (bytes_per_frame * units) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        kern = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // max(1, args.steps),
+                    "frames_per_step": v[2] // max(1, args.steps)} for k, v in timing.items() if v[1]}
+        out = {
+            "metric": "SDSS frames/sec (2048x1489) full detecttrails pipe", "value": round(value, 2),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: full removestars+bright+dim pipe, batch=%d synthetic SDSS "
+                                   "2048x1489 float32 frames per GPU, device-resident" % n,
+                       "frames_per_gpu": n, "inflight": args.inflight, "shape": [h, w],
+                       "removestars": not args.no_removestars, "parallelism": "frame-parallel x%d" % world,
+                       "found_bright": found_b, "found_dim": found_d, "frame_errors": errors,
+                       "gen_s": round(t_gen, 1)},
+            "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "avg_launch_ms": round(ms / max(1, launches), 4),
+                         "frames_per_launch": round(units / max(1, launches), 2),
+                         "algorithmic_bytes_per_frame": bytes_per_frame},
+            "kernels": kern,
+        }
+        if args.cpu_sample > 0:
+            from oracle import lfd_oracle as O
+            rs_o = O.rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
+            m = min(args.cpu_sample, n)
+            t0 = time.perf_counter()
+            agree = 0
+            for i in range(m):
+                r = O.detect_frame(host[i].copy(), pb, pd, None if args.no_removestars else cats[i], rs_o)
+                agree += all(r[k] == res[i][k].item() for k in r)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(m / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d frames of rank 0's batch through oracle/ (C, -O2, 1 thread), "
+                                             "%d/%d identical to the GPU records" % (m, agree, m),
+                                   "host_cores_available": os.cpu_count()}
+        print(json.dumps(out), flush=True)
+    det.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

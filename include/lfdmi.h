@@ -15,7 +15,7 @@
  *     LFDMI_DEVICE (hipMalloc'd / torch CUDA memory on ctx's device, used in place).
  *   - a ctx is bound to one device, is not thread-safe, and runs everything on one HIP
  *     stream (its own, or the caller's via lfdmi_set_stream).  Calls return after the
- *     stream has drained (synchronous at the ABI), except lfdmi_detect_batch_async.
+ *     stream has drained (synchronous at the ABI).
  *   - the library never retains or frees caller pointers.
  */
 #ifndef LFDMI_H
@@ -171,11 +171,16 @@ int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w,
                        int loc);
 /* copy a stage image (u8, h x w) of in-flight slot `slot` of the LAST call to dst */
 int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, uint8_t *dst, int loc);
-/* dominant-kernel timing support for bench.py: HIP-event time (ms) spent in the kernel group
- * `which` during the last detect/process call: 0 prep, 1 morph, 2 canny, 3 ccl, 4 rects+fill,
- * 5 hough vote, 6 hough peaks, 7 removestars; only recorded when enabled. */
+/* per-kernel timing for bench.py's roofline entry: when enabled, every kernel launch is
+ * bracketed by HIP events on the launch stream; lfdmi_get_timing returns, per timing slot,
+ * the summed device time (ms), the number of launches and the number of frames those launches
+ * actually worked on (a dim-pass launch only works on frames the bright pass left undecided,
+ * a Hough launch only on frames with a detected rectangle) since lfdmi_enable_timing(ctx, 1).
+ * lfdmi_timing_slots() slots, named by lfdmi_timing_name(i) (the kernel's name). */
 int lfdmi_enable_timing(lfdmi_ctx *ctx, int on);
-int lfdmi_get_timing(lfdmi_ctx *ctx, float *ms /* [8] */, int32_t *launches /* [8] */);
+int lfdmi_get_timing(lfdmi_ctx *ctx, float *ms, int32_t *launches, int64_t *units);
+int lfdmi_timing_slots(void);
+const char *lfdmi_timing_name(int slot);
 
 #ifdef __cplusplus
 }

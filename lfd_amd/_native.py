@@ -22,7 +22,6 @@ MAX_MORPH_K = 31
 
 ERR_ARG, ERR_DTYPE, ERR_HIP, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_NOLINES = -1, -2, -3, -4, -5, -6
 
-TIMING_GROUPS = ("prep", "morph", "canny", "ccl", "rects", "hough_vote", "hough_peaks", "removestars")
 
 # every symbol include/lfdmi.h declares (checked by the CPU test-suite)
 SYMBOLS = (
@@ -31,6 +30,7 @@ SYMBOLS = (
     "lfdmi_canny", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
     "lfdmi_hough_dims", "lfdmi_remove_stars", "lfdmi_process_bright", "lfdmi_process_dim",
     "lfdmi_detect_batch", "lfdmi_get_stage", "lfdmi_enable_timing", "lfdmi_get_timing",
+    "lfdmi_timing_slots", "lfdmi_timing_name",
 )
 
 
@@ -92,6 +92,7 @@ def lib():
         _lib.lfdmi_ctx_destroy.restype = None
         _lib.lfdmi_ctx_destroy.argtypes = [C.c_void_p]
         _lib.lfdmi_hough_dims.restype = None
+        _lib.lfdmi_timing_name.restype = C.c_char_p
     return _lib
 
 
@@ -190,10 +191,13 @@ class Context:
         self._chk(self._lib.lfdmi_enable_timing(self._h, int(on)))
 
     def get_timing(self):
-        ms = (C.c_float * 8)()
-        n = (C.c_int32 * 8)()
-        self._chk(self._lib.lfdmi_get_timing(self._h, ms, n))
-        return {g: (float(ms[i]), int(n[i])) for i, g in enumerate(TIMING_GROUPS)}
+        """{kernel name: (total device ms, launches, frames worked on)} since enable_timing(True)."""
+        k = self._lib.lfdmi_timing_slots()
+        ms = (C.c_float * k)()
+        n = (C.c_int32 * k)()
+        u = (C.c_int64 * k)()
+        self._chk(self._lib.lfdmi_get_timing(self._h, ms, n, u))
+        return {self._lib.lfdmi_timing_name(i).decode(): (float(ms[i]), int(n[i]), int(u[i])) for i in range(k)}
 
     # -- helpers --------------------------------------------------------------------------
     @staticmethod

@@ -1,0 +1,65 @@
+"""Frame-parallel sharding of a batch over the GPUs of one node.
+
+Frames are independent (process_field keeps no cross-frame state, detecttrails.py:30-143) and
+the reference itself scales by handing disjoint run lists to separate PBS jobs
+(createjobs/createjobs.py:173-202).  Here every rank (one process per GPU) takes a contiguous
+block of frames, runs ``lfdmi_detect_batch`` on its own device, and the per-frame result
+records (48 B each) are gathered once at the end.  There is no collective on the data path.
+"""
+import numpy as np
+
+from . import _native
+
+
+def shard_bounds(n_frames, world_size):
+    """Contiguous blocks of ceil(n/world) frames: [(start, stop)] per rank (config 4: 1024 each)."""
+    per = -(-n_frames // world_size) if world_size > 0 else n_frames
+    return [(min(r * per, n_frames), min((r + 1) * per, n_frames)) for r in range(world_size)]
+
+
+def shard_range(n_frames, rank, world_size):
+    return shard_bounds(n_frames, world_size)[rank]
+
+
+def gather_results(local, n_frames, group=None):
+    """All ranks contribute their structured result array; every rank gets the full batch back.
+
+    Uses torch.distributed (gloo on CPU tensors, RCCL on device tensors); the payload is
+    48 B x frames, so this is a latency-bound bookkeeping exchange, not data-path traffic."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world = dist.get_world_size(group)
+    bounds = shard_bounds(n_frames, world)
+    per = max(b - a for a, b in bounds)
+    rec = _native.RESULT_DTYPE.itemsize
+    buf = np.zeros(per * rec, np.uint8)
+    raw = np.ascontiguousarray(local).view(np.uint8).reshape(-1)
+    buf[:raw.size] = raw
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    mine = torch.from_numpy(buf).to(dev)
+    out = torch.empty(world * per * rec, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    allrec = out.cpu().numpy().reshape(world, per * rec)
+    parts = [allrec[r, :(b - a) * rec].copy().view(_native.RESULT_DTYPE) for r, (a, b) in enumerate(bounds)]
+    return np.concatenate(parts)
+
+
+class BatchDetector:
+    """Owns one GPU context and runs the full pipe over this rank's share of a batch."""
+
+    def __init__(self, device=0, shape=(1489, 2048), inflight=32, stream=None):
+        self.ctx = _native.Context(device, shape[0], shape[1], inflight)
+        if stream is not None:
+            self.ctx.set_stream(stream)
+        self.shape = shape
+
+    def close(self):
+        self.ctx.close()
+
+    def detect(self, frames, params_bright, params_dim, catalogs=None, rs=None):
+        """frames: (n, h, w) float32, numpy (staged through the library) or a torch CUDA tensor
+        (used in place).  catalogs: dict from synth.pack_catalogs (numpy or torch CUDA tensors)."""
+        return self.ctx.detect_batch(frames, params_bright, params_dim, catalogs, rs)

@@ -240,7 +240,7 @@ struct TailParams {
 // One thread per slot: check_theta on the first navg lines of both sets, result record,
 // and the "dim pass needed" flag (detecttrails.py:125-131).
 __global__ void k_finalize(const float *lines, const int *counters, lfdmi_result *res, int *need_dim,
-                           const int *active, TailParams tp, int G) {
+                           int *pass_flags, const int *active, TailParams tp, int G) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     if (active && !active[g]) { if (need_dim) need_dim[g] = 0; return; }
@@ -289,12 +289,14 @@ __global__ void k_finalize(const float *lines, const int *counters, lfdmi_result
         }
     }
     res[g] = r;
+    pass_flags[g] |= (tp.which == 1) ? (r.detection ? 1 : 0) : (2 | (r.detection ? 4 : 0));
     if (need_dim) need_dim[g] = (r.found == 0 && r.status == 0) ? 1 : 0;
 }
 
-__global__ void k_init_results(lfdmi_result *res, int G) {
+__global__ void k_init_results(lfdmi_result *res, int *pass_flags, int G) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
+    pass_flags[g] = 0;
     lfdmi_result r;
     r.status = 0; r.found = 0; r.rho = 0.f; r.theta = 0.f;
     r.x1 = r.y1 = r.x2 = r.y2 = 0;

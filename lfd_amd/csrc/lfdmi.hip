@@ -21,9 +21,20 @@
 
 #define LFD_PI 3.1415926535897932384626433832795
 
-enum { TG_PREP = 0, TG_MORPH, TG_CANNY, TG_CCL, TG_RECT, TG_VOTE, TG_PEAKS, TG_RS, TG_COUNT };
+// one timing slot per kernel (HIP events on the launch stream, see lfdmi_enable_timing)
+enum {
+    KID_REMOVESTARS = 0, KID_PREP_HIST, KID_LUT, KID_ERODE, KID_DILATE, KID_CANNY_NMS, KID_RUNS_INIT_FG,
+    KID_RUNS_MERGE8, KID_RUNS_FLATTEN_FG, KID_EDGE, KID_RUNS_INIT_BG, KID_RUNS_MERGE4, KID_RUNS_FLATTEN_BG,
+    KID_KEYS, KID_EXTREMES, KID_RECTS, KID_FILL, KID_PIXLIST, KID_VOTE, KID_PEAKS, KID_TOPK, KID_SORT,
+    KID_FINALIZE, KID_MISC, TG_COUNT
+};
+static const char *const KID_NAMES[TG_COUNT] = {
+    "k_removestars", "k_prep_hist", "k_lut", "k_morph(erode)", "k_morph(dilate)", "k_canny_nms", "k_runs_init(fg)",
+    "k_runs_merge8", "k_runs_flatten(fg)", "k_edge_from_cand", "k_runs_init(bg)", "k_runs_merge4_bg",
+    "k_runs_flatten(bg)", "k_keys", "k_extremes", "k_rects", "k_fill_quads", "k_pixlist", "k_hough_vote",
+    "k_hough_peaks", "k_hough_topk", "k_hough_sort", "k_finalize", "misc"};
 
-struct TimedSpan { hipEvent_t a, b; int group; };
+struct TimedSpan { hipEvent_t a, b; int group, pass, det; };
 
 struct lfdmi_ctx {
     int device = 0, H = 0, W = 0, G = 0, wq = 0;
@@ -62,6 +73,9 @@ struct lfdmi_ctx {
     std::vector<hipEvent_t> ev_pool;
     float t_ms[TG_COUNT] = {0};
     int t_n[TG_COUNT] = {0};
+    long long t_units[TG_COUNT] = {0}; // frames (images) the timed launches actually worked on
+    int cur_pass = 0;                  // 0 = bright / stand-alone operator, 1 = dim pass of detect_batch
+    int *pass_flags = nullptr;         // per slot: bit0 bright detection, bit1 dim pass ran, bit2 dim detection
     std::vector<void *> allocs;
 };
 
@@ -91,10 +105,12 @@ static int fail(lfdmi_ctx *c, int code, const std::string &msg) {
 struct Span {
     lfdmi_ctx *c;
     int idx = -1;
-    Span(lfdmi_ctx *ctx, int group) : c(ctx) {
+    Span(lfdmi_ctx *ctx, int group, int det = 0) : c(ctx) {
         if (!c->timing) return;
         TimedSpan s;
         s.group = group;
+        s.pass = ctx->cur_pass;
+        s.det = det;
         for (hipEvent_t *e : {&s.a, &s.b}) {
             if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); }
             else hipEventCreate(e);
@@ -108,10 +124,15 @@ struct Span {
     }
 };
 
-static void collect_spans(lfdmi_ctx *c) {
+// n_act[p] / n_det[p]: frames of the chunk that pass p worked on / that reached its Hough stage
+static void collect_spans(lfdmi_ctx *c, const int n_act[2], const int n_det[2]) {
     for (auto &s : c->spans) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->t_ms[s.group] += ms; c->t_n[s.group]++; }
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            c->t_ms[s.group] += ms;
+            c->t_n[s.group]++;
+            c->t_units[s.group] += s.det ? n_det[s.pass] : n_act[s.pass];
+        }
         c->ev_pool.push_back(s.a);
         c->ev_pool.push_back(s.b);
     }
@@ -178,6 +199,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     RET(dmalloc(ctx, &ctx->tab, (size_t)2 * (na + 8)));
     RET(dmalloc(ctx, &ctx->counters, G * C_COUNT));
     RET(dmalloc(ctx, &ctx->need_dim, G));
+    RET(dmalloc(ctx, &ctx->pass_flags, G));
     RET(dmalloc(ctx, &ctx->res_dev, G));
     HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -214,13 +236,20 @@ extern "C" int lfdmi_enable_timing(lfdmi_ctx *ctx, int on) {
     ctx->timing = on != 0;
     memset(ctx->t_ms, 0, sizeof ctx->t_ms);
     memset(ctx->t_n, 0, sizeof ctx->t_n);
+    memset(ctx->t_units, 0, sizeof ctx->t_units);
     return 0;
 }
-extern "C" int lfdmi_get_timing(lfdmi_ctx *ctx, float *ms, int32_t *launches) {
+extern "C" int lfdmi_get_timing(lfdmi_ctx *ctx, float *ms, int32_t *launches, int64_t *units) {
     if (!ctx) return LFDMI_ERR_ARG;
-    for (int i = 0; i < TG_COUNT; i++) { if (ms) ms[i] = ctx->t_ms[i]; if (launches) launches[i] = ctx->t_n[i]; }
+    for (int i = 0; i < TG_COUNT; i++) {
+        if (ms) ms[i] = ctx->t_ms[i];
+        if (launches) launches[i] = ctx->t_n[i];
+        if (units) units[i] = ctx->t_units[i];
+    }
     return 0;
 }
+extern "C" int lfdmi_timing_slots(void) { return TG_COUNT; }
+extern "C" const char *lfdmi_timing_name(int i) { return (i >= 0 && i < TG_COUNT) ? KID_NAMES[i] : ""; }
 
 // ---- helpers ------------------------------------------------------------------------------
 static int check_shape(lfdmi_ctx *ctx, int n, int h, int w) {
@@ -258,9 +287,13 @@ static int out_copy(lfdmi_ctx *ctx, void *dst, size_t offset, const void *dev_sr
     return 0;
 }
 
-static int sync(lfdmi_ctx *ctx) {
+// drain the stream; nc = frames of the chunk (stand-alone operators work on all of them)
+static int sync(lfdmi_ctx *ctx, int nc = 0, const int *n_act = nullptr, const int *n_det = nullptr) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (ctx->timing) collect_spans(ctx);
+    if (ctx->timing) {
+        int a[2] = {nc, 0}, d[2] = {nc, 0};
+        collect_spans(ctx, n_act ? n_act : a, n_det ? n_det : d);
+    }
     return 0;
 }
 
@@ -269,11 +302,14 @@ static dim3 word_grid(int h, int w, int n) { return dim3((unsigned)((h * LFD_WQ(
 // ---- stage runners (device pointers only, nc <= G images in workspace slots 0..nc-1) --------
 static int run_prep(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int mode,
                     double minFlux, double addFlux, const int *active) {
-    Span sp(ctx, TG_PREP);
     HIPCHK(hipMemsetAsync(ctx->hist, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
-    k_prep_hist<<<dim3((h + PREP_ROWS - 1) / PREP_ROWS, nc), 256, 0, ctx->stream>>>(
-        src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist, active);
-    KCHK("k_prep_hist");
+    {
+        Span sp(ctx, KID_PREP_HIST);
+        k_prep_hist<<<dim3((h + PREP_ROWS - 1) / PREP_ROWS, nc), 256, 0, ctx->stream>>>(
+            src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist, active);
+        KCHK("k_prep_hist");
+    }
+    Span sp(ctx, KID_LUT);
     k_lut<<<nc, 256, 0, ctx->stream>>>(ctx->hist, h * w, ctx->lut, active);
     KCHK("k_lut");
     return 0;
@@ -289,7 +325,7 @@ static int run_morph(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, u64 *bits
                      int kh, int kw, int op, int nc, int h, int w, const int *active) {
     if (!kernel || kh <= 0 || kw <= 0 || kh > LFDMI_MAX_MORPH_K || kw > LFDMI_MAX_MORPH_K)
         return fail(ctx, LFDMI_ERR_UNSUPPORTED, "structuring element must be 1..31 on both sides");
-    Span sp(ctx, TG_MORPH);
+    Span sp(ctx, op ? KID_ERODE : KID_DILATE);
     if (all_ones(kernel, kh, kw)) {
         int IH = MORPH_TH + kh - 1, IW = MORPH_TW + kw - 1;
         size_t lds = ((size_t)(IH * IW + 15) & ~(size_t)15) + (size_t)IH * MORPH_TW;
@@ -314,21 +350,24 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
     if (low_d > high_d) { double t = low_d; low_d = high_d; high_d = t; }
     int low = (int)floor(low_d), high = (int)floor(high_d);
     {
-        Span sp(ctx, TG_CANNY);
+        Span sp(ctx, KID_CANNY_NMS);
         dim3 grid((w + CANNY_TW - 1) / CANNY_TW, (h + CANNY_TH - 1) / CANNY_TH, nc);
         k_canny_nms<<<grid, 256, 0, ctx->stream>>>(img, ctx->candb, ctx->strongb, h, w, low, high, active);
         KCHK("k_canny_nms");
     }
-    Span sp(ctx, TG_CCL);
     dim3 wg = word_grid(h, w, nc);
-    k_runs_init<<<wg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->Lf, ctx->YMf, ctx->FLf, h, w, active);
-    KCHK("k_runs_init");
-    k_runs_merge8<<<wg, 256, 0, ctx->stream>>>(ctx->candb, ctx->Lf, h, w, active);
-    KCHK("k_runs_merge8");
-    k_runs_flatten<<<wg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->strongb, ctx->Lf, ctx->YMf, ctx->FLf, h, w, active);
-    KCHK("k_runs_flatten");
-    k_edge_from_cand<<<wg, 256, 0, ctx->stream>>>(ctx->candb, ctx->Lf, ctx->FLf, ctx->edgeb, h, w, active);
-    KCHK("k_edge_from_cand");
+    { Span sp(ctx, KID_RUNS_INIT_FG);
+      k_runs_init<<<wg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->Lf, ctx->YMf, ctx->FLf, h, w, active);
+      KCHK("k_runs_init"); }
+    { Span sp(ctx, KID_RUNS_MERGE8);
+      k_runs_merge8<<<wg, 256, 0, ctx->stream>>>(ctx->candb, ctx->Lf, h, w, active);
+      KCHK("k_runs_merge8"); }
+    { Span sp(ctx, KID_RUNS_FLATTEN_FG);
+      k_runs_flatten<<<wg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->strongb, ctx->Lf, ctx->YMf, ctx->FLf, h, w, active);
+      KCHK("k_runs_flatten"); }
+    { Span sp(ctx, KID_EDGE);
+      k_edge_from_cand<<<wg, 256, 0, ctx->stream>>>(ctx->candb, ctx->Lf, ctx->FLf, ctx->edgeb, h, w, active);
+      KCHK("k_edge_from_cand"); }
     return 0;
 }
 
@@ -345,26 +384,29 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
         return fail(ctx, LFDMI_ERR_UNSUPPORTED, "contoursMode: only RETR_LIST / RETR_CCOMP / RETR_TREE");
     dim3 wg = word_grid(h, w, nc);
     size_t BW = (size_t)h * LFD_WQ(w);
-    {
-        Span sp(ctx, TG_CCL);
-        k_runs_init<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->Lb, ctx->YMb, ctx->FLb, h, w, active);
-        KCHK("k_runs_init(bg)");
-        k_runs_merge4_bg<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lb, h, w, active);
-        KCHK("k_runs_merge4_bg");
-        k_runs_flatten<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, nullptr, ctx->Lb, ctx->YMb, ctx->FLb, h, w, active);
-        KCHK("k_runs_flatten(bg)");
-    }
-    Span sp(ctx, TG_RECT);
+    { Span sp(ctx, KID_RUNS_INIT_BG);
+      k_runs_init<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->Lb, ctx->YMb, ctx->FLb, h, w, active);
+      KCHK("k_runs_init(bg)"); }
+    { Span sp(ctx, KID_RUNS_MERGE4);
+      k_runs_merge4_bg<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lb, h, w, active);
+      KCHK("k_runs_merge4_bg"); }
+    { Span sp(ctx, KID_RUNS_FLATTEN_BG);
+      k_runs_flatten<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, nullptr, ctx->Lb, ctx->YMb, ctx->FLb, h, w, active);
+      KCHK("k_runs_flatten(bg)"); }
     HIPCHK(hipMemsetAsync(ctx->boxb, 0, (size_t)nc * BW * sizeof(u64), ctx->stream));
+    { Span sp(ctx, KID_KEYS);
     k_keys<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lf, ctx->YMf, ctx->Lb, ctx->YMb, ctx->FLb, ctx->SBf, ctx->SBb,
                                          ctx->PAb, ctx->keys, ctx->rowext, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, active);
-    KCHK("k_keys");
+    KCHK("k_keys"); }
+    { Span sp(ctx, KID_EXTREMES);
     k_extremes<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lf, ctx->Lb, ctx->FLb, ctx->SBf, ctx->SBb, ctx->PAb, ctx->rowext,
                                              h, w, ctx->slot_cap, active);
-    KCHK("k_extremes");
+    KCHK("k_extremes"); }
+    { Span sp(ctx, KID_RECTS);
     k_rects<<<dim3(256, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, ctx->hullbuf, ctx->quads, ctx->counters, h, w,
                                                     ctx->key_cap, ctx->slot_cap, minLen, lwTresh, active);
-    KCHK("k_rects");
+    KCHK("k_rects"); }
+    Span sp(ctx, KID_FILL);
     k_fill_quads<<<dim3(FILL_BLOCKS, nc), 256, 0, ctx->stream>>>(ctx->quads, ctx->counters, ctx->boxb, h, w, ctx->key_cap, active);
     KCHK("k_fill_quads");
     return 0;
@@ -405,22 +447,24 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
     int nslabs = (na + apb - 1) / apb;
     dim3 wg = word_grid(h, w, nc);
     {
-        Span sp(ctx, TG_VOTE);
+        { Span sp(ctx, KID_PIXLIST, need_detect);
         k_pixlist<<<wg, 256, 0, ctx->stream>>>(ctx->equb, ctx->pix_equ, ctx->counters, C_NPIX_EQU, h, w, ctx->list_cap, active, need_detect);
         KCHK("k_pixlist(equ)");
         if (n_img > 1) {
             k_pixlist<<<wg, 256, 0, ctx->stream>>>(ctx->boxb, ctx->pix_box, ctx->counters, C_NPIX_BOX, h, w, ctx->list_cap, active, need_detect);
             KCHK("k_pixlist(box)");
-        }
+        } }
+        Span sp(ctx, KID_VOTE, need_detect);
         k_hough_vote<<<dim3(nslabs, n_img, nc), VOTE_THREADS, (size_t)apb * stride * 4, ctx->stream>>>(
             ctx->pix_equ, ctx->pix_box, ctx->counters, ctx->tab, ctx->accum, na, nr, apb, ctx->list_cap, ctx->acc_cap, active, need_detect);
         KCHK("k_hough_vote");
     }
-    Span sp(ctx, TG_PEAKS);
+    { Span sp(ctx, KID_PEAKS, need_detect);
     k_hough_peaks<<<dim3(32, n_img, nc), 256, 0, ctx->stream>>>(ctx->accum, ctx->peaks, ctx->counters, na, nr, threshold,
                                                                 ctx->acc_cap, ctx->peak_cap, active, need_detect);
-    KCHK("k_hough_peaks");
+    KCHK("k_hough_peaks"); }
     if (K > 0) {
+        Span sp(ctx, KID_TOPK, need_detect);
         k_hough_topk<<<dim3(n_img, nc), 256, 0, ctx->stream>>>(ctx->peaks, ctx->counters, ctx->lines, K, nr, (float)rho, (float)theta,
                                                                ctx->peak_cap, active, need_detect);
         KCHK("k_hough_topk");
@@ -453,7 +497,8 @@ static int run_pass(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, i
     TailParams tp;
     tp.navg = p->nlinesInSet; tp.dro = p->dro; tp.thetaTresh = p->thetaTresh; tp.lineSetTresh = p->lineSetTresh;
     tp.which = dim ? 2 : 1;
-    k_finalize<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->lines, ctx->counters, ctx->res_dev, need_dim, active, tp, nc);
+    Span sp(ctx, KID_FINALIZE);
+    k_finalize<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->lines, ctx->counters, ctx->res_dev, need_dim, ctx->pass_flags, active, tp, nc);
     KCHK("k_finalize");
     return 0;
 }
@@ -483,7 +528,7 @@ extern "C" int lfdmi_prep_u8(lfdmi_ctx *ctx, const void *src, int dtype, int n, 
         RET(run_prep(ctx, d, dtype, nc, h, w, flip, mode, minFlux, addFlux, nullptr));
         RET(out_copy(ctx, gray, (size_t)c0 * N, ctx->gray, (size_t)nc * N, loc));
         RET(out_copy(ctx, hist, (size_t)c0 * 256 * 4, ctx->hist, (size_t)nc * 256 * 4, loc));
-        RET(sync(ctx));
+        RET(sync(ctx, nc));
     }
     return 0;
 }
@@ -497,7 +542,7 @@ extern "C" int lfdmi_equalize_hist(lfdmi_ctx *ctx, const uint8_t *src, int n, in
         const void *d;
         RET(in_ptr(ctx, src, (size_t)c0 * N, (size_t)nc * N, loc, &d));
         {
-            Span sp(ctx, TG_PREP);
+            Span sp(ctx, KID_MISC);
             HIPCHK(hipMemsetAsync(ctx->hist, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
             k_hist_u8<<<dim3(256, nc), 256, 0, ctx->stream>>>((const uint8_t *)d, N, ctx->hist);
             KCHK("k_hist_u8");
@@ -507,7 +552,7 @@ extern "C" int lfdmi_equalize_hist(lfdmi_ctx *ctx, const uint8_t *src, int n, in
             KCHK("k_apply_lut");
         }
         RET(out_copy(ctx, dst, (size_t)c0 * N, ctx->equ, (size_t)nc * N, loc));
-        RET(sync(ctx));
+        RET(sync(ctx, nc));
     }
     return 0;
 }
@@ -523,7 +568,7 @@ static int morph_api(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, co
         RET(in_ptr(ctx, src, (size_t)c0 * N, (size_t)nc * N, loc, &d));
         RET(run_morph(ctx, (const uint8_t *)d, ctx->equ, nullptr, nullptr, kernel, kh, kw, op, nc, h, w, nullptr));
         RET(out_copy(ctx, dst, (size_t)c0 * N, ctx->equ, (size_t)nc * N, loc));
-        RET(sync(ctx));
+        RET(sync(ctx, nc));
     }
     return 0;
 }
@@ -549,7 +594,7 @@ extern "C" int lfdmi_canny(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int
         RET(run_canny(ctx, (const uint8_t *)d, nc, h, w, low, high, nullptr));
         RET(expand_bits(ctx, ctx->edgeb, ctx->tmp, nc, h, w));
         RET(out_copy(ctx, dst, (size_t)c0 * N, ctx->tmp, (size_t)nc * N, loc));
-        RET(sync(ctx));
+        RET(sync(ctx, nc));
     }
     return 0;
 }
@@ -573,7 +618,7 @@ extern "C" int lfdmi_fit_min_area_rect(lfdmi_ctx *ctx, const uint8_t *img, int n
             RET(out_copy(ctx, box_img, (size_t)c0 * N, ctx->tmp, (size_t)nc * N, loc));
         }
         HIPCHK(hipMemcpyAsync(cnt.data(), ctx->counters, (size_t)nc * C_COUNT * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        RET(sync(ctx));
+        RET(sync(ctx, nc));
         for (int i = 0; i < nc; i++) {
             if (cnt[(size_t)i * C_COUNT + C_OVERFLOW]) return fail(ctx, LFDMI_ERR_CAPACITY, "contour workspace overflow");
             int det = cnt[(size_t)i * C_COUNT + C_DETECT], nb = cnt[(size_t)i * C_COUNT + C_NQUADS];
@@ -617,13 +662,13 @@ static int hough_api(lfdmi_ctx *ctx, const uint8_t *img, int n, int h, int w, do
             for (int i = 0; i < nc; i++)
                 RET(out_copy(ctx, accum, (size_t)(c0 + i) * acc_n * 4, ctx->accum + (size_t)i * 2 * ctx->acc_cap, acc_n * 4, loc));
         if (lines_dev) {
-            Span sp(ctx, TG_PEAKS);
+            Span sp(ctx, KID_SORT);
             k_hough_sort<<<dim3(1, nc), 1024, 0, ctx->stream>>>(ctx->peaks, ctx->counters, lines_dev, max_lines, nr, (float)rho,
                                                                (float)theta, ctx->peak_cap);
             KCHK("k_hough_sort");
         }
         HIPCHK(hipMemcpyAsync(cnt.data(), ctx->counters, (size_t)nc * C_COUNT * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        RET(sync(ctx));
+        RET(sync(ctx, nc));
         for (int i = 0; i < nc; i++) {
             int total = cnt[(size_t)i * C_COUNT + C_NPEAK_EQU];
             if (n_lines) {
@@ -693,7 +738,7 @@ static int run_removestars(lfdmi_ctx *ctx, float *frames_dev, int f0, int nc, in
     RsDev p;
     p.defaultxy = rs->defaultxy; p.maxxy = rs->maxxy; p.magcount = rs->magcount; p.filter_index = rs->filter_index;
     p.pixscale = rs->pixscale; p.maxmagdiff = rs->maxmagdiff; p.filter_cap = rs->filter_cap;
-    Span sp(ctx, TG_RS);
+    Span sp(ctx, KID_REMOVESTARS);
     k_removestars<<<dim3(cat->max_obj, nc), 256, 0, ctx->stream>>>(frames_dev, h, w, cat->max_obj, dev.count, dev.rowc, dev.colc,
                                                                    dev.psfmag, dev.petro90, dev.nobserve, dev.ndetect, p);
     KCHK("k_removestars");
@@ -711,7 +756,7 @@ extern "C" int lfdmi_remove_stars(lfdmi_ctx *ctx, float *img, int n, int h, int 
         RET(in_ptr(ctx, img, (size_t)c0 * N * 4, (size_t)nc * N * 4, loc, &d));
         RET(run_removestars(ctx, (float *)d, c0, nc, h, w, cat, rs));
         if (loc == LFDMI_HOST) RET(out_copy(ctx, img, (size_t)c0 * N * 4, d, (size_t)nc * N * 4, loc));
-        RET(sync(ctx));
+        RET(sync(ctx, nc));
     }
     return 0;
 }
@@ -727,16 +772,24 @@ static int pass_api(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, in
     int K = p->nlinesInSet;
     std::vector<lfdmi_result> host((size_t)ctx->G);
     std::vector<float> hl((size_t)ctx->G * 2 * K * 2);
+    std::vector<int> flags((size_t)ctx->G);
+    ctx->cur_pass = 0;
     for (int c0 = 0; c0 < n; c0 += ctx->G) {
         int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
         const void *d;
         RET(in_ptr(ctx, img, (size_t)c0 * N * es, (size_t)nc * N * es, loc, &d));
-        k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, nc);
+        k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, ctx->pass_flags, nc);
         KCHK("k_init_results");
         RET(run_pass(ctx, d, dtype, nc, h, w, flip, prep_mode, dim, p, nullptr, nullptr));
         HIPCHK(hipMemcpyAsync(host.data(), ctx->res_dev, (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(hl.data(), ctx->lines, (size_t)nc * 2 * K * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        RET(sync(ctx));
+        HIPCHK(hipMemcpyAsync(flags.data(), ctx->pass_flags, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        {
+            int na[2] = {nc, 0}, nd[2] = {0, 0};
+            for (int i = 0; i < nc; i++) nd[0] += (flags[i] & (dim ? 4 : 1)) != 0;
+            RET(sync(ctx, nc, na, nd));
+        }
         for (int i = 0; i < nc; i++) {
             dictify(h, w, &host[i]);
             results[c0 + i] = host[i];
@@ -771,20 +824,30 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
     if (!frames || !results) return fail(ctx, LFDMI_ERR_ARG, "NULL argument");
     size_t N = (size_t)h * w;
     std::vector<lfdmi_result> host((size_t)ctx->G);
+    std::vector<int> flags((size_t)ctx->G);
     for (int c0 = 0; c0 < n; c0 += ctx->G) {
         int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
         const void *d;
         RET(in_ptr(ctx, frames, (size_t)c0 * N * 4, (size_t)nc * N * 4, loc, &d));
-        k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, nc);
+        k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, ctx->pass_flags, nc);
         KCHK("k_init_results");
         if (cat) {
             RET(run_removestars(ctx, (float *)d, c0, nc, h, w, cat, rs));
             if (loc == LFDMI_HOST) RET(out_copy(ctx, frames, (size_t)c0 * N * 4, d, (size_t)nc * N * 4, loc));
         }
+        ctx->cur_pass = 0;
         RET(run_pass(ctx, d, LFDMI_F32, nc, h, w, 1, LFDMI_PREP_BRIGHT, false, bright, nullptr, ctx->need_dim));
+        ctx->cur_pass = 1;
         RET(run_pass(ctx, d, LFDMI_F32, nc, h, w, 1, LFDMI_PREP_BRIGHT_THEN_DIM, true, dim, ctx->need_dim, nullptr));
+        ctx->cur_pass = 0;
         HIPCHK(hipMemcpyAsync(host.data(), ctx->res_dev, (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
-        RET(sync(ctx));
+        HIPCHK(hipMemcpyAsync(flags.data(), ctx->pass_flags, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        {
+            int na[2] = {nc, 0}, nd[2] = {0, 0};
+            for (int i = 0; i < nc; i++) { nd[0] += flags[i] & 1; na[1] += (flags[i] >> 1) & 1; nd[1] += (flags[i] >> 2) & 1; }
+            RET(sync(ctx, nc, na, nd));
+        }
         for (int i = 0; i < nc; i++) {
             dictify(h, w, &host[i]);
             results[c0 + i] = host[i];
@@ -808,5 +871,5 @@ extern "C" int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, uint8_t *dst
         src = ctx->tmp;
     } else return fail(ctx, LFDMI_ERR_ARG, "unknown stage");
     RET(out_copy(ctx, dst, 0, src, N, loc));
-    return sync(ctx);
+    return sync(ctx, 1);
 }

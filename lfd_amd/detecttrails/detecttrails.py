@@ -1,0 +1,230 @@
+"""SDSS-facing driver: which frames to process, in what order, and what gets written.
+
+Host-side mirror of ``lfd/detecttrails/detecttrails.py``.  ``DetectTrails(**kwargs).process()``
+keeps the reference's keyword interface, its three parameter dictionaries
+(``params_bright`` / ``params_dim`` / ``params_removestars``, same keys and defaults,
+detecttrails.py:202-239) and its frame-selection rules (detecttrails.py:290-342); per frame,
+``process_field`` runs remove_stars -> vertical flip -> bright pass -> dim pass on the GPU
+through one ``lfdmi_detect_batch`` call and appends a results row / an errors entry in the
+reference's text formats.
+
+Deliberate fixes of reference bugs: C8 ``params_dim=`` /
+``params_removestars=`` keyword arguments land in their own dictionaries; C9 the results row
+carries the 13 header values instead of literal ``{h['CRPIX2']}`` text.
+"""
+import bz2
+import os
+import traceback
+
+import numpy as _np
+
+from .. import _native
+from . import fitslite, sdssfiles
+from .processfield import get_context, setup_debug, check_theta, dictify_hough  # noqa: F401
+from .removestars import read_photoObj_arrays
+
+# values of the cv2 constants the reference re-exports (detecttrails.py:14-18)
+RETR_EXTERNAL, RETR_LIST, RETR_CCOMP, RETR_TREE = 0, 1, 2, 3
+CHAIN_APPROX_NONE, CHAIN_APPROX_SIMPLE, CHAIN_APPROX_TC89_L1, CHAIN_APPROX_TC89_KCOS = 1, 2, 3, 4
+
+__all__ = ["DetectTrails", "process_field", "process_frame_arrays", "default_params"]
+
+_HEADER_KEYS = ("TAI", "CRPIX1", "CRPIX2", "CRVAL1", "CRVAL2", "CD1_1", "CD1_2", "CD2_1", "CD2_2")
+
+
+def default_params():
+    """Fresh copies of the three default dictionaries (detecttrails.py:202-239)."""
+    bright = {"lwTresh": 5, "thetaTresh": 0.15, "dilateKernel": _np.ones((4, 4), _np.uint8),
+              "contoursMode": RETR_LIST, "contoursMethod": CHAIN_APPROX_NONE, "minAreaRectMinLen": 1,
+              "houghMethod": 20, "nlinesInSet": 3, "lineSetTresh": 0.15, "dro": 25, "debug": False}
+    dim = {"minFlux": 0.02, "addFlux": 0.5, "lwTresh": 5, "thetaTresh": 0.15,
+           "erodeKernel": _np.ones((3, 3), _np.uint8), "dilateKernel": _np.ones((9, 9), _np.uint8),
+           "contoursMode": RETR_LIST, "contoursMethod": CHAIN_APPROX_NONE, "minAreaRectMinLen": 1,
+           "houghMethod": 20, "nlinesInSet": 3, "lineSetTresh": 0.15, "dro": 20, "debug": False}
+    removestars = {"pixscale": 0.396, "defaultxy": 20, "maxxy": 60,
+                   "filter_caps": {'u': 22.0, 'g': 22.2, 'r': 22.2, 'i': 21.3, 'z': 20.5},
+                   "magcount": 3, "maxmagdiff": 3, "debug": False}
+    return bright, dim, removestars
+
+
+def _rs_struct(filter, params_removestars):
+    p = {k: v for k, v in params_removestars.items() if k != "debug"}
+    return _native.make_rs_params(filter, **p)
+
+
+def process_frame_arrays(img, cat, filter, params_bright, params_dim, params_removestars):
+    """The hot part of process_field (detecttrails.py:119-131) on arrays.
+
+    ``img``: float32 (h, w) frame, blotted in place by remove_stars like the reference;
+    ``cat``: photoObj columns (dict) or None.  Returns ``(detection, res_dict_or_None, record)``.
+    """
+    if img.dtype != _np.float32 or not img.flags.c_contiguous:
+        raise TypeError("process_frame_arrays needs a C-contiguous float32 frame")
+    ctx = get_context(*img.shape)
+    packed = rs = None
+    if cat is not None and len(cat["NOBSERVE"]):
+        from .removestars import _check_finite
+        _check_finite(cat)
+        n = len(cat["NOBSERVE"])
+        packed = {"count": _np.array([n], _np.int32)}
+        for key in ("ROWC", "COLC", "PSFMAG", "PETROTH90"):
+            packed[key] = _np.ascontiguousarray(cat[key], _np.float32).reshape(1, n, 5)
+        for key in ("NOBSERVE", "NDETECT"):
+            packed[key] = _np.ascontiguousarray(cat[key], _np.int32).reshape(1, n)
+        rs = _rs_struct(filter, params_removestars)
+    rec = ctx.detect_batch(img, params_bright, params_dim, packed, rs)[0]
+    status = int(rec["status"])
+    if status == _native.ERR_NOLINES:
+        raise TypeError("'NoneType' object is not subscriptable")  # HoughLines gave None
+    if status:
+        raise _native.NativeError(status, "frame failed on the device")
+    if rec["found"]:
+        # coordinates the way the reference computes them: numpy float32 scalars
+        res = dictify_hough(img.shape, (_np.float32(rec["rho"]), _np.float32(rec["theta"])))
+        return True, res, rec
+    return False, None, rec
+
+
+def process_field(results, errors, run, camcol, filter, field, params_bright, params_dim,
+                  params_removestars):
+    """One frame end to end (reference: detecttrails.py:30-143): locate the frame (or its .bz2),
+    read image + header + photoObj, detect, append ``run camcol filter field tai crpix1 crpix2
+    crval1 crval2 cd11 cd12 cd21 cd22 x1 y1 x2 y2`` to ``results``; every exception is logged
+    to ``errors`` (ids, 3-frame traceback, message) and swallowed."""
+    try:
+        path = sdssfiles.filename("frame", run=run, camcol=camcol, field=field, filter=filter)
+        if not os.path.exists(path):
+            if not os.path.exists(path + ".bz2"):
+                raise FileNotFoundError(("File {0} or its bz2 compressed version not found. "
+                                         "Are you sure they exist?").format(path))
+            path = path + ".bz2"  # decompressed in memory; no $FITS_DUMP round trip needed
+        img, h = fitslite.read_image(path)
+        img = _np.ascontiguousarray(img, dtype=_np.float32)
+        head = " ".join(str(x) for x in (run, camcol, filter, field, *(h[k] for k in _HEADER_KEYS)))
+        cat = read_photoObj_arrays(sdssfiles.filename("photoObj", run=run, camcol=camcol, field=field))
+        detection, res, _ = process_frame_arrays(img, cat, filter, params_bright, params_dim,
+                                                 params_removestars)
+        if detection:
+            results.write(f"{head} {res['x1']} {res['y1']} {res['x2']} {res['y2']}\n")
+    except Exception as e:  # noqa: BLE001 - the reference swallows everything per frame
+        if params_bright.get("debug") or params_dim.get("debug"):
+            traceback.print_exc(limit=3)
+        errors.write(f"{run} {camcol} {filter} {field}\n")
+        traceback.print_exc(limit=3, file=errors)
+        errors.write(str(e) + "\n\n")
+
+
+class DetectTrails:
+    """Process a selection of SDSS frames.
+
+    ``DetectTrails(run=2888)``, ``DetectTrails(run=2888, camcol=1, filter='i')``,
+    ``DetectTrails(run=2888, camcol=1, filter='i', field=139).process()`` ... at least one of
+    run / camcol / filter / field (or frame) must be given.  ``results`` / ``errors`` /
+    ``savepath`` choose the output files (appended to), ``debug`` switches all three parameter
+    dictionaries to debug mode, ``params_bright`` / ``params_dim`` / ``params_removestars``
+    replace the defaults; the dictionaries can also be edited on the instance afterwards.
+    """
+
+    _FILTERS = ('u', 'g', 'r', 'i', 'z')
+    _CAMCOLS = (1, 2, 3, 4, 5, 6)
+
+    def __init__(self, **kwargs):
+        save = kwargs.get("savepath", ".")
+        self.kwargs = kwargs
+        self.params_bright, self.params_dim, self.params_removestars = default_params()
+        self.results = kwargs.get("results", os.path.join(save, "results.txt"))
+        self.errors = kwargs.get("errors", os.path.join(save, "errors.txt"))
+        for name in ("params_bright", "params_dim", "params_removestars"):
+            if name in kwargs:
+                setattr(self, name, kwargs[name])
+        if "debug" in kwargs:
+            self.debug = kwargs.pop("debug")
+            for d in (self.params_bright, self.params_dim, self.params_removestars):
+                d["debug"] = self.debug
+        if any(d["debug"] for d in (self.params_removestars, self.params_bright, self.params_dim)):
+            setup_debug()
+        self._load()
+
+    def _runInfo(self):
+        rl = sdssfiles.runlist()
+        w = _np.nonzero(rl["run"] == self._run)[0]
+        if len(w) == 0:
+            raise ValueError("Run %s not found in runList.par" % self._run)
+        return int(rl["startfield"][w[0]]), int(rl["endfield"][w[0]])
+
+    def _getRuns(self):
+        return [int(r) for r in sdssfiles.runlist()["run"]]
+
+    def _load(self):
+        """Selection mode from the keywords given (detecttrails.py:290-342): run, run-camcol,
+        run-filter, run-camcol-filter, camcol-filter, camcol-frame, field."""
+        kw = self.kwargs
+        self._run = self._camcol = self._field = 0
+        self._filter = self._pick = "0"
+        if "run" in kw:
+            self._run, self._pick = kw["run"], "run"
+        if "camcol" in kw:
+            if kw["camcol"] not in self._CAMCOLS:
+                raise ValueError("Nonexisting camcol")
+            self._camcol, self._pick = kw["camcol"], "run-camcol"
+        if "field" in kw or "frame" in kw:
+            if self._camcol == 0:
+                raise ValueError("send camcol= ")
+            self._field = kw["field"] if "field" in kw else kw["frame"]
+        if "filter" in kw:
+            if kw["filter"] not in self._FILTERS:
+                raise ValueError("Nonexistting filter")
+            self._filter = kw["filter"]
+            if self._camcol != 0:
+                self._pick = "camcol-filter"
+            if self._run != 0:
+                self._pick = "run-filter"
+            if self._camcol != 0 and self._run != 0:
+                self._pick = "run-camcol-filter"
+        elif self._field != 0 and self._camcol != 0:
+            self._pick = "camcol-frame"
+        if self._field != 0 and self._camcol != 0 and self._filter != "0":
+            self._pick = "field"
+
+    def _frames(self):
+        """Yield (run, camcol, filter, field) in the reference's loop order (detecttrails.py:350-407)."""
+        pick = self._pick
+        if pick == "camcol-filter":
+            for run in self._getRuns():
+                self._run = run
+                start, end = self._runInfo()
+                for field in range(start, end):
+                    yield run, self._camcol, self._filter, field
+            self._run = 0
+        elif pick == "run":
+            start, end = self._runInfo()
+            for camcol in self._CAMCOLS:
+                for flt in self._FILTERS:
+                    for field in range(start, end):
+                        yield self._run, camcol, flt, field
+        elif pick == "run-filter":
+            start, end = self._runInfo()
+            for camcol in self._CAMCOLS:
+                for field in range(start, end):
+                    yield self._run, camcol, self._filter, field
+        elif pick == "run-camcol":
+            start, end = self._runInfo()
+            for flt in self._FILTERS:
+                for field in range(start, end, 50):  # the reference samples every 50th field here
+                    yield self._run, self._camcol, flt, field
+        elif pick == "run-camcol-filter":
+            start, end = self._runInfo()
+            for field in range(start, end):
+                yield self._run, self._camcol, self._filter, field
+        elif pick == "camcol-frame":
+            for flt in self._FILTERS:
+                yield self._run, self._camcol, flt, self._field
+        elif pick == "field":
+            yield self._run, self._camcol, self._filter, self._field
+
+    def process(self):
+        """Run process_field over the selection; results and errors files are opened in append mode."""
+        with open(self.results, "a") as results, open(self.errors, "a") as errors:
+            for run, camcol, flt, field in self._frames():
+                process_field(results, errors, run, camcol, flt, field, self.params_bright,
+                              self.params_dim, self.params_removestars)

@@ -1,0 +1,214 @@
+"""Per-image trail detection: the bright and the dim pass, on the GPU.
+
+Host-side mirror of the reference module ``lfd/detecttrails/processfield.py``: same function
+names, same arguments (the keys of ``params_bright`` / ``params_dim`` are splatted into them,
+detecttrails.py:125,129), same return values ``(bool, dict-or-None)`` and the same in-place
+side effects on ``img``.  Every image operation (convertScaleAbs, equalizeHist, erode/dilate,
+Canny, contours -> minAreaRect -> fillPoly, HoughLines) runs in liblfdmi.so on the MI355X;
+only the two scalar tails the reference itself evaluates in numpy, ``check_theta``
+(processfield.py:36-150) and ``dictify_hough`` (:266-288), are evaluated here in numpy.
+There is no CPU fallback for the image operations.
+"""
+import os
+
+import numpy as np
+
+from .. import _native
+
+__all__ = ["process_field_bright", "process_field_dim", "check_theta", "dictify_hough",
+           "fit_minAreaRect", "setup_debug", "pathBright", "pathDim"]
+
+pathBright = None
+pathDim = None
+
+_ctx = None
+
+
+def setup_debug():
+    """Point the debug image dumps at $DEBUG_PATH (reference: processfield.py:22-33)."""
+    global pathBright, pathDim
+    where = os.environ.get("DEBUG_PATH")
+    if where is not None:
+        pathBright = where
+        pathDim = where
+
+
+def _device_index():
+    for key in ("LFD_DEVICE", "LOCAL_RANK"):
+        if key in os.environ:
+            return int(os.environ[key])
+    return 0
+
+
+def get_context(h, w, inflight=None):
+    """Process-wide GPU context, grown when a larger image arrives."""
+    global _ctx
+    want = int(inflight or os.environ.get("LFD_INFLIGHT", 4))
+    if _ctx is None or _ctx.max_h * _ctx.max_w < h * w or _ctx.max_h < h or _ctx.max_w < w \
+            or _ctx.max_inflight < want:
+        if _ctx is not None:
+            want = max(want, _ctx.max_inflight)
+            h, w = max(h, _ctx.max_h), max(w, _ctx.max_w)
+            _ctx.close()
+        _ctx = _native.Context(_device_index(), h, w, want)
+    return _ctx
+
+
+def check_theta(hough1, hough2, navg, dro, thetaTresh, lineSetTresh, debug):
+    """Colinearity test between two sets of Hough lines; **True means "not colinear"**.
+
+    Follows processfield.py:89-150: four zero-initialised float64 columns of length ``navg``
+    are filled from the first ``navg`` lines while both sets still have a line ``i`` (a missing
+    line leaves zeros behind); the sets are rejected when the mean rho differs by more than
+    ``dro``, when either set's theta spread exceeds ``thetaTresh``, or when the mean absolute
+    theta difference exceeds ``lineSetTresh``.  Returns ``None`` (falsy) when all tests pass.
+    """
+    cols = np.zeros((4, navg, 1))
+    ro1, ro2, theta1, theta2 = cols
+    for i in range(navg):
+        try:
+            ro1[i] = hough1[i][0][0]
+            ro2[i] = hough2[i][0][0]
+            theta1[i] = hough1[i][0][1]
+            theta2[i] = hough2[i][0][1]
+        except IndexError:
+            continue
+    if debug:
+        print(f"rho test: |{np.average(ro1)} - {np.average(ro2)}| vs dro={dro}")
+    if abs(np.average(ro1) - np.average(ro2)) > dro:
+        return True
+    spread1 = abs(theta1.max() - theta1.min())
+    spread2 = abs(theta2.max() - theta2.min())
+    if debug:
+        print(f"theta spreads {spread1} {spread2} vs {thetaTresh}; "
+              f"set difference {np.average(abs(theta1 - theta2))} vs {lineSetTresh}")
+    if spread1 > thetaTresh or spread2 > thetaTresh:
+        return True
+    if np.average(abs(theta1 - theta2)) > lineSetTresh:
+        return True
+    return None
+
+
+def dictify_hough(shape, houghVals):
+    """(rho, theta) -> two points far along the line, as the reference does (processfield.py:266-288)."""
+    rho, theta = houghVals
+    reach = shape[0] + shape[1]
+    c, s = np.cos(theta), np.sin(theta)
+    x0, y0 = c * rho, s * rho
+    return {"x1": int(x0 - reach * s), "y1": int(y0 + reach * c),
+            "x2": int(x0 + reach * s), "y2": int(y0 - reach * c)}
+
+
+def _as_native_image(img):
+    """Array of a dtype the kernels read directly (u8 / f32 / f64); torch CUDA tensors pass through."""
+    if _native._is_dev(img):
+        _native._dtype_code(img)  # raises TypeError for unsupported dtypes
+        return img.contiguous()
+    if img.dtype in (np.uint8, np.float32, np.float64):
+        return np.ascontiguousarray(img)
+    if img.dtype.kind in "iub":
+        return np.ascontiguousarray(img, dtype=np.float64)  # exact for |x| < 2**53
+    if img.dtype == np.float16:
+        return np.ascontiguousarray(img, dtype=np.float32)
+    raise TypeError(f"unsupported image dtype {img.dtype}")
+
+
+def fit_minAreaRect(img, contoursMode, contoursMethod, minAreaRectMinLen, lwTresh, debug):
+    """Canny(0, 255) -> contours -> minimum-area rectangles -> (detection, box image)
+    (reference: processfield.py:201-263)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    ctx = get_context(*img.shape)
+    detection, box_img, _ = ctx.fit_min_area_rect(img, contoursMode, contoursMethod,
+                                                  minAreaRectMinLen, lwTresh)
+    return detection, box_img
+
+
+def _lines_as_cv(lines, n_total):
+    k = min(int(n_total), len(lines))
+    if k == 0:
+        return None
+    return np.ascontiguousarray(lines[:k]).reshape(k, 1, 2)
+
+
+def _finish(ctx, res, lines_equ, lines_box, shape, nlinesInSet, dro, thetaTresh, lineSetTresh,
+            debug, tag, path):
+    status = int(res["status"])
+    if status not in (0, _native.ERR_NOLINES):
+        raise _native.NativeError(status, "frame failed on the device")
+    if debug:
+        _dump_debug(ctx, shape, tag, path)
+    if not res["detection"]:
+        if debug:
+            print(f"{tag}: no boxes found")
+        return (False, None)
+    equhough = _lines_as_cv(lines_equ, res["n_lines_equ"])
+    boxhough = _lines_as_cv(lines_box, res["n_lines_box"])
+    if equhough is None or boxhough is None:
+        # cv2.HoughLines returned None: the reference dies inside check_theta with this error
+        raise TypeError("'NoneType' object is not subscriptable")
+    if check_theta(equhough, boxhough, nlinesInSet, dro, thetaTresh, lineSetTresh, debug):
+        return (False, None)
+    return (True, dictify_hough(shape, equhough[0][0]))
+
+
+def _dump_debug(ctx, shape, tag, path):
+    """Stage images of slot 0 as PNGs (names after docs/source/detecttrails/detparams.rst:39-54)."""
+    from . import debugio
+    if path is None:
+        raise TypeError("expected str, bytes or os.PathLike object, not NoneType")  # os.path.join(None, ..)
+    names = {"BRIGHT": ("2dilateBRIGHT.png", "3contoursBRIGHT.png"),
+             "DIM": ("8openedDIM.png", "9contoursDIM.png")}[tag]
+    h, w = shape
+    debugio.write_png(os.path.join(path, names[0]), ctx.get_stage(0, _native.STAGE_EQU, h, w))
+    debugio.write_png(os.path.join(path, names[1]), ctx.get_stage(0, _native.STAGE_BOX, h, w))
+
+
+def process_field_bright(img, lwTresh, thetaTresh, dilateKernel, contoursMode, contoursMethod,
+                         minAreaRectMinLen, houghMethod, nlinesInSet, lineSetTresh, dro, debug):
+    """Bright-trail pass (reference: processfield.py:291-388).
+
+    ``img`` is clamped at zero IN PLACE (``img[img < 0] = 0``), converted to 8 bit, equalised,
+    dilated, screened with minimum-area rectangles and, if any rectangle qualifies, fitted with
+    Hough lines on the dilated image and on the rectangle image; colinear line sets give
+    ``(True, {"x1":..,"y1":..,"x2":..,"y2":..})``, anything else ``(False, None)``.
+    """
+    img[img < 0] = 0
+    dev_img = _as_native_image(img)
+    ctx = get_context(*tuple(dev_img.shape))
+    params = dict(lwTresh=lwTresh, thetaTresh=thetaTresh, dilateKernel=dilateKernel,
+                  contoursMode=contoursMode, contoursMethod=contoursMethod,
+                  minAreaRectMinLen=minAreaRectMinLen, houghMethod=houghMethod,
+                  nlinesInSet=nlinesInSet, lineSetTresh=lineSetTresh, dro=dro)
+    res, le, lb = ctx.process_bright(dev_img, params)
+    return _finish(ctx, res, le, lb, tuple(dev_img.shape), nlinesInSet, dro, thetaTresh, lineSetTresh, debug,
+                   "BRIGHT", pathBright)
+
+
+def process_field_dim(img, minFlux, addFlux, lwTresh, thetaTresh, erodeKernel, dilateKernel,
+                      contoursMode, contoursMethod, minAreaRectMinLen, houghMethod, nlinesInSet,
+                      dro, lineSetTresh, debug):
+    """Dim-trail pass (reference: processfield.py:391-506).
+
+    IN PLACE: ``img[img < minFlux] = 0; img[img > 0] += addFlux``.  Then 8-bit conversion,
+    equalisation, erosion, dilation and the same rectangle / Hough screening as the bright pass.
+    Integer images raise like numpy does for ``uint8 += float``.
+    """
+    if _native._is_dev(img):
+        if not img.is_floating_point():
+            raise TypeError("dim pass needs a floating-point image")
+        gpu_src = img.contiguous().clone()
+    else:
+        gpu_src = _as_native_image(img).copy() if img.dtype.kind == "f" else None
+    img[img < minFlux] = 0
+    img[img > 0] += addFlux  # raises numpy's casting error for integer images, as the reference
+    if gpu_src is None:  # pragma: no cover - unreachable: the line above raised
+        raise TypeError("dim pass needs a floating-point image")
+    ctx = get_context(*tuple(gpu_src.shape))
+    params = dict(minFlux=minFlux, addFlux=addFlux, lwTresh=lwTresh, thetaTresh=thetaTresh,
+                  erodeKernel=erodeKernel, dilateKernel=dilateKernel, contoursMode=contoursMode,
+                  contoursMethod=contoursMethod, minAreaRectMinLen=minAreaRectMinLen,
+                  houghMethod=houghMethod, nlinesInSet=nlinesInSet, lineSetTresh=lineSetTresh, dro=dro)
+    # the device applies the same masking to the untouched copy (PREP_DIM)
+    res, le, lb = ctx.process_dim(gpu_src, params, after_bright=False)
+    return _finish(ctx, res, le, lb, tuple(gpu_src.shape), nlinesInSet, dro, thetaTresh, lineSetTresh, debug,
+                   "DIM", pathDim)
