@@ -124,3 +124,48 @@ def pack_catalogs(cats, filter_index=None):
         for key in ("ROWC", "COLC", "PSFMAG", "PETROTH90", "NOBSERVE", "NDETECT"):
             out[key][i, :k] = c[key]
     return out
+
+
+def make_portable_frame(k, shape=(512, 768), n_star=40, with_catalog=True):
+    """A frame built ONLY from integer RNG draws and IEEE +,-,*,/,sqrt, so that every machine
+    produces the same bits (``make_frame`` uses exp/normal, whose last bit may depend on the
+    CPU's vector math library).  Used for golden fixtures that travel to the GPU box."""
+    h, w = shape
+    rng = np.random.default_rng(np.random.PCG64(7700000 + int(k)))
+    u = rng.integers(0, 1 << 16, (h, w), dtype=np.int64)
+    img = ((u - 32768).astype(np.float64) / 65536.0 * 0.1).astype(np.float32)       # sky in [-0.05, 0.05)
+    ys = rng.integers(0, h, n_star)
+    xs = rng.integers(0, w, n_star)
+    amp = rng.integers(1, 400, n_star)
+    rad = rng.integers(2, 7, n_star)
+    yy = np.arange(h, dtype=np.int64)[:, None]
+    xx = np.arange(w, dtype=np.int64)[None, :]
+    for y, x, a, r in zip(ys, xs, amp, rad):
+        y0, y1, x0, x1 = max(y - r, 0), min(y + r + 1, h), max(x - r, 0), min(x + r + 1, w)
+        d = np.abs(yy[y0:y1] - y) + np.abs(xx[:, x0:x1] - x)
+        prof = np.maximum(0, (r + 1) - d).astype(np.float64) * (float(a) / float(r + 1))
+        img[y0:y1, x0:x1] += prof.astype(np.float32)
+    kind = ("bright", "dim", "none")[k % 3]
+    dirs = [(1, 2), (2, 1), (1, 1), (3, -1), (-1, 3), (5, 2), (-2, 5), (1, -4)]
+    a, b = dirs[int(rng.integers(0, len(dirs)))]
+    y0 = int(rng.integers(h // 4, 3 * h // 4))
+    x0 = int(rng.integers(w // 4, 3 * w // 4))
+    if kind != "none":
+        num = np.abs((xx - x0) * a - (yy - y0) * b).astype(np.float64)          # |cross| = distance * norm
+        dist = num / np.sqrt(float(a * a + b * b))
+        peak = 6.0 if kind == "bright" else 0.2
+        prof = np.maximum(0.0, 1.0 - dist / 5.0) * peak
+        img += prof.astype(np.float32)
+    truth = {"k": int(k), "streak": kind, "y0": y0, "x0": x0, "dir": [a, b]}
+    cat = None
+    if with_catalog:
+        n = n_star
+        rowc = np.repeat(ys.astype(np.float32)[:, None], 5, 1) + np.float32(0.25)
+        colc = np.repeat(xs.astype(np.float32)[:, None], 5, 1) + np.float32(0.25)
+        mag = (rng.integers(140, 240, (n, 5)).astype(np.float32)) / np.float32(10.0)
+        pet = (rng.integers(-10, 120, (n, 5)).astype(np.float32)) / np.float32(8.0)
+        nob = rng.integers(1, 3, n).astype(np.int32)
+        nde = np.where(rng.integers(0, 10, n) < 8, nob, nob + 1).astype(np.int32)
+        mag[::9, int(k) % 5] = -9999.0
+        cat = {"ROWC": rowc, "COLC": colc, "PSFMAG": mag, "PETROTH90": pet, "NOBSERVE": nob, "NDETECT": nde}
+    return img, cat, truth

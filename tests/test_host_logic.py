@@ -1,0 +1,168 @@
+"""Host-side logic that needs no GPU: DetectTrails keyword handling and frame selection
+(reference: detecttrails.py:199-267, :290-407), FITS / SDSS-path plumbing, results and errors
+text formats, sharding arithmetic, synthetic-data determinism."""
+import hashlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from lfd_amd import batch, synth
+from lfd_amd.detecttrails import DetectTrails, default_params, detecttrails, fitslite, sdssfiles
+
+
+def test_default_params_match_reference_defaults():
+    pb, pd, prs = default_params()
+    assert pb["dilateKernel"].shape == (4, 4) and pb["houghMethod"] == 20 and pb["dro"] == 25
+    assert pb["contoursMode"] == 1 and pb["contoursMethod"] == 1 and pb["nlinesInSet"] == 3
+    assert pd["erodeKernel"].shape == (3, 3) and pd["dilateKernel"].shape == (9, 9) and pd["dro"] == 20
+    assert pd["minFlux"] == 0.02 and pd["addFlux"] == 0.5
+    assert prs["filter_caps"] == {'u': 22.0, 'g': 22.2, 'r': 22.2, 'i': 21.3, 'z': 20.5}
+    assert set(pb) == {"lwTresh", "thetaTresh", "dilateKernel", "contoursMode", "contoursMethod",
+                       "minAreaRectMinLen", "houghMethod", "nlinesInSet", "lineSetTresh", "dro", "debug"}
+
+
+@pytest.mark.parametrize("kw,pick", [
+    (dict(run=94), "run"), (dict(run=94, camcol=1), "run-camcol"), (dict(run=94, filter="i"), "run-filter"),
+    (dict(run=94, camcol=1, filter="i"), "run-camcol-filter"), (dict(camcol=1, filter="i"), "camcol-filter"),
+    (dict(run=94, camcol=1, field=12), "camcol-frame"), (dict(run=94, camcol=1, filter="i", field=12), "field"),
+    (dict(run=94, camcol=1, filter="i", frame=12), "field")])
+def test_selection_modes(kw, pick):
+    assert DetectTrails(**kw)._pick == pick
+
+
+def test_bad_keywords_raise():
+    with pytest.raises(ValueError):
+        DetectTrails(run=1, camcol=7)
+    with pytest.raises(ValueError):
+        DetectTrails(run=1, filter="x")
+    with pytest.raises(ValueError):
+        DetectTrails(run=1, field=5)
+
+
+def test_param_kwargs_land_in_their_own_dicts_and_debug_fans_out():
+    _, pd, prs = default_params()
+    pd["minFlux"] = 0.03
+    prs["maxxy"] = 50
+    d = DetectTrails(run=1, params_dim=pd, params_removestars=prs, debug=False)
+    assert d.params_dim["minFlux"] == 0.03 and d.params_removestars["maxxy"] == 50
+    assert d.params_bright["dro"] == 25          # not overwritten (reference bug C8 fixed)
+    assert d.results == os.path.join(".", "results.txt")
+    d2 = DetectTrails(run=1, savepath="/tmp/x", results="/tmp/r.txt")
+    assert d2.results == "/tmp/r.txt" and d2.errors == "/tmp/x/errors.txt"
+
+
+def _write_runlist(tmp_path):
+    redux = tmp_path / "photo" / "redux"
+    redux.mkdir(parents=True)
+    (redux / "runList.par").write_text(
+        "typedef struct {\n int run;\n char rerun[];\n int exist;\n int done;\n int calib;\n"
+        " int startfield;\n int endfield;\n char machine[];\n char disk[];\n} RUNDATA;\n\n"
+        "RUNDATA 94 301 1 1 1 100 104 m d\nRUNDATA 125 301 1 1 1 11 13 m d\n"
+        "RUNDATA 5194 157 1 1 1 1 2 m d\nRUNDATA 5194 301 1 1 1 30 33 m d\n")
+    os.environ["PHOTO_REDUX"] = str(redux)
+    os.environ["BOSS_PHOTOOBJ"] = str(tmp_path / "photoObj")
+    sdssfiles._runlist_cache.clear()
+
+
+def test_runlist_and_filenames(tmp_path):
+    _write_runlist(tmp_path)
+    rl = sdssfiles.runlist()
+    assert rl["run"].tolist() == [94, 125, 5194] and sdssfiles.find_rerun(5194) == "301"
+    f = sdssfiles.filename("frame", 94, 3, 101, "r")
+    assert f.endswith("photoObj/frames/301/94/3/frame-r-000094-3-0101.fits")
+    p = sdssfiles.filename("photoObj", 94, 3, 101)
+    assert p.endswith("photoObj/301/94/3/photoObj-000094-3-0101.fits")
+    with pytest.raises(ValueError):
+        sdssfiles.find_rerun(7)
+
+
+def test_frame_iteration_order(tmp_path):
+    _write_runlist(tmp_path)
+    fr = list(DetectTrails(run=94, camcol=2, filter="g")._frames())
+    assert fr == [(94, 2, "g", f) for f in range(100, 104)]
+    fr = list(DetectTrails(run=94, camcol=2)._frames())
+    assert fr == [(94, 2, flt, 100) for flt in "ugriz"]           # every 50th field (reference quirk C11)
+    fr = list(DetectTrails(run=125)._frames())
+    assert len(fr) == 6 * 5 * 2 and fr[0] == (125, 1, "u", 11) and fr[-1] == (125, 6, "z", 12)
+    fr = list(DetectTrails(camcol=1, filter="z")._frames())
+    assert [x[0] for x in fr] == [94] * 4 + [125] * 2 + [5194] * 3
+
+
+def test_fits_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    img = rng.normal(0, 1, (17, 23)).astype(np.float32)
+    hdr = {"TAI": 4.5e9, "CRPIX1": 1025.0, "CRPIX2": 745.0, "CRVAL1": 10.5, "CRVAL2": -1.25,
+           "CD1_1": 1e-4, "CD1_2": 2e-5, "CD2_1": -2e-5, "CD2_2": 1e-4}
+    path = tmp_path / "frame.fits"
+    fitslite.write_image(path, img, hdr)
+    got, h = fitslite.read_image(path)
+    assert got.dtype == np.float32 and np.array_equal(got, img)
+    assert all(h[k] == v for k, v in hdr.items())
+    cols = {"OBJC_TYPE": np.arange(5, dtype=np.int32), "ROWC": rng.random((5, 5)).astype(np.float32),
+            "NOBSERVE": np.ones(5, np.int32), "PSFMAG": rng.random((5, 5)).astype(np.float32)}
+    tpath = tmp_path / "t.fits"
+    fitslite.write_table(tpath, cols)
+    t = fitslite.read_table(tpath, ["ROWC", "NOBSERVE", "PSFMAG"])
+    assert np.array_equal(t["ROWC"], cols["ROWC"]) and np.array_equal(t["NOBSERVE"], cols["NOBSERVE"])
+    with pytest.raises(KeyError):
+        fitslite.read_table(tpath, ["NDETECT"])
+    import bz2
+    (tmp_path / "frame.fits.bz2").write_bytes(bz2.compress(path.read_bytes()))
+    got2, _ = fitslite.read_image(tmp_path / "frame.fits.bz2")
+    assert np.array_equal(got2, img)
+
+
+def test_process_field_row_and_error_formats(tmp_path, monkeypatch):
+    _write_runlist(tmp_path)
+    hdr = {"TAI": 4.5e9, "CRPIX1": 1025.0, "CRPIX2": 745.0, "CRVAL1": 10.5, "CRVAL2": -1.25,
+           "CD1_1": 1e-4, "CD1_2": 2e-5, "CD2_1": -2e-5, "CD2_2": 1e-4}
+    fpath = sdssfiles.filename("frame", 94, 1, 100, "r")
+    os.makedirs(os.path.dirname(fpath))
+    fitslite.write_image(fpath, np.zeros((8, 9), np.float32), hdr)
+    ppath = sdssfiles.filename("photoObj", 94, 1, 100)
+    os.makedirs(os.path.dirname(ppath))
+    fitslite.write_table(ppath, {"OBJC_TYPE": np.zeros(1, np.int32), "TYPE": np.zeros((1, 5), np.int32),
+                                 "ROWC": np.zeros((1, 5), np.float32), "COLC": np.zeros((1, 5), np.float32),
+                                 "PETROTH90": np.zeros((1, 5), np.float32), "PSFMAG": np.zeros((1, 5), np.float32),
+                                 "NOBSERVE": np.ones(1, np.int32), "NDETECT": np.ones(1, np.int32)})
+    seen = {}
+
+    def fake(img, cat, flt, pb, pd, prs):
+        seen["shape"], seen["n"] = img.shape, len(cat["NOBSERVE"])
+        return True, {"x1": 1, "y1": -2, "x2": 3, "y2": 4}, None
+
+    monkeypatch.setattr(detecttrails, "process_frame_arrays", fake)
+    pb, pd, prs = default_params()
+    res, err = io.StringIO(), io.StringIO()
+    detecttrails.process_field(res, err, 94, 1, "r", 100, pb, pd, prs)
+    row = res.getvalue().split()
+    assert len(row) == 17 and row[:4] == ["94", "1", "r", "100"] and row[-4:] == ["1", "-2", "3", "4"]
+    assert float(row[4]) == 4.5e9 and float(row[6]) == 745.0 and err.getvalue() == ""
+    assert seen == {"shape": (8, 9), "n": 1}
+    detecttrails.process_field(res, err, 94, 1, "r", 101, pb, pd, prs)      # missing file -> errors entry
+    e = err.getvalue()
+    assert e.startswith("94 1 r 101\n") and "FileNotFoundError" in e and e.endswith("\n\n")
+
+
+def test_shard_bounds():
+    assert batch.shard_bounds(8192, 8) == [(1024 * g, 1024 * (g + 1)) for g in range(8)]
+    assert batch.shard_bounds(10, 4) == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert batch.shard_bounds(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    assert batch.shard_range(256, 0, 1) == (0, 256)
+
+
+def test_synthetic_frames_are_deterministic():
+    img, cat, truth = synth.make_frame(3, shape=(96, 128), n_star=12)
+    img2, cat2, truth2 = synth.make_frame(3, shape=(96, 128), n_star=12)
+    assert np.array_equal(img, img2) and truth == truth2 and np.array_equal(cat["PSFMAG"], cat2["PSFMAG"])
+    with open(os.path.join(os.path.dirname(__file__), "golden", "synth_checksums.json")) as f:
+        gold = json.load(f)
+    for k in (0, 1):
+        im, c, t = synth.make_frame(k)
+        assert hashlib.sha256(im.tobytes()).hexdigest() == gold[str(k)]["image_sha256"]
+        assert t["streak"] == gold[str(k)]["streak"] and len(c["NOBSERVE"]) == gold[str(k)]["n_obj"]
+    c1 = synth.make_config1_frame()
+    assert c1.dtype == np.uint8 and c1.shape == (1489, 2048) and set(np.unique(c1)) == {0, 200, 255}
