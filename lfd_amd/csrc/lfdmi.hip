@@ -20,6 +20,7 @@
 #include "k_rect.h"
 
 #define LFD_PI 3.1415926535897932384626433832795
+#define MAX_ANGLES 4096 // rows of the cos/sin table (theta >= pi/4096)
 
 // one timing slot per kernel (HIP events on the launch stream, see lfdmi_enable_timing)
 enum {
@@ -196,7 +197,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     RET(dmalloc(ctx, &ctx->accum, G * 2 * ctx->acc_cap));
     RET(dmalloc(ctx, &ctx->peaks, G * 2 * ctx->peak_cap));
     RET(dmalloc(ctx, &ctx->lines, G * 2 * LFDMI_MAX_SET_LINES * 2));
-    RET(dmalloc(ctx, &ctx->tab, (size_t)2 * (na + 8)));
+    RET(dmalloc(ctx, &ctx->tab, (size_t)2 * MAX_ANGLES));
     RET(dmalloc(ctx, &ctx->counters, G * C_COUNT));
     RET(dmalloc(ctx, &ctx->need_dim, G));
     RET(dmalloc(ctx, &ctx->pass_flags, G));
@@ -258,6 +259,7 @@ static int check_shape(lfdmi_ctx *ctx, int n, int h, int w) {
     if ((size_t)h * w > ctx->N || h > 65535 || w > 65535 || LFD_WQ(w) * (size_t)h > (size_t)ctx->wq * ctx->H)
         return fail(ctx, LFDMI_ERR_CAPACITY, "frame larger than the context was created for");
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, LFDMI_ERR_HIP, "hipSetDevice");
+    (void)hipGetLastError(); // a failed earlier call must not poison this one
     return 0;
 }
 
@@ -418,7 +420,7 @@ static int ensure_tables(lfdmi_ctx *ctx, int h, int w, double rho_d, double thet
     if (!(rho > 0) || !(theta > 0)) return fail(ctx, LFDMI_ERR_ARG, "rho and theta must be positive");
     int na, nr;
     lfdmi_hough_dims(h, w, rho_d, theta_d, &na, &nr);
-    if (na <= 0 || nr <= 0 || (size_t)(na + 2) * (nr + 2) > ctx->acc_cap || (size_t)na * nr > ctx->peak_cap)
+    if (na <= 0 || nr <= 0 || na > MAX_ANGLES || (size_t)(na + 2) * (nr + 2) > ctx->acc_cap || (size_t)na * nr > ctx->peak_cap)
         return fail(ctx, LFDMI_ERR_CAPACITY, "Hough accumulator larger than the workspace (rho < 1 px or theta < 1 deg)");
     std::vector<float> t((size_t)2 * na);
     float irho = 1 / rho;

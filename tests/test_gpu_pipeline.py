@@ -76,6 +76,7 @@ def test_device_resident_frames_and_inplace_blotting(gpu_ctx, oracle):
     packed = synth.pack_catalogs(list(cats))
     dframes = torch.from_numpy(np.stack(frames)).cuda()
     dcat = {k: torch.from_numpy(v).cuda() for k, v in packed.items()}
+    torch.cuda.synchronize()
     res = gpu_ctx.detect_batch(dframes, pb, pd, dcat, rs_g)
     for i in range(2):
         ref = frames[i].copy()
@@ -174,9 +175,12 @@ def test_full_batch_properties_at_baseline_size(gpu_ctx):
     pb, pd, prs = params()
     frames = np.stack([synth.make_frame(k, with_catalog=False)[0] for k in range(16)] * 4)
     d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
     res = gpu_ctx.detect_batch(d, pb, pd)
     assert res[:16].tobytes() == res[16:32].tobytes() == res[48:].tobytes()
     perm = np.random.default_rng(0).permutation(64)
-    res_p = gpu_ctx.detect_batch(d[torch.from_numpy(perm).cuda()].contiguous(), pb, pd)
+    dp = d[torch.from_numpy(perm).cuda()].contiguous()
+    torch.cuda.synchronize()          # the context runs on its own stream: inputs must be complete
+    res_p = gpu_ctx.detect_batch(dp, pb, pd)
     assert res_p.tobytes() == res[perm].tobytes()
     assert (res["status"] == 0).all() and set(np.unique(res["found"])) == {0, 1, 2}
