@@ -16,6 +16,7 @@ enum {
     C_NPEAK_BOX = 6,
     C_OVERFLOW = 7,  // workspace overflow flag
     C_DETECT = 8,    // fit_minAreaRect's `detection`
+    C_NBIG = 9,      // keys tall enough for the wave-per-key hull path
     C_COUNT = 16
 };
 

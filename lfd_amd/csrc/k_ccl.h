@@ -144,7 +144,10 @@ k_runs_flatten(const u64 *bits, int val, const u64 *mark, int *L, int *YM, int *
         int p = y * w + xs;
         int root = uf_find(Lg, p);
         if (root != p) Lg[p] = root;
-        atomicMax(&YMg[root], y);
+        // last row of the component: needed for edge components here; for 0-components only
+        // holes need it (k_bg_extent) -- the outside is one giant component and every one of
+        // its runs would hammer the same word
+        if (val) atomicMax(&YMg[root], y);
         int xe = run_end(row, xs, val, w);
         bool flag;
         if (val) {
@@ -160,6 +163,26 @@ k_runs_flatten(const u64 *bits, int val, const u64 *mark, int *L, int *YM, int *
             flag = (y == 0) || (y == h - 1) || (xs == 0) || (xe == w - 1);
         }
         if (flag) FLg[root] = 1;
+    }
+}
+
+// last row of every hole (0-component that does not touch the frame); runs after k_runs_flatten
+__global__ void __launch_bounds__(256)
+k_bg_extent(const u64 *bits, const int *L, int *YM, const int *FL, int h, int w, const int *active) {
+    int g = blockIdx.y;
+    if (active && !active[g]) return;
+    int wq = LFD_WQ(w);
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= h * wq) return;
+    int y = idx / wq, q = idx - y * wq;
+    const u64 *row = bits + (size_t)g * h * wq + (size_t)y * wq;
+    u64 s = start_bits(row, q, 0, w);
+    size_t N = (size_t)h * w;
+    while (s) {
+        int b = __ffsll((long long)s) - 1;
+        s &= s - 1;
+        int root = L[g * N + y * w + (q << 6) + b];
+        if (!FL[g * N + root]) atomicMax(&YM[g * N + root], y);
     }
 }
 

@@ -47,14 +47,19 @@ k_pixlist(const u64 *bits, uint32_t *list, int *counters, int cidx, int h, int w
     }
 }
 
-#define VOTE_THREADS 512
+#define VOTE_THREADS 1024
+#define VOTE_UNROLL 8
 
-// grid (nslabs, n_images_per_slot, G).  accum layout per (slot, image): (numangle+2) x (numrho+2).
+// grid (nslabs * nsplit, n_images_per_slot, G).  accum layout per (slot, image):
+// (numangle+2) x (numrho+2).  With nsplit > 1 the pixel list of one image is cut into nsplit
+// pieces handled by different workgroups whose LDS slabs are merged with global atomic adds
+// (the accumulator is zeroed beforehand); with nsplit == 1 the slab is stored directly.
 __global__ void __launch_bounds__(VOTE_THREADS)
 k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, const float *tab,
-             int *accum, int numangle, int numrho, int apb, size_t list_cap, size_t acc_cap,
+             int *accum, int numangle, int numrho, int apb, int nsplit, size_t list_cap, size_t acc_cap,
              const int *active, int need_detect) {
-    int g = blockIdx.z, im = blockIdx.y, slab = blockIdx.x;
+    int g = blockIdx.z, im = blockIdx.y;
+    int slab = blockIdx.x / nsplit, split = blockIdx.x - slab * nsplit;
     if (active && !active[g]) return;
     const int *cnt = counters + g * C_COUNT;
     if (need_detect && !cnt[C_DETECT]) return;
@@ -62,30 +67,46 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     const int stride = numrho | 1; // odd row stride spreads the lanes over the LDS banks
     int a0 = slab * apb;
     int na = min(apb, numangle - a0);
+    int n = cnt[im ? C_NPIX_BOX : C_NPIX_EQU];
+    if ((size_t)n > list_cap) n = (int)list_cap;
+    // this workgroup's piece of the list, in multiples of the unroll width
+    int per = ((n + nsplit - 1) / nsplit + VOTE_UNROLL - 1) / VOTE_UNROLL * VOTE_UNROLL;
+    int begin = min(n, split * per), end = min(n, begin + per);
+    if (nsplit > 1 && begin >= end) return; // nothing to add
     for (int k = threadIdx.x; k < apb * stride; k += VOTE_THREADS) acc[k] = 0;
     __syncthreads();
     const uint32_t *list = (im ? list1 : list0) + (size_t)g * list_cap;
-    int n = cnt[im ? C_NPIX_BOX : C_NPIX_EQU];
-    if ((size_t)n > list_cap) n = (int)list_cap;
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int lane = threadIdx.x & 63;
+    int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: pixel loads become scalar
     bool act = lane < na;
     float c = 0.f, s = 0.f;
     if (act) { c = tab[a0 + lane]; s = tab[numangle + a0 + lane]; }
     int *myrow = acc + lane * stride;
     const int roff = (numrho - 1) / 2;
-    for (int i0 = wv * 64; i0 < n; i0 += (VOTE_THREADS / 64) * 64) {
-        uint32_t pv = (i0 + lane < n) ? list[i0 + lane] : 0u;
-        int m = min(64, n - i0);
-        for (int k = 0; k < m; k++) {
-            uint32_t p = (uint32_t)__shfl((int)pv, k);
+    const int nw = VOTE_THREADS / 64;
+    for (int i0 = begin + wv * VOTE_UNROLL; i0 < end; i0 += nw * VOTE_UNROLL) {
+        uint32_t px[VOTE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < VOTE_UNROLL; u++) px[u] = (i0 + u < end) ? list[i0 + u] : 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < VOTE_UNROLL; u++) {
+            uint32_t p = px[u];
             float fj = (float)(p & 0xffffu), fi = (float)(p >> 16);
             int r = __float2int_rn(__fadd_rn(__fmul_rn(fj, c), __fmul_rn(fi, s))) + roff;
-            if (act && (unsigned)r < (unsigned)numrho) atomicAdd(&myrow[r], 1);
+            if (act && p != 0xffffffffu && (unsigned)r < (unsigned)numrho) atomicAdd(&myrow[r], 1);
         }
     }
     __syncthreads();
     int *ag = accum + ((size_t)g * 2 + im) * acc_cap;
     int rs = numrho + 2;
+    if (nsplit > 1) {
+        for (int k = threadIdx.x; k < na * numrho; k += VOTE_THREADS) {
+            int al = k / numrho, rr = k - al * numrho;
+            int v = acc[al * stride + rr];
+            if (v) atomicAdd(&ag[(size_t)(a0 + al + 1) * rs + rr + 1], v);
+        }
+        return;
+    }
     // rows of this slab, including the zero guard columns
     for (int k = threadIdx.x; k < na * rs; k += VOTE_THREADS) {
         int al = k / rs, rr = k - al * rs;

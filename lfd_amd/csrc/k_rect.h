@@ -12,11 +12,12 @@
 #include "common.h"
 
 #define KEY_HOLE_BIT (1 << 30)
+#define BIG_KEY_ROWS 48 // keys with more rows than this get a whole wave (k_rects_big)
 
 __global__ void __launch_bounds__(256)
 k_keys(const u64 *edge, const int *Lf, const int *YMf, const int *Lb, const int *YMb,
-       const int *FLb, int *SBf, int *SBb, int *PAb, int4 *keys, int2 *rowext, int *counters,
-       int h, int w, int key_cap, int slot_cap, const int *active) {
+       const int *FLb, int *SBf, int *SBb, int *PAb, int4 *keys, int *bigkeys, int2 *rowext,
+       int *counters, int h, int w, int key_cap, int slot_cap, const int *active) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     int wq = LFD_WQ(w);
@@ -57,6 +58,7 @@ k_keys(const u64 *edge, const int *Lf, const int *YMf, const int *Lb, const int 
             if (val) SBf[g * N + p] = base;
             else { SBb[g * N + p] = base; PAb[g * N + p] = parent; }
             kg[ki] = make_int4(p, extent | (val ? 0 : KEY_HOLE_BIT), ymin, base);
+            if (extent > BIG_KEY_ROWS) bigkeys[(size_t)g * key_cap + atomicAdd(&cnt[C_NBIG], 1)] = ki;
             for (int r = 0; r < extent; r++) re[base + r] = make_int2(0x7fffffff, -1);
         }
     }
@@ -137,7 +139,8 @@ struct HullView {
     __device__ __forceinline__ float py(int i) const { return (float)at(i).y; }
 };
 
-__device__ __forceinline__ void hv_vect(const HullView &hv, int i, float *vx, float *vy, float *inv) {
+template <class HV>
+__device__ __forceinline__ void hv_vect(const HV &hv, int i, float *vx, float *vy, float *inv) {
     int j = (i + 1 < hv.n) ? i + 1 : 0;
     int2 a = hv.at(i), b = hv.at(j);
     double dx = (double)__fsub_rn((float)b.x, (float)a.x);
@@ -148,7 +151,8 @@ __device__ __forceinline__ void hv_vect(const HullView &hv, int i, float *vx, fl
 }
 
 // rotcalipers.cpp CALIPERS_MINAREARECT, n > 2.  out = corner, vec1, vec2 (6 floats).
-__device__ void rotating_calipers_dev(const HullView &hv, float *out) {
+template <class HV>
+__device__ void rotating_calipers_dev(const HV &hv, float *out) {
     int n = hv.n;
     float minarea = 3.402823466e+38f;
     int buf_i0 = 0, buf_i5 = 0;
@@ -244,6 +248,55 @@ __device__ __forceinline__ long long cross_i(int2 o, int2 a, int2 b) {
     return (long long)(a.x - o.x) * (b.y - o.y) - (long long)(a.y - o.y) * (b.x - o.x);
 }
 
+// minAreaRect of a hull -> lfd's filter -> boxPoints -> truncated quad appended to the slot's list
+template <class HV>
+__device__ __forceinline__ void rect_from_hull(const HV &hv, double minLen, double lwTresh, int *cnt, int *quads,
+                                               size_t quad_base, bool writer) {
+    float cx = 0, cy = 0, sw = 0, sh = 0, angle = 0;
+    if (hv.n > 2) {
+        float out[6];
+        rotating_calipers_dev(hv, out);
+        cx = __fadd_rn(out[0], __fmul_rn(__fadd_rn(out[2], out[4]), 0.5f));
+        cy = __fadd_rn(out[1], __fmul_rn(__fadd_rn(out[3], out[5]), 0.5f));
+        sw = (float)sqrt((double)out[2] * out[2] + (double)out[3] * out[3]);
+        sh = (float)sqrt((double)out[4] * out[4] + (double)out[5] * out[5]);
+        angle = (float)atan2((double)out[3], (double)out[2]);
+    } else if (hv.n == 2) {
+        float x0 = hv.px(0), y0 = hv.py(0), x1 = hv.px(1), y1 = hv.py(1);
+        cx = __fmul_rn(__fadd_rn(x0, x1), 0.5f);
+        cy = __fmul_rn(__fadd_rn(y0, y1), 0.5f);
+        double dx = (double)__fsub_rn(x1, x0), dy = (double)__fsub_rn(y1, y0);
+        sw = (float)sqrt(dx * dx + dy * dy);
+        sh = 0;
+        angle = (float)atan2(dy, dx);
+    } else {
+        cx = hv.px(0); cy = hv.py(0);
+    }
+    angle = (float)((double)__fmul_rn(angle, 180.0f) / 3.1415926535897932384626433832795);
+    double length, width;
+    if (sw > sh) { length = sw; width = sh; } else { width = sw; length = sh; }
+    if (!(length > minLen && width > minLen)) return;
+    if (!(length / width > lwTresh)) return;
+    // RotatedRect::points
+    double ang = (double)angle * 3.1415926535897932384626433832795 / 180.;
+    float b = __fmul_rn((float)cos(ang), 0.5f);
+    float a_ = __fmul_rn((float)sin(ang), 0.5f);
+    float bx[8];
+    bx[0] = __fsub_rn(__fsub_rn(cx, __fmul_rn(a_, sh)), __fmul_rn(b, sw));
+    bx[1] = __fsub_rn(__fadd_rn(cy, __fmul_rn(b, sh)), __fmul_rn(a_, sw));
+    bx[2] = __fsub_rn(__fadd_rn(cx, __fmul_rn(a_, sh)), __fmul_rn(b, sw));
+    bx[3] = __fsub_rn(__fsub_rn(cy, __fmul_rn(b, sh)), __fmul_rn(a_, sw));
+    bx[4] = __fsub_rn(__fmul_rn(2.f, cx), bx[0]);
+    bx[5] = __fsub_rn(__fmul_rn(2.f, cy), bx[1]);
+    bx[6] = __fsub_rn(__fmul_rn(2.f, cx), bx[2]);
+    bx[7] = __fsub_rn(__fmul_rn(2.f, cy), bx[3]);
+    if (!writer) return;
+    int qi = atomicAdd(&cnt[C_NQUADS], 1);
+    cnt[C_DETECT] = 1;
+    int *qd = quads + (quad_base + qi) * 8;
+    for (int k = 0; k < 8; k++) qd[k] = (int)bx[k]; // np.int32: truncation toward zero
+}
+
 // One thread per key (grid-stride): hull -> minAreaRect -> filter -> boxPoints -> quad.
 // rects (optional, 5 floats per key in key order) is for the per-operator parity test.
 __global__ void __launch_bounds__(64)
@@ -259,6 +312,7 @@ k_rects(const int4 *keys, const int2 *rowext, int2 *hullbuf, int *quads, int *co
     for (int ki = blockIdx.x * blockDim.x + threadIdx.x; ki < nkeys; ki += gridDim.x * blockDim.x) {
         int4 key = kg[ki];
         int extent = key.y & ~KEY_HOLE_BIT, ymin = key.z, base = key.w;
+        if (extent > BIG_KEY_ROWS) continue; // k_rects_big
         int2 *c1 = hb + 2 * (size_t)base, *c2 = c1 + extent;
         int n1 = 0, n2 = 0;
         for (int r = 0; r < extent; r++) {
@@ -290,48 +344,113 @@ k_rects(const int4 *keys, const int2 *rowext, int2 *hullbuf, int *quads, int *co
             if (v.x < best.x || (v.x == best.x && v.y < best.y)) { best = v; s0 = i; }
         }
         hv.s0 = s0;
-        float cx = 0, cy = 0, sw = 0, sh = 0, angle = 0;
-        if (hv.n > 2) {
-            float out[6];
-            rotating_calipers_dev(hv, out);
-            cx = __fadd_rn(out[0], __fmul_rn(__fadd_rn(out[2], out[4]), 0.5f));
-            cy = __fadd_rn(out[1], __fmul_rn(__fadd_rn(out[3], out[5]), 0.5f));
-            sw = (float)sqrt((double)out[2] * out[2] + (double)out[3] * out[3]);
-            sh = (float)sqrt((double)out[4] * out[4] + (double)out[5] * out[5]);
-            angle = (float)atan2((double)out[3], (double)out[2]);
-        } else if (hv.n == 2) {
-            float x0 = hv.px(0), y0 = hv.py(0), x1 = hv.px(1), y1 = hv.py(1);
-            cx = __fmul_rn(__fadd_rn(x0, x1), 0.5f);
-            cy = __fmul_rn(__fadd_rn(y0, y1), 0.5f);
-            double dx = (double)__fsub_rn(x1, x0), dy = (double)__fsub_rn(y1, y0);
-            sw = (float)sqrt(dx * dx + dy * dy);
-            sh = 0;
-            angle = (float)atan2(dy, dx);
-        } else {
-            cx = hv.px(0); cy = hv.py(0);
+        rect_from_hull(hv, minLen, lwTresh, cnt, quads, (size_t)g * key_cap, true);
+    }
+}
+
+
+// ---- big keys: one wave per key, hull candidates filtered in parallel in LDS -----------------
+// A chain candidate p with neighbours a, b (in chain order) that does not make a strict right
+// turn (cross >= 0) lies on or inside the hull and can never be a strict hull vertex; dropping
+// all such points at once and repeating until nothing changes leaves exactly the strictly
+// convex chain the sequential monotone-chain scan produces (the survivors contain every hull
+// vertex and form a strictly convex polyline, which cannot hold a non-vertex).
+struct LdsHullView {
+    const int2 *c1, *c2;
+    int n1, n, s0;
+    __device__ __forceinline__ int2 raw(int i) const { return i < n1 ? c1[i] : c2[i - n1]; }
+    __device__ __forceinline__ int2 at(int i) const {
+        int k = i + s0;
+        if (k >= n) k -= n;
+        return raw(k);
+    }
+    __device__ __forceinline__ float px(int i) const { return (float)at(i).x; }
+    __device__ __forceinline__ float py(int i) const { return (float)at(i).y; }
+};
+
+// compacts the chain held in A (n points) into strictly convex form; returns the buffer holding it
+__device__ __forceinline__ int2 *filter_chain(int2 *A, int2 *B, int *n_io) {
+    int n = *n_io, lane = lfd_lane();
+    for (int pass = 0; pass < 4096 && n > 2; pass++) {
+        int m = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            int i = i0 + lane;
+            bool keep = false;
+            int2 p = make_int2(0, 0);
+            if (i < n) {
+                p = A[i];
+                keep = (i == 0) || (i == n - 1) || cross_i(A[i - 1], p, A[i + 1]) < 0;
+            }
+            u64 bal = __ballot(keep);
+            if (keep) B[m + __popcll(bal & ((1ull << lane) - 1ull))] = p;
+            m += __popcll(bal);
         }
-        angle = (float)((double)__fmul_rn(angle, 180.0f) / 3.1415926535897932384626433832795);
-        double length, width;
-        if (sw > sh) { length = sw; width = sh; } else { width = sw; length = sh; }
-        if (!(length > minLen && width > minLen)) continue;
-        if (!(length / width > lwTresh)) continue;
-        // RotatedRect::points
-        double ang = (double)angle * 3.1415926535897932384626433832795 / 180.;
-        float b = __fmul_rn((float)cos(ang), 0.5f);
-        float a_ = __fmul_rn((float)sin(ang), 0.5f);
-        float bx[8];
-        bx[0] = __fsub_rn(__fsub_rn(cx, __fmul_rn(a_, sh)), __fmul_rn(b, sw));
-        bx[1] = __fsub_rn(__fadd_rn(cy, __fmul_rn(b, sh)), __fmul_rn(a_, sw));
-        bx[2] = __fsub_rn(__fadd_rn(cx, __fmul_rn(a_, sh)), __fmul_rn(b, sw));
-        bx[3] = __fsub_rn(__fsub_rn(cy, __fmul_rn(b, sh)), __fmul_rn(a_, sw));
-        bx[4] = __fsub_rn(__fmul_rn(2.f, cx), bx[0]);
-        bx[5] = __fsub_rn(__fmul_rn(2.f, cy), bx[1]);
-        bx[6] = __fsub_rn(__fmul_rn(2.f, cx), bx[2]);
-        bx[7] = __fsub_rn(__fmul_rn(2.f, cy), bx[3]);
-        int qi = atomicAdd(&cnt[C_NQUADS], 1);
-        cnt[C_DETECT] = 1;
-        int *qd = quads + ((size_t)g * key_cap + qi) * 8;
-        for (int k = 0; k < 8; k++) qd[k] = (int)bx[k]; // np.int32: truncation toward zero
+        __syncthreads(); // one wave per block: orders the LDS writes before the next pass reads them
+        int2 *t = A; A = B; B = t;
+        if (m == n) break;
+        n = m;
+    }
+    *n_io = n;
+    return A;
+}
+
+__global__ void __launch_bounds__(64)
+k_rects_big(const int4 *keys, const int *bigkeys, const int2 *rowext, int *quads, int *counters, int h, int w,
+            int key_cap, int slot_cap, int cap, double minLen, double lwTresh, const int *active) {
+    int g = blockIdx.y;
+    if (active && !active[g]) return;
+    extern __shared__ int2 lds_pts[]; // 4 x cap
+    int *cnt = counters + g * C_COUNT;
+    int nbig = cnt[C_NBIG];
+    const int4 *kg = keys + (size_t)g * key_cap;
+    const int2 *re = rowext + (size_t)g * slot_cap;
+    int lane = lfd_lane();
+    for (int bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+        int4 key = kg[bigkeys[(size_t)g * key_cap + bi]];
+        int extent = key.y & ~KEY_HOLE_BIT, ymin = key.z, base = key.w;
+        if (extent > cap) { if (lane == 0) cnt[C_OVERFLOW] = 1; continue; }
+        int2 *P0 = lds_pts, *P1 = lds_pts + cap, *P2 = lds_pts + 2 * cap, *P3 = lds_pts + 3 * cap;
+        __syncthreads();
+        // chain 1: left-most pixel of every row, rows increasing
+        int n1 = 0;
+        for (int r0 = 0; r0 < extent; r0 += 64) {
+            int r = r0 + lane;
+            int2 e = make_int2(1, 0);
+            if (r < extent) e = re[base + r];
+            bool ok = e.x <= e.y;
+            u64 bal = __ballot(ok);
+            if (ok) P0[n1 + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(e.x, ymin + r);
+            n1 += __popcll(bal);
+        }
+        // chain 2: right-most pixel of every row, rows decreasing
+        int n2 = 0;
+        for (int r0 = 0; r0 < extent; r0 += 64) {
+            int r = extent - 1 - (r0 + lane);
+            int2 e = make_int2(1, 0);
+            if (r >= 0) e = re[base + r];
+            bool ok = e.x <= e.y;
+            u64 bal = __ballot(ok);
+            if (ok) P2[n2 + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(e.y, ymin + r);
+            n2 += __popcll(bal);
+        }
+        __syncthreads();
+        if (n1 == 0) continue;
+        int2 *c1 = filter_chain(P0, P1, &n1);
+        int2 *c2 = filter_chain(P2, P3, &n2);
+        int a = 0, bnd = n2;
+        if (c2[0].x == c1[n1 - 1].x && c2[0].y == c1[n1 - 1].y) a = 1;
+        if (bnd > a && c2[bnd - 1].x == c1[0].x && c2[bnd - 1].y == c1[0].y) bnd--;
+        LdsHullView hv;
+        hv.c1 = c1; hv.c2 = c2 + a; hv.n1 = n1; hv.n = n1 + (bnd - a); hv.s0 = 0;
+        int s0 = 0;
+        int2 best = hv.raw(0);
+        for (int i = 1; i < hv.n; i++) {
+            int2 v = hv.raw(i);
+            if (v.x < best.x || (v.x == best.x && v.y < best.y)) { best = v; s0 = i; }
+        }
+        hv.s0 = s0;
+        // every lane evaluates the same rectangle (uniform control flow, LDS broadcasts); lane 0 writes
+        rect_from_hull(hv, minLen, lwTresh, cnt, quads, (size_t)g * key_cap, lane == 0);
     }
 }
 

@@ -51,6 +51,7 @@ struct lfdmi_ctx {
     int *Lf = nullptr, *YMf = nullptr, *FLf = nullptr, *Lb = nullptr, *YMb = nullptr, *FLb = nullptr;
     int *SBf = nullptr, *SBb = nullptr, *PAb = nullptr;
     int4 *keys = nullptr;
+    int *bigkeys = nullptr;
     int2 *rowext = nullptr, *hullbuf = nullptr;
     int *quads = nullptr;
     uint32_t *pix_equ = nullptr, *pix_box = nullptr;
@@ -189,6 +190,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     for (int **p : {&ctx->Lf, &ctx->YMf, &ctx->FLf, &ctx->Lb, &ctx->YMb, &ctx->FLb, &ctx->SBf, &ctx->SBb, &ctx->PAb})
         RET(dmalloc(ctx, p, G * N));
     RET(dmalloc(ctx, &ctx->keys, G * ctx->key_cap));
+    RET(dmalloc(ctx, &ctx->bigkeys, G * ctx->key_cap));
     RET(dmalloc(ctx, &ctx->rowext, G * ctx->slot_cap));
     RET(dmalloc(ctx, &ctx->hullbuf, G * ctx->slot_cap * 2));
     RET(dmalloc(ctx, &ctx->quads, G * ctx->key_cap * 8));
@@ -203,6 +205,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     RET(dmalloc(ctx, &ctx->pass_flags, G));
     RET(dmalloc(ctx, &ctx->res_dev, G));
     HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_rects_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     return 0;
@@ -394,11 +397,13 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
       KCHK("k_runs_merge4_bg"); }
     { Span sp(ctx, KID_RUNS_FLATTEN_BG);
       k_runs_flatten<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, nullptr, ctx->Lb, ctx->YMb, ctx->FLb, h, w, active);
-      KCHK("k_runs_flatten(bg)"); }
+      KCHK("k_runs_flatten(bg)");
+      k_bg_extent<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lb, ctx->YMb, ctx->FLb, h, w, active);
+      KCHK("k_bg_extent"); }
     HIPCHK(hipMemsetAsync(ctx->boxb, 0, (size_t)nc * BW * sizeof(u64), ctx->stream));
     { Span sp(ctx, KID_KEYS);
     k_keys<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lf, ctx->YMf, ctx->Lb, ctx->YMb, ctx->FLb, ctx->SBf, ctx->SBb,
-                                         ctx->PAb, ctx->keys, ctx->rowext, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, active);
+                                         ctx->PAb, ctx->keys, ctx->bigkeys, ctx->rowext, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, active);
     KCHK("k_keys"); }
     { Span sp(ctx, KID_EXTREMES);
     k_extremes<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lf, ctx->Lb, ctx->FLb, ctx->SBf, ctx->SBb, ctx->PAb, ctx->rowext,
@@ -407,7 +412,14 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     { Span sp(ctx, KID_RECTS);
     k_rects<<<dim3(256, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, ctx->hullbuf, ctx->quads, ctx->counters, h, w,
                                                     ctx->key_cap, ctx->slot_cap, minLen, lwTresh, active);
-    KCHK("k_rects"); }
+    KCHK("k_rects");
+    {
+        int cap = h + 2; // rows a key can span (a hole border adds one row above and below)
+        k_rects_big<<<dim3(48, nc), 64, (size_t)cap * 4 * sizeof(int2), ctx->stream>>>(
+            ctx->keys, ctx->bigkeys, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, cap,
+            minLen, lwTresh, active);
+        KCHK("k_rects_big");
+    } }
     Span sp(ctx, KID_FILL);
     k_fill_quads<<<dim3(FILL_BLOCKS, nc), 256, 0, ctx->stream>>>(ctx->quads, ctx->counters, ctx->boxb, h, w, ctx->key_cap, active);
     KCHK("k_fill_quads");
@@ -456,9 +468,15 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
             k_pixlist<<<wg, 256, 0, ctx->stream>>>(ctx->boxb, ctx->pix_box, ctx->counters, C_NPIX_BOX, h, w, ctx->list_cap, active, need_detect);
             KCHK("k_pixlist(box)");
         } }
+        // cut each pixel list into pieces so that a launch carries >= ~3 workgroups per CU
+        int nsplit = 1;
+        while (nsplit < 8 && nslabs * n_img * nc * nsplit < 768) nsplit <<= 1;
+        if (nsplit > 1)
+            HIPCHK(hipMemsetAsync(ctx->accum, 0, (size_t)nc * 2 * ctx->acc_cap * sizeof(int), ctx->stream));
         Span sp(ctx, KID_VOTE, need_detect);
-        k_hough_vote<<<dim3(nslabs, n_img, nc), VOTE_THREADS, (size_t)apb * stride * 4, ctx->stream>>>(
-            ctx->pix_equ, ctx->pix_box, ctx->counters, ctx->tab, ctx->accum, na, nr, apb, ctx->list_cap, ctx->acc_cap, active, need_detect);
+        k_hough_vote<<<dim3(nslabs * nsplit, n_img, nc), VOTE_THREADS, (size_t)apb * stride * 4, ctx->stream>>>(
+            ctx->pix_equ, ctx->pix_box, ctx->counters, ctx->tab, ctx->accum, na, nr, apb, nsplit, ctx->list_cap, ctx->acc_cap,
+            active, need_detect);
         KCHK("k_hough_vote");
     }
     { Span sp(ctx, KID_PEAKS, need_detect);
