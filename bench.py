@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames-per-gpu", type=int, default=256)
-    ap.add_argument("--inflight", type=int, default=32)
+    ap.add_argument("--inflight", type=int, default=256)
     ap.add_argument("--cpu-sample", type=int, default=24, help="frames timed through the CPU oracle (0 = skip)")
     ap.add_argument("--gen-workers", type=int, default=-1)
     ap.add_argument("--no-removestars", action="store_true")

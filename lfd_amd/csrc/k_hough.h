@@ -48,7 +48,6 @@ k_pixlist(const u64 *bits, uint32_t *list, int *counters, int cidx, int h, int w
 }
 
 #define VOTE_THREADS 1024
-#define VOTE_UNROLL 8
 
 // grid (nslabs * nsplit, n_images_per_slot, G).  accum layout per (slot, image):
 // (numangle+2) x (numrho+2).  With nsplit > 1 the pixel list of one image is cut into nsplit
@@ -70,10 +69,10 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     int n = cnt[im ? C_NPIX_BOX : C_NPIX_EQU];
     if ((size_t)n > list_cap) n = (int)list_cap;
     // this workgroup's piece of the list, in multiples of the unroll width
-    int per = ((n + nsplit - 1) / nsplit + VOTE_UNROLL - 1) / VOTE_UNROLL * VOTE_UNROLL;
+    int per = ((n + nsplit - 1) / nsplit + 63) / 64 * 64;
     int begin = min(n, split * per), end = min(n, begin + per);
     if (nsplit > 1 && begin >= end) return; // nothing to add
-    for (int k = threadIdx.x; k < apb * stride; k += VOTE_THREADS) acc[k] = 0;
+    for (int k = threadIdx.x; k < (apb + 1) * stride; k += VOTE_THREADS) acc[k] = 0;
     __syncthreads();
     const uint32_t *list = (im ? list1 : list0) + (size_t)g * list_cap;
     int lane = threadIdx.x & 63;
@@ -81,19 +80,36 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     bool act = lane < na;
     float c = 0.f, s = 0.f;
     if (act) { c = tab[a0 + lane]; s = tab[numangle + a0 + lane]; }
-    int *myrow = acc + lane * stride;
-    const int roff = (numrho - 1) / 2;
     const int nw = VOTE_THREADS / 64;
-    for (int i0 = begin + wv * VOTE_UNROLL; i0 < end; i0 += nw * VOTE_UNROLL) {
-        uint32_t px[VOTE_UNROLL];
+    // |r| <= (numrho-1)/2 by construction (numrho ~ 2(w+h)/rho, |j cos + i sin| < w+h), as in
+    // OpenCV, which indexes its accumulator without a range check.
+    // lanes without an angle (last slab) vote into a spare row so that the loop stays branch-free:
+    // v_readlane needs every lane's converted coordinates, computed outside any divergent branch
+    int *mybin = acc + (act ? lane : apb) * stride + (numrho - 1) / 2;
+    // One coalesced load fetches 64 list entries per wave; each lane converts its own entry to
+    // float once, then the wave walks the 64 entries with v_readlane (wave-uniform pixel, lane =
+    // angle): 2 readlane + 2 mul + add + rint + cvt + address + one LDS add per pixel.
+    for (int base = begin + wv * 64; base < end; base += nw * 64) {
+        int m = min(64, end - base);
+        uint32_t pv = (lane < m) ? list[base + lane] : 0u;
+        float fxv = (float)(pv & 0xffffu), fyv = (float)(pv >> 16);
+        {
+            int k = 0;
+            for (; k + 8 <= m; k += 8) {
 #pragma unroll
-        for (int u = 0; u < VOTE_UNROLL; u++) px[u] = (i0 + u < end) ? list[i0 + u] : 0xffffffffu;
-#pragma unroll
-        for (int u = 0; u < VOTE_UNROLL; u++) {
-            uint32_t p = px[u];
-            float fj = (float)(p & 0xffffu), fi = (float)(p >> 16);
-            int r = __float2int_rn(__fadd_rn(__fmul_rn(fj, c), __fmul_rn(fi, s))) + roff;
-            if (act && p != 0xffffffffu && (unsigned)r < (unsigned)numrho) atomicAdd(&myrow[r], 1);
+                for (int u = 0; u < 8; u++) {
+                    float fj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fxv), k + u));
+                    float fi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyv), k + u));
+                    int r = __float2int_rn(__fadd_rn(__fmul_rn(fj, c), __fmul_rn(fi, s)));
+                    atomicAdd(&mybin[r], 1);
+                }
+            }
+            for (; k < m; k++) {
+                float fj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fxv), k));
+                float fi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyv), k));
+                int r = __float2int_rn(__fadd_rn(__fmul_rn(fj, c), __fmul_rn(fi, s)));
+                atomicAdd(&mybin[r], 1);
+            }
         }
     }
     __syncthreads();

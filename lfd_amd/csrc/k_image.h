@@ -4,6 +4,7 @@
 // :453-471, :236 (Canny's first half).  All HBM-bound; algorithmic bytes in DESIGN.md.
 #pragma once
 #include "common.h"
+#include "../../include/lfdmi.h"
 
 // ------------------------------------------------------------------------------------------
 // remove_stars: one workgroup per catalogue object; lane 0 evaluates the catalogue tests of
@@ -269,6 +270,105 @@ k_morph_rect(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, in
     }
 }
 
+// Same operator for frames whose width is a multiple of 16 (SDSS 2048, 4096): the tile and a
+// 16-byte halo are fetched as aligned dwords, an all-zero input tile (sky after the bright clamp,
+// or after erosion in the dim pass) short-circuits a dilation, and the result tile is staged in
+// LDS and written with 16 B per lane.
+#define MORPH_HALO 16
+
+template <int OP>
+__global__ void __launch_bounds__(256)
+k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, int h, int w, int kh,
+               int kw, const int *active) {
+    int g = blockIdx.z;
+    if (active && !active[g]) return;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smv[];
+    const int IH = MORPH_TH + kh - 1;
+    const int IWB = MORPH_TW + 2 * MORPH_HALO; // bytes per staged row
+    uint8_t *tin = smv;                       // IH x IWB
+    uint8_t *tmp = smv + IH * IWB;            // IH x MORPH_TW
+    uint8_t *tout = tmp + IH * MORPH_TW;      // MORPH_TH x MORPH_TW
+    __shared__ uint8_t slut[256];
+    __shared__ int rowflag[MORPH_TH + LFDMI_MAX_MORPH_K]; // dilation: staged row holds a non-zero byte
+    const int fill = OP ? 255 : 0;
+    const uint32_t fillw = OP ? 0xffffffffu : 0u;
+    int x0 = blockIdx.x * MORPH_TW, y0 = blockIdx.y * MORPH_TH;
+    int ay = kh / 2, ax = kw / 2;
+    size_t N = (size_t)h * w;
+    const uint8_t *s = src + (size_t)g * N;
+    if (lut) slut[threadIdx.x] = lut[g * 256 + threadIdx.x];
+    if (threadIdx.x < IH) rowflag[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t any = 0;
+    const int IW16 = IWB / 16; // 16-byte pieces per staged row (6)
+    for (int idx = threadIdx.x; idx < IH * IW16; idx += 256) {
+        int iy = idx / IW16, wx = idx - iy * IW16;
+        int gy = y0 + iy - ay, gx = x0 - MORPH_HALO + 16 * wx;
+        uint4 v = make_uint4(fillw, fillw, fillw, fillw);
+        if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = *(const uint4 *)(s + (size_t)gy * w + gx);
+        uint32_t nzv = v.x | v.y | v.z | v.w;
+        if (OP == 0 && nzv) rowflag[iy] = 1;
+        any |= nzv;
+        ((uint4 *)tin)[idx] = v;
+    }
+    int wq = LFD_WQ(w);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int nz = __syncthreads_or(any != 0);
+    uint8_t *d = dst + (size_t)g * N;
+    if (OP == 0 && !nz) {
+        // dilation of an all-zero neighbourhood
+        uint32_t z = lut ? slut[0] : 0u;
+        z |= z << 8; z |= z << 16;
+        if (threadIdx.x < MORPH_TH * 4) {
+            int row = threadIdx.x >> 2, c16 = threadIdx.x & 3;
+            int gy = y0 + row, gx = x0 + 16 * c16;
+            if (gy < h && gx < w) *(uint4 *)(d + (size_t)gy * w + gx) = make_uint4(z, z, z, z);
+        }
+        if (bits) {
+            u64 bal = z ? valid_mask(blockIdx.x, w) : 0ull;
+            if (threadIdx.x < MORPH_TH && y0 + threadIdx.x < h)
+                bits[(size_t)g * h * wq + (size_t)(y0 + threadIdx.x) * wq + blockIdx.x] = bal;
+        }
+        return;
+    }
+    for (int ry = wv; ry < IH; ry += 4) {
+        int m = fill;
+        if (OP || rowflag[ry]) { // an all-zero staged row dilates to zeros
+            const uint8_t *row = tin + ry * IWB + (MORPH_HALO - ax) + lane;
+            for (int dx = 0; dx < kw; dx++) {
+                int v = row[dx];
+                m = OP ? min(m, v) : max(m, v);
+            }
+        }
+        tmp[ry * MORPH_TW + lane] = (uint8_t)m;
+    }
+    __syncthreads();
+    for (int oy = wv; oy < MORPH_TH; oy += 4) {
+        int m = fill;
+        bool live = OP != 0;
+        if (!OP) for (int dy = 0; dy < kh; dy++) live = live || rowflag[oy + dy];
+        if (live)
+            for (int dy = 0; dy < kh; dy++) {
+                int v = tmp[(oy + dy) * MORPH_TW + lane];
+                m = OP ? min(m, v) : max(m, v);
+            }
+        int gy = y0 + oy, gx = x0 + lane;
+        bool valid = gy < h && gx < w;
+        int out = lut ? slut[m] : m;
+        tout[oy * MORPH_TW + lane] = (uint8_t)out;
+        if (bits) {
+            u64 bal = __ballot(valid && out != 0);
+            if (lane == 0 && gy < h) bits[(size_t)g * h * wq + (size_t)gy * wq + blockIdx.x] = bal;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < MORPH_TH * 4) {
+        int row = threadIdx.x >> 2, c16 = threadIdx.x & 3;
+        int gy = y0 + row, gx = x0 + 16 * c16;
+        if (gy < h && gx < w) *(uint4 *)(d + (size_t)gy * w + gx) = *(const uint4 *)(tout + row * MORPH_TW + 16 * c16);
+    }
+}
+
 // arbitrary 0/1 structuring element (the knob is an array: detecttrails.py:205,220-221)
 template <int OP>
 __global__ void __launch_bounds__(256)
@@ -345,17 +445,51 @@ k_canny_nms(const uint8_t *img, u64 *cand, u64 *strong, int h, int w, int low, i
             const int *active) {
     int g = blockIdx.z;
     if (active && !active[g]) return;
+    uint32_t any = 0;
     const int PW = CANNY_TW + 4, PH = CANNY_TH + 4, MW = CANNY_TW + 2, MH = CANNY_TH + 2;
     __shared__ uint8_t px[PH * PW];
     __shared__ int mg[MH * MW];
     int x0 = blockIdx.x * CANNY_TW, y0 = blockIdx.y * CANNY_TH;
     const uint8_t *s = img + (size_t)g * h * w;
-    for (int idx = threadIdx.x; idx < PH * PW; idx += 256) {
-        int ty = idx / PW, tx = idx - ty * PW;
-        int gy = min(max(y0 - 2 + ty, 0), h - 1), gx = min(max(x0 - 2 + tx, 0), w - 1);
-        px[idx] = s[(size_t)gy * w + gx];
+    if ((w & 3) == 0) {
+        // interior columns as aligned dwords (16 per row), the 2-px halo columns as bytes
+        for (int idx = threadIdx.x; idx < PH * 16; idx += 256) {
+            int ty = idx >> 4, wx = idx & 15;
+            int gy = min(max(y0 - 2 + ty, 0), h - 1), gx = x0 + 4 * wx;
+            uint32_t v;
+            if (gx + 3 < w) v = *(const uint32_t *)(s + (size_t)gy * w + gx);
+            else { uint32_t e = s[(size_t)gy * w + w - 1]; v = e | (e << 8) | (e << 16) | (e << 24); }
+            any |= v;
+            uint8_t *p = px + ty * PW + 2 + 4 * wx;
+            p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+        }
+        for (int idx = threadIdx.x; idx < PH * 4; idx += 256) {
+            int ty = idx >> 2, k = idx & 3;
+            int tx = k < 2 ? k : CANNY_TW + k; // 0,1 | 66,67
+            int gy = min(max(y0 - 2 + ty, 0), h - 1), gx = min(max(x0 - 2 + tx, 0), w - 1);
+            uint8_t v = s[(size_t)gy * w + gx];
+            any |= v;
+            px[ty * PW + tx] = v;
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < PH * PW; idx += 256) {
+            int ty = idx / PW, tx = idx - ty * PW;
+            int gy = min(max(y0 - 2 + ty, 0), h - 1), gx = min(max(x0 - 2 + tx, 0), w - 1);
+            uint8_t v = s[(size_t)gy * w + gx];
+            any |= v;
+            px[idx] = v;
+        }
     }
-    __syncthreads();
+    // an all-zero tile (sky) has zero gradient everywhere: no candidate when low >= 0
+    if (!__syncthreads_or(any != 0) && low >= 0) {
+        int wq0 = LFD_WQ(w);
+        if (threadIdx.x < CANNY_TH && y0 + threadIdx.x < h) {
+            size_t o = (size_t)g * h * wq0 + (size_t)(y0 + threadIdx.x) * wq0 + blockIdx.x;
+            cand[o] = 0ull;
+            strong[o] = 0ull;
+        }
+        return;
+    }
     for (int idx = threadIdx.x; idx < MH * MW; idx += 256) {
         int my = idx / MW, mx = idx - my * MW;
         int gy = y0 - 1 + my, gx = x0 - 1 + mx;

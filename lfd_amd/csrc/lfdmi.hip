@@ -331,7 +331,14 @@ static int run_morph(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, u64 *bits
     if (!kernel || kh <= 0 || kw <= 0 || kh > LFDMI_MAX_MORPH_K || kw > LFDMI_MAX_MORPH_K)
         return fail(ctx, LFDMI_ERR_UNSUPPORTED, "structuring element must be 1..31 on both sides");
     Span sp(ctx, op ? KID_ERODE : KID_DILATE);
-    if (all_ones(kernel, kh, kw)) {
+    if (all_ones(kernel, kh, kw) && (w % 16) == 0) {
+        int IH = MORPH_TH + kh - 1;
+        size_t lds = (size_t)IH * (MORPH_TW + 2 * MORPH_HALO) + (size_t)IH * MORPH_TW + (size_t)MORPH_TH * MORPH_TW;
+        dim3 grid((w + MORPH_TW - 1) / MORPH_TW, (h + MORPH_TH - 1) / MORPH_TH, nc);
+        if (op == 0) k_morph_rect_v<0><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active);
+        else k_morph_rect_v<1><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active);
+        KCHK("k_morph_rect_v");
+    } else if (all_ones(kernel, kh, kw)) {
         int IH = MORPH_TH + kh - 1, IW = MORPH_TW + kw - 1;
         size_t lds = ((size_t)(IH * IW + 15) & ~(size_t)15) + (size_t)IH * MORPH_TW;
         dim3 grid((w + MORPH_TW - 1) / MORPH_TW, (h + MORPH_TH - 1) / MORPH_TH, nc);
@@ -455,7 +462,7 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
     RET(ensure_tables(ctx, h, w, rho, theta));
     int na = ctx->numangle, nr = ctx->numrho;
     int stride = nr | 1;
-    int apb = (int)((152 * 1024) / ((size_t)stride * 4));
+    int apb = (int)((152 * 1024) / ((size_t)stride * 4)) - 1; // one spare row for lanes without an angle
     if (apb > 64) apb = 64;
     if (apb < 1) return fail(ctx, LFDMI_ERR_CAPACITY, "numrho too large for one LDS row");
     int nslabs = (na + apb - 1) / apb;
@@ -474,7 +481,7 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         if (nsplit > 1)
             HIPCHK(hipMemsetAsync(ctx->accum, 0, (size_t)nc * 2 * ctx->acc_cap * sizeof(int), ctx->stream));
         Span sp(ctx, KID_VOTE, need_detect);
-        k_hough_vote<<<dim3(nslabs * nsplit, n_img, nc), VOTE_THREADS, (size_t)apb * stride * 4, ctx->stream>>>(
+        k_hough_vote<<<dim3(nslabs * nsplit, n_img, nc), VOTE_THREADS, (size_t)(apb + 1) * stride * 4, ctx->stream>>>(
             ctx->pix_equ, ctx->pix_box, ctx->counters, ctx->tab, ctx->accum, na, nr, apb, nsplit, ctx->list_cap, ctx->acc_cap,
             active, need_detect);
         KCHK("k_hough_vote");
