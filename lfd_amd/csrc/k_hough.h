@@ -49,93 +49,100 @@ k_pixlist(const u64 *bits, uint32_t *list, int *counters, int cidx, int h, int w
 
 #define VOTE_THREADS 1024
 
-// grid (nslabs * nsplit, n_images_per_slot, G).  accum layout per (slot, image):
-// (numangle+2) x (numrho+2).  With nsplit > 1 the pixel list of one image is cut into nsplit
-// pieces handled by different workgroups whose LDS slabs are merged with global atomic adds
-// (the accumulator is zeroed beforehand); with nsplit == 1 the slab is stored directly.
+// Accumulator layouts.  OpenCV indexes accum[(n+1)*(numrho+2) + r+1] ("base"); that value is
+// still what orders equal-vote lines.  In memory the accumulator is kept TRANSPOSED,
+// T[(r+1)*(numangle+2) + n+1], because the vote kernel's LDS slab is bin-major:
+//   acc[r * AW + lane]   (AW = angles per workgroup, a power of two <= 64, lane = angle)
+// so the LDS bank of a vote is lane % 32 whatever the data-dependent bin r is: the 32 lanes of
+// a half-wave never collide (the angle-major layout lost 75 % of its LDS cycles to conflicts),
+// and flushing a bin row is a coalesced store of AW consecutive angles.
+//
+// grid (nslabs * nsplit, n_images_per_slot, G).  With nsplit > 1 the pixel list of one image is
+// cut into nsplit pieces whose slabs are merged with global atomic adds (accumulator zeroed
+// beforehand); with nsplit == 1 the slab is stored directly.
 __global__ void __launch_bounds__(VOTE_THREADS)
 k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, const float *tab,
-             int *accum, int numangle, int numrho, int apb, int nsplit, size_t list_cap, size_t acc_cap,
+             int *accum, int numangle, int numrho, int aw_log2, int nsplit, size_t list_cap, size_t acc_cap,
              const int *active, int need_detect) {
     int g = blockIdx.z, im = blockIdx.y;
     int slab = blockIdx.x / nsplit, split = blockIdx.x - slab * nsplit;
     if (active && !active[g]) return;
     const int *cnt = counters + g * C_COUNT;
     if (need_detect && !cnt[C_DETECT]) return;
-    extern __shared__ int acc[];
-    const int stride = numrho | 1; // odd row stride spreads the lanes over the LDS banks
-    int a0 = slab * apb;
-    int na = min(apb, numangle - a0);
+    extern __shared__ int acc[]; // numrho * AW votes + 64 spare words for lanes without an angle
+    const int AW = 1 << aw_log2;
+    int a0 = slab * AW;
+    int na = min(AW, numangle - a0);
     int n = cnt[im ? C_NPIX_BOX : C_NPIX_EQU];
     if ((size_t)n > list_cap) n = (int)list_cap;
-    // this workgroup's piece of the list, in multiples of the unroll width
     int per = ((n + nsplit - 1) / nsplit + 63) / 64 * 64;
     int begin = min(n, split * per), end = min(n, begin + per);
     if (nsplit > 1 && begin >= end) return; // nothing to add
-    for (int k = threadIdx.x; k < (apb + 1) * stride; k += VOTE_THREADS) acc[k] = 0;
+    for (int k = threadIdx.x; k < numrho * AW + 64; k += VOTE_THREADS) acc[k] = 0;
     __syncthreads();
     const uint32_t *list = (im ? list1 : list0) + (size_t)g * list_cap;
     int lane = threadIdx.x & 63;
-    int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: pixel loads become scalar
+    int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     bool act = lane < na;
     float c = 0.f, s = 0.f;
     if (act) { c = tab[a0 + lane]; s = tab[numangle + a0 + lane]; }
     const int nw = VOTE_THREADS / 64;
     // |r| <= (numrho-1)/2 by construction (numrho ~ 2(w+h)/rho, |j cos + i sin| < w+h), as in
     // OpenCV, which indexes its accumulator without a range check.
-    // lanes without an angle (last slab) vote into a spare row so that the loop stays branch-free:
-    // v_readlane needs every lane's converted coordinates, computed outside any divergent branch
-    int *mybin = acc + (act ? lane : apb) * stride + (numrho - 1) / 2;
+    const int lanebase = ((numrho - 1) / 2) * AW + lane;
+    const int spare = numrho * AW + lane;
     // One coalesced load fetches 64 list entries per wave; each lane converts its own entry to
-    // float once, then the wave walks the 64 entries with v_readlane (wave-uniform pixel, lane =
-    // angle): 2 readlane + 2 mul + add + rint + cvt + address + one LDS add per pixel.
+    // float once, then the wave walks the entries with v_readlane (wave-uniform pixel, lane =
+    // angle).  The loop is branch-free: lanes without an angle vote into the spare words, because
+    // v_readlane needs every lane's converted coordinates computed outside divergent control flow.
     for (int base = begin + wv * 64; base < end; base += nw * 64) {
         int m = min(64, end - base);
         uint32_t pv = (lane < m) ? list[base + lane] : 0u;
         float fxv = (float)(pv & 0xffffu), fyv = (float)(pv >> 16);
-        {
-            int k = 0;
-            for (; k + 8 <= m; k += 8) {
+        int k = 0;
+        for (; k + 8 <= m; k += 8) {
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    float fj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fxv), k + u));
-                    float fi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyv), k + u));
-                    int r = __float2int_rn(__fadd_rn(__fmul_rn(fj, c), __fmul_rn(fi, s)));
-                    atomicAdd(&mybin[r], 1);
-                }
-            }
-            for (; k < m; k++) {
-                float fj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fxv), k));
-                float fi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyv), k));
+            for (int u = 0; u < 8; u++) {
+                float fj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fxv), k + u));
+                float fi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyv), k + u));
                 int r = __float2int_rn(__fadd_rn(__fmul_rn(fj, c), __fmul_rn(fi, s)));
-                atomicAdd(&mybin[r], 1);
+                atomicAdd(&acc[act ? (r << aw_log2) + lanebase : spare], 1);
             }
+        }
+        for (; k < m; k++) {
+            float fj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fxv), k));
+            float fi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyv), k));
+            int r = __float2int_rn(__fadd_rn(__fmul_rn(fj, c), __fmul_rn(fi, s)));
+            atomicAdd(&acc[act ? (r << aw_log2) + lanebase : spare], 1);
         }
     }
     __syncthreads();
     int *ag = accum + ((size_t)g * 2 + im) * acc_cap;
-    int rs = numrho + 2;
+    const int ts = numangle + 2; // transposed row length
     if (nsplit > 1) {
-        for (int k = threadIdx.x; k < na * numrho; k += VOTE_THREADS) {
-            int al = k / numrho, rr = k - al * numrho;
-            int v = acc[al * stride + rr];
-            if (v) atomicAdd(&ag[(size_t)(a0 + al + 1) * rs + rr + 1], v);
+        for (int k = threadIdx.x; k < numrho * AW; k += VOTE_THREADS) {
+            int rr = k >> aw_log2, al = k & (AW - 1);
+            int v = acc[k];
+            if (v && al < na) atomicAdd(&ag[(size_t)(rr + 1) * ts + a0 + al + 1], v);
         }
         return;
     }
-    // rows of this slab, including the zero guard columns
-    for (int k = threadIdx.x; k < na * rs; k += VOTE_THREADS) {
-        int al = k / rs, rr = k - al * rs;
-        int v = (rr == 0 || rr == rs - 1) ? 0 : acc[al * stride + rr - 1];
-        ag[(size_t)(a0 + al + 1) * rs + rr] = v;
+    for (int k = threadIdx.x; k < numrho * AW; k += VOTE_THREADS) {
+        int rr = k >> aw_log2, al = k & (AW - 1);
+        if (al < na) ag[(size_t)(rr + 1) * ts + a0 + al + 1] = acc[k];
     }
-    if (slab == 0) for (int k = threadIdx.x; k < rs; k += VOTE_THREADS) ag[k] = 0;
-    if (slab == gridDim.x - 1)
-        for (int k = threadIdx.x; k < rs; k += VOTE_THREADS) ag[(size_t)(numangle + 1) * rs + k] = 0;
+    // guard cells: bins -1 and numrho for this slab's angles; angles -1 and numangle for all bins
+    for (int k = threadIdx.x; k < na; k += VOTE_THREADS) {
+        ag[a0 + k + 1] = 0;
+        ag[(size_t)(numrho + 1) * ts + a0 + k + 1] = 0;
+    }
+    if (slab == 0)
+        for (int k = threadIdx.x; k < numrho + 2; k += VOTE_THREADS) { ag[(size_t)k * ts] = 0; ag[(size_t)k * ts + ts - 1] = 0; }
 }
 
-// findLocalMaximums: key = votes << 32 | (0x7fffffff - base) so that a descending sort of the
-// keys is OpenCV's hough_cmp_gt order (votes desc, base asc).
+// findLocalMaximums on the transposed accumulator: key = votes << 32 | (0x7fffffff - base) with
+// OpenCV's base = (n+1)*(numrho+2) + r+1, so that a descending sort of the keys is OpenCV's
+// hough_cmp_gt order (votes desc, base asc).  Enumeration order is irrelevant.
 __global__ void __launch_bounds__(256)
 k_hough_peaks(const int *accum, u64 *peaks, int *counters, int numangle, int numrho, int threshold,
               size_t acc_cap, size_t peak_cap, const int *active, int need_detect) {
@@ -145,17 +152,31 @@ k_hough_peaks(const int *accum, u64 *peaks, int *counters, int numangle, int num
     if (need_detect && !cnt[C_DETECT]) return;
     const int *ag = accum + ((size_t)g * 2 + im) * acc_cap;
     u64 *pg = peaks + ((size_t)g * 2 + im) * peak_cap;
-    int rs = numrho + 2;
+    int ts = numangle + 2;
     int total = numangle * numrho;
     for (int k = blockIdx.x * 256 + threadIdx.x; k < total; k += gridDim.x * 256) {
-        int n = k / numrho, r = k - n * numrho;
-        int base = (n + 1) * rs + r + 1;
-        int v = ag[base];
-        if (v > threshold && v > ag[base - 1] && v >= ag[base + 1] && v > ag[base - rs] &&
-            v >= ag[base + rs]) {
+        int r = k / numangle, n = k - r * numangle;
+        int t = (r + 1) * ts + n + 1;
+        int v = ag[t];
+        // accum[base-1], [base+1]: r -/+ 1;  accum[base -/+ (numrho+2)]: angle -/+ 1
+        if (v > threshold && v > ag[t - ts] && v >= ag[t + ts] && v > ag[t - 1] && v >= ag[t + 1]) {
+            int base = (n + 1) * (numrho + 2) + r + 1;
             int o = atomicAdd(&cnt[im ? C_NPEAK_BOX : C_NPEAK_EQU], 1);
             if ((size_t)o < peak_cap) pg[o] = ((u64)(uint32_t)v << 32) | (u64)(uint32_t)(0x7fffffff - base);
         }
+    }
+}
+
+// transposed accumulator -> OpenCV layout (stand-alone lfdmi_hough_accum only)
+__global__ void __launch_bounds__(256)
+k_accum_untranspose(const int *accum, int *out, int numangle, int numrho, size_t acc_cap) {
+    int g = blockIdx.y;
+    const int *ag = accum + (size_t)g * 2 * acc_cap;
+    int *og = out + (size_t)g * (numangle + 2) * (numrho + 2);
+    int total = (numangle + 2) * (numrho + 2);
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < total; k += gridDim.x * 256) {
+        int n1 = k / (numrho + 2), r1 = k - n1 * (numrho + 2);
+        og[k] = ag[(size_t)r1 * (numangle + 2) + n1];
     }
 }
 

@@ -461,11 +461,12 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
                      int need_detect, const int *active) {
     RET(ensure_tables(ctx, h, w, rho, theta));
     int na = ctx->numangle, nr = ctx->numrho;
-    int stride = nr | 1;
-    int apb = (int)((152 * 1024) / ((size_t)stride * 4)) - 1; // one spare row for lanes without an angle
-    if (apb > 64) apb = 64;
-    if (apb < 1) return fail(ctx, LFDMI_ERR_CAPACITY, "numrho too large for one LDS row");
-    int nslabs = (na + apb - 1) / apb;
+    // angles per workgroup: the largest power of two whose bin-major slab fits in LDS
+    int aw_log2 = 6;
+    while (aw_log2 > 0 && ((size_t)nr << aw_log2) * 4 + 256 > 152 * 1024) aw_log2--;
+    if (((size_t)nr << aw_log2) * 4 + 256 > 152 * 1024) return fail(ctx, LFDMI_ERR_CAPACITY, "numrho too large for LDS");
+    int AW = 1 << aw_log2;
+    int nslabs = (na + AW - 1) / AW;
     dim3 wg = word_grid(h, w, nc);
     {
         { Span sp(ctx, KID_PIXLIST, need_detect);
@@ -477,12 +478,12 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         } }
         // cut each pixel list into pieces so that a launch carries >= ~3 workgroups per CU
         int nsplit = 1;
-        while (nsplit < 8 && nslabs * n_img * nc * nsplit < 768) nsplit <<= 1;
+        while (nsplit < 8 && nslabs * n_img * nc * nsplit < 3072) nsplit <<= 1;
         if (nsplit > 1)
             HIPCHK(hipMemsetAsync(ctx->accum, 0, (size_t)nc * 2 * ctx->acc_cap * sizeof(int), ctx->stream));
         Span sp(ctx, KID_VOTE, need_detect);
-        k_hough_vote<<<dim3(nslabs * nsplit, n_img, nc), VOTE_THREADS, (size_t)(apb + 1) * stride * 4, ctx->stream>>>(
-            ctx->pix_equ, ctx->pix_box, ctx->counters, ctx->tab, ctx->accum, na, nr, apb, nsplit, ctx->list_cap, ctx->acc_cap,
+        k_hough_vote<<<dim3(nslabs * nsplit, n_img, nc), VOTE_THREADS, ((size_t)nr << aw_log2) * 4 + 256, ctx->stream>>>(
+            ctx->pix_equ, ctx->pix_box, ctx->counters, ctx->tab, ctx->accum, na, nr, aw_log2, nsplit, ctx->list_cap, ctx->acc_cap,
             active, need_detect);
         KCHK("k_hough_vote");
     }
@@ -685,9 +686,12 @@ static int hough_api(lfdmi_ctx *ctx, const uint8_t *img, int n, int h, int w, do
         k_bits_from_u8<<<dim3((w + 63) / 64, (h + 3) / 4, nc), 256, 0, ctx->stream>>>((const uint8_t *)d, ctx->equb, h, w);
         KCHK("k_bits_from_u8");
         RET(run_hough(ctx, nc, h, w, rho, theta, threshold, 1, 0, 0, nullptr));
-        if (accum)
-            for (int i = 0; i < nc; i++)
-                RET(out_copy(ctx, accum, (size_t)(c0 + i) * acc_n * 4, ctx->accum + (size_t)i * 2 * ctx->acc_cap, acc_n * 4, loc));
+        if (accum) {
+            int *tmp_acc = (int *)ctx->hullbuf; // scratch unused by this entry point
+            k_accum_untranspose<<<dim3(64, nc), 256, 0, ctx->stream>>>(ctx->accum, tmp_acc, na, nr, ctx->acc_cap);
+            KCHK("k_accum_untranspose");
+            RET(out_copy(ctx, accum, (size_t)c0 * acc_n * 4, tmp_acc, (size_t)nc * acc_n * 4, loc));
+        }
         if (lines_dev) {
             Span sp(ctx, KID_SORT);
             k_hough_sort<<<dim3(1, nc), 1024, 0, ctx->stream>>>(ctx->peaks, ctx->counters, lines_dev, max_lines, nr, (float)rho,
