@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames-per-gpu", type=int, default=256)
     ap.add_argument("--inflight", type=int, default=256)
+    ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches (streams) per GPU")
     ap.add_argument("--cpu-sample", type=int, default=24, help="frames timed through the CPU oracle (0 = skip)")
     ap.add_argument("--gen-workers", type=int, default=-1)
     ap.add_argument("--no-removestars", action="store_true")
@@ -110,7 +111,7 @@ def main():
         packed = synth.pack_catalogs(cats)
         cat = {k: torch.from_numpy(v).to(dev) for k, v in packed.items()}
     stream = torch.cuda.current_stream().cuda_stream
-    det = BatchDetector(local_rank, (h, w), args.inflight, stream=stream)
+    det = BatchDetector(local_rank, (h, w), args.inflight, stream=stream, lanes=args.lanes)
 
     def step():
         return det.detect(dframes, pb, pd, cat, rs)
@@ -124,15 +125,15 @@ def main():
     res = None
     for _ in range(args.warmup):
         res = step()
-    det.ctx.enable_timing(True)
+    det.enable_timing(True)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     fence()
     elapsed = time.perf_counter() - t0
-    timing = det.ctx.get_timing()
-    det.ctx.enable_timing(False)
+    timing = det.get_timing()
+    det.enable_timing(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -158,7 +159,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: full removestars+bright+dim pipe, batch=%d synthetic SDSS "
                                    "2048x1489 float32 frames per GPU, device-resident" % n,
-                       "frames_per_gpu": n, "inflight": args.inflight, "shape": [h, w],
+                       "frames_per_gpu": n, "inflight": args.inflight, "lanes": args.lanes, "shape": [h, w],
                        "removestars": not args.no_removestars, "parallelism": "frame-parallel x%d" % world,
                        "found_bright": found_b, "found_dim": found_d, "frame_errors": errors,
                        "gen_s": round(t_gen, 1)},

@@ -48,18 +48,60 @@ def gather_results(local, n_frames, group=None):
 
 
 class BatchDetector:
-    """Owns one GPU context and runs the full pipe over this rank's share of a batch."""
+    """Runs the full pipe over this rank's share of a batch on one GPU.
 
-    def __init__(self, device=0, shape=(1489, 2048), inflight=32, stream=None):
-        self.ctx = _native.Context(device, shape[0], shape[1], inflight)
-        if stream is not None:
+    ``lanes`` independent contexts (own HIP stream, own workspace for ``inflight // lanes``
+    frames) work on disjoint slices of the batch concurrently, each driven by its own host
+    thread (ctypes releases the GIL).  Most kernels of this path are latency-bound with long
+    tails (a few tall contours, the largest Hough lists), so two or more streams keep the CUs
+    busy where one stream would idle between dependent launches.  Frames are independent, so
+    this is the same frame-parallel sharding as across GPUs, one level down.
+    """
+
+    def __init__(self, device=0, shape=(1489, 2048), inflight=32, stream=None, lanes=1):
+        from concurrent.futures import ThreadPoolExecutor
+        self.lanes = max(1, int(lanes))
+        per = max(1, inflight // self.lanes)
+        self.ctxs = [_native.Context(device, shape[0], shape[1], per) for _ in range(self.lanes)]
+        self.ctx = self.ctxs[0]
+        if stream is not None and self.lanes == 1:
             self.ctx.set_stream(stream)
+        self.pool = ThreadPoolExecutor(self.lanes) if self.lanes > 1 else None
         self.shape = shape
 
     def close(self):
-        self.ctx.close()
+        if self.pool is not None:
+            self.pool.shutdown()
+        for c in self.ctxs:
+            c.close()
+
+    def enable_timing(self, on=True):
+        for c in self.ctxs:
+            c.enable_timing(on)
+
+    def get_timing(self):
+        out = {}
+        for c in self.ctxs:
+            for k, (ms, n, u) in c.get_timing().items():
+                a = out.get(k, (0.0, 0, 0))
+                out[k] = (a[0] + ms, a[1] + n, a[2] + u)
+        return out
+
+    @staticmethod
+    def _slice_cat(cat, a, b):
+        if cat is None:
+            return None
+        return {k: v[a:b] for k, v in cat.items()}
 
     def detect(self, frames, params_bright, params_dim, catalogs=None, rs=None):
         """frames: (n, h, w) float32, numpy (staged through the library) or a torch CUDA tensor
-        (used in place).  catalogs: dict from synth.pack_catalogs (numpy or torch CUDA tensors)."""
-        return self.ctx.detect_batch(frames, params_bright, params_dim, catalogs, rs)
+        (used in place; must be complete on the device before the call when lanes > 1).
+        catalogs: dict from synth.pack_catalogs (numpy or torch CUDA tensors)."""
+        if self.lanes == 1:
+            return self.ctx.detect_batch(frames, params_bright, params_dim, catalogs, rs)
+        n = frames.shape[0]
+        bounds = shard_bounds(n, self.lanes)
+        futs = [self.pool.submit(c.detect_batch, frames[a:b], params_bright, params_dim,
+                                 self._slice_cat(catalogs, a, b), rs)
+                for c, (a, b) in zip(self.ctxs, bounds) if b > a]
+        return np.concatenate([f.result() for f in futs])
