@@ -150,6 +150,16 @@ def main():
         name, (ms, launches, units) = max(timing.items(), key=lambda kv: kv[1][0])
         bytes_per_frame = STAGE_BYTES_PER_PX[name] * h * w
         achieved = (bytes_per_frame * units) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic = None
+        try:  # HBM bytes per launch from the committed PMC passes, valid for the default workload only
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tj = json.load(f)
+            c = tj["config"]
+            if (c["frames_per_gpu"], c["inflight"], c["lanes"], c["shape"]) == (n, args.inflight, args.lanes, [h, w]):
+                key = {"k_morph(dilate)": "k_morph_rect_v<0>", "k_morph(erode)": "k_morph_rect_v<1>"}.get(name, name.split("(")[0])
+                traffic = tj["kernels"][key]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         kern = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // max(1, args.steps),
                     "frames_per_step": v[2] // max(1, args.steps)} for k, v in timing.items() if v[1]}
         out = {
@@ -164,7 +174,7 @@ def main():
                        "found_bright": found_b, "found_dim": found_d, "frame_errors": errors,
                        "gen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "avg_launch_ms": round(ms / max(1, launches), 4),
                          "frames_per_launch": round(units / max(1, launches), 2),
                          "algorithmic_bytes_per_frame": bytes_per_frame},

@@ -17,6 +17,8 @@ enum {
     C_OVERFLOW = 7,  // workspace overflow flag
     C_DETECT = 8,    // fit_minAreaRect's `detection`
     C_NBIG = 9,      // keys tall enough for the wave-per-key hull path
+    C_NFGW = 10,     // bit-row words holding Canny candidates (work list of the edge-run kernels)
+    C_NBGW = 11,     // bit-row words where a background run can start or join (work list of the hole kernels)
     C_COUNT = 16
 };
 

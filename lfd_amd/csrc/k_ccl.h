@@ -10,7 +10,10 @@
 // so labelling runs of the bit rows (union-find over run starts, labels indexed by the pixel
 // index of the run start, root = raster-first run) replaces the sequential Suzuki-Abe trace.
 // Work is proportional to the number of runs (~ edge pixels + rows), not to the image area.
-// One thread per 64-bit word of a bit row.
+// One thread per ACTIVE 64-bit word of a bit row: k_collect_words compacts the few words that
+// hold any work (a few % of a sky frame) into a per-frame list, so every lane of the run
+// kernels has a word to chew on and their dependent, cache-missing label loads overlap
+// (thread-per-word over the whole bit image left ~4 % of the lanes busy).
 #pragma once
 #include "common.h"
 
@@ -29,42 +32,79 @@ __device__ __forceinline__ u64 start_bits(const u64 *row, int wq, int val, int W
     return c & ~((c << 1) | prev_msb);
 }
 
-// L[p] = p, YM[p] = row, FL[p] = 0 for every run start p
+// mode 1: words with candidate bits.  mode 0 (background runs of the edge image): words where a
+// 0-run can start or a vertical 0-0 contact stretch can begin: an edge bit in this word or at
+// the end of the previous word, in this row or the row above, or the first word of a row.
 __global__ void __launch_bounds__(256)
-k_runs_init(const u64 *bits, int val, int *L, int *YM, int *FL, int h, int w, const int *active) {
+k_collect_words(const u64 *bits, int mode, int *wlist, int *counters, int cidx, int h, int w, const int *active) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     int wq = LFD_WQ(w);
     int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= h * wq) return;
-    int y = idx / wq, q = idx - y * wq;
-    const u64 *row = bits + (size_t)g * h * wq + (size_t)y * wq;
-    u64 s = start_bits(row, q, val, w);
-    size_t N = (size_t)h * w;
-    while (s) {
-        int b = __ffsll((long long)s) - 1;
-        s &= s - 1;
-        int p = y * w + (q << 6) + b;
-        L[g * N + p] = p;
-        YM[g * N + p] = y;
-        FL[g * N + p] = 0;
+    bool take = false;
+    if (idx < h * wq) {
+        const u64 *b = bits + (size_t)g * h * wq;
+        if (mode) take = b[idx] != 0;
+        else {
+            int y = idx / wq, q = idx - y * wq;
+            u64 m = b[idx];
+            if (q > 0) m |= b[idx - 1] >> 63;
+            if (y > 0) { m |= b[idx - wq]; if (q > 0) m |= b[idx - wq - 1] >> 63; }
+            take = (m != 0) || (q == 0);
+        }
+    }
+    u64 bal = __ballot(take);
+    int lane = lfd_lane();
+    int base = 0;
+    if (lane == 0 && bal) base = atomicAdd(&counters[g * C_COUNT + cidx], __popcll(bal));
+    base = __shfl(base, 0);
+    if (take) wlist[(size_t)g * h * wq + base + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
+}
+
+// every run kernel walks its frame's work list with a fixed grid
+#define LFD_WORDLIST_LOOP(cidx_)                                                          \
+    int g = blockIdx.y;                                                                   \
+    if (active && !active[g]) return;                                                     \
+    const int wq = LFD_WQ(w);                                                             \
+    const int nwork_ = counters[g * C_COUNT + (cidx_)];                                   \
+    const int *wl_ = wlist + (size_t)g * h * wq;                                          \
+    for (int it_ = blockIdx.x * 256 + threadIdx.x; it_ < nwork_; it_ += gridDim.x * 256)
+
+#define WORDLIST_BLOCKS 48
+
+// L[p] = p, YM[p] = row, FL[p] = 0 for every run start p
+__global__ void __launch_bounds__(256)
+k_runs_init(const u64 *bits, int val, int *L, int *YM, int *FL, int h, int w, const int *wlist,
+            const int *counters, int cidx, const int *active) {
+    LFD_WORDLIST_LOOP(cidx) {
+        int idx = wl_[it_];
+        int y = idx / wq, q = idx - y * wq;
+        const u64 *row = bits + (size_t)g * h * wq + (size_t)y * wq;
+        u64 s = start_bits(row, q, val, w);
+        size_t N = (size_t)h * w;
+        while (s) {
+            int b = __ffsll((long long)s) - 1;
+            s &= s - 1;
+            int p = y * w + (q << 6) + b;
+            L[g * N + p] = p;
+            YM[g * N + p] = y;
+            FL[g * N + p] = 0;
+        }
     }
 }
 
 // 8-connectivity between runs of 1-bits in rows y and y-1
 __global__ void __launch_bounds__(256)
-k_runs_merge8(const u64 *bits, int *L, int h, int w, const int *active) {
-    int g = blockIdx.y;
-    if (active && !active[g]) return;
-    int wq = LFD_WQ(w);
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= h * wq) return;
+k_runs_merge8(const u64 *bits, int *L, int h, int w, const int *wlist, const int *counters, int cidx,
+              const int *active) {
+    LFD_WORDLIST_LOOP(cidx) {
+    int idx = wl_[it_];
     int y = idx / wq, q = idx - y * wq;
-    if (y == 0) return;
+    if (y == 0) continue;
     const u64 *row = bits + (size_t)g * h * wq + (size_t)y * wq;
     const u64 *up = row - wq;
     u64 c = row[q];
-    if (!c) return;
+    if (!c) continue;
     u64 u = up[q];
     u64 uprev = q > 0 ? up[q - 1] : 0ull, unext = q + 1 < wq ? up[q + 1] : 0ull;
     u64 uL = (u << 1) | (uprev >> 63); // bit x set <=> up[x-1]
@@ -92,18 +132,17 @@ k_runs_merge8(const u64 *bits, int *L, int h, int w, const int *active) {
         int x = (q << 6) + b;
         uf_union(Lg, y * w + run_start(row, x, 1), (y - 1) * w + run_start(up, x + 1, 1));
     }
+    }
 }
 
 // 4-connectivity between runs of 0-bits in rows y and y-1
 __global__ void __launch_bounds__(256)
-k_runs_merge4_bg(const u64 *bits, int *L, int h, int w, const int *active) {
-    int g = blockIdx.y;
-    if (active && !active[g]) return;
-    int wq = LFD_WQ(w);
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= h * wq) return;
+k_runs_merge4_bg(const u64 *bits, int *L, int h, int w, const int *wlist, const int *counters, int cidx,
+                 const int *active) {
+    LFD_WORDLIST_LOOP(cidx) {
+    int idx = wl_[it_];
     int y = idx / wq, q = idx - y * wq;
-    if (y == 0) return;
+    if (y == 0) continue;
     const u64 *row = bits + (size_t)g * h * wq + (size_t)y * wq;
     const u64 *up = row - wq;
     u64 v = ~row[q] & ~up[q] & valid_mask(q, w);
@@ -117,7 +156,12 @@ k_runs_merge4_bg(const u64 *bits, int *L, int h, int w, const int *active) {
         int b = __ffsll((long long)st) - 1;
         st &= st - 1;
         int x = (q << 6) + b;
-        uf_union(Lg, y * w + run_start(row, x, 0), (y - 1) * w + run_start(up, x, 0));
+        int sa = run_start(row, x, 0), sb = run_start(up, x, 0);
+        // two runs that both start at column 0 touch the frame: each is flagged "outside" on its
+        // own, joining them would only build a 1 489-link chain down the left image border
+        if (sa == 0 && sb == 0) continue;
+        uf_union(Lg, y * w + sa, (y - 1) * w + sb);
+    }
     }
 }
 
@@ -126,12 +170,9 @@ k_runs_merge4_bg(const u64 *bits, int *L, int h, int w, const int *active) {
 // (val==0) the run touches the image frame (the 0-component is the outside).
 __global__ void __launch_bounds__(256)
 k_runs_flatten(const u64 *bits, int val, const u64 *mark, int *L, int *YM, int *FL, int h, int w,
-               const int *active) {
-    int g = blockIdx.y;
-    if (active && !active[g]) return;
-    int wq = LFD_WQ(w);
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= h * wq) return;
+               const int *wlist, const int *counters, int cidx, const int *active) {
+    LFD_WORDLIST_LOOP(cidx) {
+    int idx = wl_[it_];
     int y = idx / wq, q = idx - y * wq;
     const u64 *row = bits + (size_t)g * h * wq + (size_t)y * wq;
     u64 s = start_bits(row, q, val, w);
@@ -164,16 +205,15 @@ k_runs_flatten(const u64 *bits, int val, const u64 *mark, int *L, int *YM, int *
         }
         if (flag) FLg[root] = 1;
     }
+    }
 }
 
 // last row of every hole (0-component that does not touch the frame); runs after k_runs_flatten
 __global__ void __launch_bounds__(256)
-k_bg_extent(const u64 *bits, const int *L, int *YM, const int *FL, int h, int w, const int *active) {
-    int g = blockIdx.y;
-    if (active && !active[g]) return;
-    int wq = LFD_WQ(w);
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= h * wq) return;
+k_bg_extent(const u64 *bits, const int *L, int *YM, const int *FL, int h, int w, const int *wlist,
+            const int *counters, int cidx, const int *active) {
+    LFD_WORDLIST_LOOP(cidx) {
+    int idx = wl_[it_];
     int y = idx / wq, q = idx - y * wq;
     const u64 *row = bits + (size_t)g * h * wq + (size_t)y * wq;
     u64 s = start_bits(row, q, 0, w);
@@ -184,17 +224,16 @@ k_bg_extent(const u64 *bits, const int *L, int *YM, const int *FL, int h, int w,
         int root = L[g * N + y * w + (q << 6) + b];
         if (!FL[g * N + root]) atomicMax(&YM[g * N + root], y);
     }
+    }
 }
 
 // hysteresis result: edge = candidate runs whose component holds a strong pixel
 __global__ void __launch_bounds__(256)
 k_edge_from_cand(const u64 *cand, const int *L, const int *FL, u64 *edge, int h, int w,
-                 const int *active) {
-    int g = blockIdx.y;
-    if (active && !active[g]) return;
-    int wq = LFD_WQ(w);
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= h * wq) return;
+                 const int *wlist, const int *counters, int cidx, const int *active) {
+    // words without candidates are zero in `edge` (cleared by the caller)
+    LFD_WORDLIST_LOOP(cidx) {
+    int idx = wl_[it_];
     int y = idx / wq, q = idx - y * wq;
     const u64 *row = cand + (size_t)g * h * wq + (size_t)y * wq;
     size_t N = (size_t)h * w;
@@ -211,4 +250,5 @@ k_edge_from_cand(const u64 *cand, const int *L, const int *FL, u64 *edge, int h,
         rem &= ~seg;
     }
     edge[(size_t)g * h * wq + (size_t)y * wq + q] = res;
+    }
 }

@@ -60,10 +60,12 @@ k_pixlist(const u64 *bits, uint32_t *list, int *counters, int cidx, int h, int w
 // grid (nslabs * nsplit, n_images_per_slot, G).  With nsplit > 1 the pixel list of one image is
 // cut into nsplit pieces whose slabs are merged with global atomic adds (accumulator zeroed
 // beforehand); with nsplit == 1 the slab is stored directly.
+template <int AWL> // log2 of the angles per workgroup
 __global__ void __launch_bounds__(VOTE_THREADS)
 k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, const float *tab,
-             int *accum, int numangle, int numrho, int aw_log2, int nsplit, size_t list_cap, size_t acc_cap,
+             int *accum, int numangle, int numrho, int nsplit, size_t list_cap, size_t acc_cap,
              const int *active, int need_detect) {
+    constexpr int aw_log2 = AWL;
     int g = blockIdx.z, im = blockIdx.y;
     int slab = blockIdx.x / nsplit, split = blockIdx.x - slab * nsplit;
     if (active && !active[g]) return;
@@ -89,33 +91,41 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     const int nw = VOTE_THREADS / 64;
     // |r| <= (numrho-1)/2 by construction (numrho ~ 2(w+h)/rho, |j cos + i sin| < w+h), as in
     // OpenCV, which indexes its accumulator without a range check.
-    const int lanebase = ((numrho - 1) / 2) * AW + lane;
-    const int spare = numrho * AW + lane;
-    // One coalesced load fetches 64 list entries per wave; each lane converts its own entry to
-    // float once, then the wave walks the entries with v_readlane (wave-uniform pixel, lane =
-    // angle).  The loop is branch-free: lanes without an angle vote into the spare words, because
-    // v_readlane needs every lane's converted coordinates computed outside divergent control flow.
+    // Vote address (bytes) = (rint(v) << (aw_log2+2)) + lanebase.  rint (round-half-even,
+    // |v| < 2^22) uses the 1.5*2^23 trick: bits(v + 12582912.f) = 0x4B400000 + rint(v); the
+    // constant is folded into the base (address arithmetic is mod 2^32).  Lanes without an angle
+    // have c = s = 0, hence rint = 0, and their base points at the spare words: no select.
+    const unsigned cell = act ? (unsigned)(((numrho - 1) / 2) * AW + lane) : (unsigned)(numrho * AW + lane);
+    const unsigned lanebase = (cell << 2) - (0x4B400000u << (aw_log2 + 2));
+    char *accb = (char *)acc;
+#define LFD_VOTE(K)                                                                                   \
+    {                                                                                                 \
+        float fj_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fxv), (K))); \
+        float v_ = __fadd_rn(__fadd_rn(__fmul_rn(fj_, c), ys), 12582912.0f);                         \
+        atomicAdd((int *)(accb + ((__builtin_bit_cast(unsigned, v_) << (aw_log2 + 2)) + lanebase)), 1); \
+    }
+    // One coalesced load fetches 64 list entries per wave; each lane converts its own x to float
+    // once, then the wave walks the entries with v_readlane (wave-uniform pixel, lane = angle).
+    // Entries arrive row by row, so the chunk is cut at row changes (wave-uniform mask) and the
+    // y*sin term is computed once per row segment: 1 readlane + mul + 2 add + shift-add + LDS add
+    // per pixel.  No per-lane branch anywhere (v_readlane needs every lane's fxv).
     for (int base = begin + wv * 64; base < end; base += nw * 64) {
         int m = min(64, end - base);
         uint32_t pv = (lane < m) ? list[base + lane] : 0u;
-        float fxv = (float)(pv & 0xffffu), fyv = (float)(pv >> 16);
+        float fxv = (float)(pv & 0xffffu);
+        int yv = (int)(pv >> 16);
+        int yprev = __shfl_up(yv, 1);
+        u64 starts = __ballot(lane < m && (lane == 0 || yv != yprev));
         int k = 0;
-        for (; k + 8 <= m; k += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                float fj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fxv), k + u));
-                float fi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyv), k + u));
-                int r = __float2int_rn(__fadd_rn(__fmul_rn(fj, c), __fmul_rn(fi, s)));
-                atomicAdd(&acc[act ? (r << aw_log2) + lanebase : spare], 1);
-            }
-        }
-        for (; k < m; k++) {
-            float fj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fxv), k));
-            float fi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyv), k));
-            int r = __float2int_rn(__fadd_rn(__fmul_rn(fj, c), __fmul_rn(fi, s)));
-            atomicAdd(&acc[act ? (r << aw_log2) + lanebase : spare], 1);
+        while (k < m) {
+            u64 rest = (k >= 63) ? 0ull : (starts & ~((2ull << k) - 1ull));
+            int kend = rest ? (int)__ffsll((long long)rest) - 1 : m;
+            float ys = __fmul_rn((float)__builtin_amdgcn_readlane(yv, k), s);
+            for (; k + 4 <= kend; k += 4) { LFD_VOTE(k) LFD_VOTE(k + 1) LFD_VOTE(k + 2) LFD_VOTE(k + 3) }
+            for (; k < kend; k++) LFD_VOTE(k)
         }
     }
+#undef LFD_VOTE
     __syncthreads();
     int *ag = accum + ((size_t)g * 2 + im) * acc_cap;
     const int ts = numangle + 2; // transposed row length

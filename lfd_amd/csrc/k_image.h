@@ -438,19 +438,23 @@ k_u8_from_bits(const u64 *bits, uint8_t *dst, int h, int w) {
 // __ballot is exactly one output word.
 // ------------------------------------------------------------------------------------------
 #define CANNY_TW 64
-#define CANNY_TH 16
+#define CANNY_TH 32
 
 __global__ void __launch_bounds__(256)
 k_canny_nms(const uint8_t *img, u64 *cand, u64 *strong, int h, int w, int low, int high,
             const int *active) {
     int g = blockIdx.z;
     if (active && !active[g]) return;
-    uint32_t any = 0;
     const int PW = CANNY_TW + 4, PH = CANNY_TH + 4, MW = CANNY_TW + 2, MH = CANNY_TH + 2;
     __shared__ uint8_t px[PH * PW];
-    __shared__ int mg[MH * MW];
+    __shared__ int mg[MH * MW];       // L1 gradient magnitude
+    __shared__ int dxy[MH * MW];      // Sobel dx (low 16 bits) | dy (high 16 bits)
+    __shared__ int rowflag[PH];       // staged pixel row holds a non-zero byte
     int x0 = blockIdx.x * CANNY_TW, y0 = blockIdx.y * CANNY_TH;
     const uint8_t *s = img + (size_t)g * h * w;
+    if (threadIdx.x < PH) rowflag[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t any = 0;
     if ((w & 3) == 0) {
         // interior columns as aligned dwords (16 per row), the 2-px halo columns as bytes
         for (int idx = threadIdx.x; idx < PH * 16; idx += 256) {
@@ -459,6 +463,7 @@ k_canny_nms(const uint8_t *img, u64 *cand, u64 *strong, int h, int w, int low, i
             uint32_t v;
             if (gx + 3 < w) v = *(const uint32_t *)(s + (size_t)gy * w + gx);
             else { uint32_t e = s[(size_t)gy * w + w - 1]; v = e | (e << 8) | (e << 16) | (e << 24); }
+            if (v) rowflag[ty] = 1;
             any |= v;
             uint8_t *p = px + ty * PW + 2 + 4 * wx;
             p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
@@ -468,6 +473,7 @@ k_canny_nms(const uint8_t *img, u64 *cand, u64 *strong, int h, int w, int low, i
             int tx = k < 2 ? k : CANNY_TW + k; // 0,1 | 66,67
             int gy = min(max(y0 - 2 + ty, 0), h - 1), gx = min(max(x0 - 2 + tx, 0), w - 1);
             uint8_t v = s[(size_t)gy * w + gx];
+            if (v) rowflag[ty] = 1;
             any |= v;
             px[ty * PW + tx] = v;
         }
@@ -476,35 +482,38 @@ k_canny_nms(const uint8_t *img, u64 *cand, u64 *strong, int h, int w, int low, i
             int ty = idx / PW, tx = idx - ty * PW;
             int gy = min(max(y0 - 2 + ty, 0), h - 1), gx = min(max(x0 - 2 + tx, 0), w - 1);
             uint8_t v = s[(size_t)gy * w + gx];
+            if (v) rowflag[ty] = 1;
             any |= v;
             px[idx] = v;
         }
     }
+    int wq = LFD_WQ(w);
     // an all-zero tile (sky) has zero gradient everywhere: no candidate when low >= 0
     if (!__syncthreads_or(any != 0) && low >= 0) {
-        int wq0 = LFD_WQ(w);
         if (threadIdx.x < CANNY_TH && y0 + threadIdx.x < h) {
-            size_t o = (size_t)g * h * wq0 + (size_t)(y0 + threadIdx.x) * wq0 + blockIdx.x;
+            size_t o = (size_t)g * h * wq + (size_t)(y0 + threadIdx.x) * wq + blockIdx.x;
             cand[o] = 0ull;
             strong[o] = 0ull;
         }
         return;
     }
+    // Sobel + magnitude once per pixel of the tile and its 1-px ring
     for (int idx = threadIdx.x; idx < MH * MW; idx += 256) {
         int my = idx / MW, mx = idx - my * MW;
         int gy = y0 - 1 + my, gx = x0 - 1 + mx;
-        int m = 0;
-        if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
+        int m = 0, d = 0;
+        if ((rowflag[my] | rowflag[my + 1] | rowflag[my + 2]) && gy >= 0 && gy < h && gx >= 0 && gx < w) {
             const uint8_t *p = px + my * PW + mx; // top-left of the 3x3 window
             int dx = (p[2] - p[0]) + 2 * (p[PW + 2] - p[PW]) + (p[2 * PW + 2] - p[2 * PW]);
             int dy = (p[2 * PW] - p[0]) + 2 * (p[2 * PW + 1] - p[1]) + (p[2 * PW + 2] - p[2]);
             m = abs(dx) + abs(dy);
+            d = (dx & 0xffff) | (dy << 16);
         }
         mg[idx] = m;
+        dxy[idx] = d;
     }
     __syncthreads();
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int wq = LFD_WQ(w);
     for (int oy = wv; oy < CANNY_TH; oy += 4) {
         int gy = y0 + oy, gx = x0 + lane;
         bool keep = false, str = false;
@@ -512,9 +521,8 @@ k_canny_nms(const uint8_t *img, u64 *cand, u64 *strong, int h, int w, int low, i
             const int *mc = mg + (oy + 1) * MW + (lane + 1);
             int m = mc[0];
             if (m > low) {
-                const uint8_t *p = px + (oy + 1) * PW + (lane + 1);
-                int xs = (p[2] - p[0]) + 2 * (p[PW + 2] - p[PW]) + (p[2 * PW + 2] - p[2 * PW]);
-                int ys = (p[2 * PW] - p[0]) + 2 * (p[2 * PW + 1] - p[1]) + (p[2 * PW + 2] - p[2]);
+                int d = dxy[(oy + 1) * MW + (lane + 1)];
+                int xs = (int)(short)(d & 0xffff), ys = d >> 16;
                 int ax = abs(xs), ay = abs(ys) << 15;
                 int tg22x = ax * 13573;
                 if (ay < tg22x) {

@@ -17,19 +17,23 @@
 __global__ void __launch_bounds__(256)
 k_keys(const u64 *edge, const int *Lf, const int *YMf, const int *Lb, const int *YMb,
        const int *FLb, int *SBf, int *SBb, int *PAb, int4 *keys, int *bigkeys, int2 *rowext,
-       int *counters, int h, int w, int key_cap, int slot_cap, const int *active) {
+       int *counters, int h, int w, int key_cap, int slot_cap, const int *wlist_fg, const int *wlist_bg,
+       const int *active) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     int wq = LFD_WQ(w);
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= h * wq) return;
-    int y = idx / wq, q = idx - y * wq;
-    const u64 *row = edge + (size_t)g * h * wq + (size_t)y * wq;
     size_t N = (size_t)h * w;
     int *cnt = counters + g * C_COUNT;
     int4 *kg = keys + (size_t)g * key_cap;
     int2 *re = rowext + (size_t)g * slot_cap;
+    // edge components come from the candidate-word list, holes from the background-word list
     for (int val = 1; val >= 0; val--) {
+        const int nwork = cnt[val ? C_NFGW : C_NBGW];
+        const int *wl = (val ? wlist_fg : wlist_bg) + (size_t)g * h * wq;
+        for (int it = blockIdx.x * 256 + threadIdx.x; it < nwork; it += gridDim.x * 256) {
+        int idx = wl[it];
+        int y = idx / wq, q = idx - y * wq;
+        const u64 *row = edge + (size_t)g * h * wq + (size_t)y * wq;
         u64 s = start_bits(row, q, val, w);
         while (s) {
             int b = __ffsll((long long)s) - 1;
@@ -61,6 +65,7 @@ k_keys(const u64 *edge, const int *Lf, const int *YMf, const int *Lb, const int 
             if (extent > BIG_KEY_ROWS) bigkeys[(size_t)g * key_cap + atomicAdd(&cnt[C_NBIG], 1)] = ki;
             for (int r = 0; r < extent; r++) re[base + r] = make_int2(0x7fffffff, -1);
         }
+        }
     }
 }
 
@@ -74,12 +79,14 @@ __device__ __forceinline__ void slot_update(int2 *re, int slot, int xa, int xb) 
 __global__ void __launch_bounds__(256)
 k_extremes(const u64 *edge, const int *Lf, const int *Lb, const int *FLb, const int *SBf,
            const int *SBb, const int *PAb, int2 *rowext, int h, int w, int slot_cap,
-           const int *active) {
+           const int *wlist, const int *counters, const int *active) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     int wq = LFD_WQ(w);
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= h * wq) return;
+    const int nwork = counters[g * C_COUNT + C_NFGW];
+    const int *wl = wlist + (size_t)g * h * wq;
+    for (int it = blockIdx.x * 256 + threadIdx.x; it < nwork; it += gridDim.x * 256) {
+    int idx = wl[it];
     int y = idx / wq, q = idx - y * wq;
     const u64 *row = edge + (size_t)g * h * wq + (size_t)y * wq;
     size_t N = (size_t)h * w;
@@ -121,6 +128,7 @@ k_extremes(const u64 *edge, const int *Lf, const int *Lb, const int *FLb, const 
                 x = ge + 1;
             }
         }
+    }
     }
 }
 

@@ -52,6 +52,7 @@ struct lfdmi_ctx {
     int *SBf = nullptr, *SBb = nullptr, *PAb = nullptr;
     int4 *keys = nullptr;
     int *bigkeys = nullptr;
+    int *wl_fg = nullptr, *wl_bg = nullptr; // work lists of active bit-row words
     int2 *rowext = nullptr, *hullbuf = nullptr;
     int *quads = nullptr;
     uint32_t *pix_equ = nullptr, *pix_box = nullptr;
@@ -191,6 +192,8 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
         RET(dmalloc(ctx, p, G * N));
     RET(dmalloc(ctx, &ctx->keys, G * ctx->key_cap));
     RET(dmalloc(ctx, &ctx->bigkeys, G * ctx->key_cap));
+    RET(dmalloc(ctx, &ctx->wl_fg, G * BW));
+    RET(dmalloc(ctx, &ctx->wl_bg, G * BW));
     RET(dmalloc(ctx, &ctx->rowext, G * ctx->slot_cap));
     RET(dmalloc(ctx, &ctx->hullbuf, G * ctx->slot_cap * 2));
     RET(dmalloc(ctx, &ctx->quads, G * ctx->key_cap * 8));
@@ -204,7 +207,13 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     RET(dmalloc(ctx, &ctx->need_dim, G));
     RET(dmalloc(ctx, &ctx->pass_flags, G));
     RET(dmalloc(ctx, &ctx->res_dev, G));
-    HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_rects_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -368,17 +377,22 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
         KCHK("k_canny_nms");
     }
     dim3 wg = word_grid(h, w, nc);
+    dim3 lg(WORDLIST_BLOCKS, nc);
+    size_t BW = (size_t)h * LFD_WQ(w);
+    HIPCHK(hipMemsetAsync(ctx->edgeb, 0, (size_t)nc * BW * sizeof(u64), ctx->stream));
     { Span sp(ctx, KID_RUNS_INIT_FG);
-      k_runs_init<<<wg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->Lf, ctx->YMf, ctx->FLf, h, w, active);
+      k_collect_words<<<wg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->wl_fg, ctx->counters, C_NFGW, h, w, active);
+      KCHK("k_collect_words(fg)");
+      k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->Lf, ctx->YMf, ctx->FLf, h, w, ctx->wl_fg, ctx->counters, C_NFGW, active);
       KCHK("k_runs_init"); }
     { Span sp(ctx, KID_RUNS_MERGE8);
-      k_runs_merge8<<<wg, 256, 0, ctx->stream>>>(ctx->candb, ctx->Lf, h, w, active);
+      k_runs_merge8<<<lg, 256, 0, ctx->stream>>>(ctx->candb, ctx->Lf, h, w, ctx->wl_fg, ctx->counters, C_NFGW, active);
       KCHK("k_runs_merge8"); }
     { Span sp(ctx, KID_RUNS_FLATTEN_FG);
-      k_runs_flatten<<<wg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->strongb, ctx->Lf, ctx->YMf, ctx->FLf, h, w, active);
+      k_runs_flatten<<<lg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->strongb, ctx->Lf, ctx->YMf, ctx->FLf, h, w, ctx->wl_fg, ctx->counters, C_NFGW, active);
       KCHK("k_runs_flatten"); }
     { Span sp(ctx, KID_EDGE);
-      k_edge_from_cand<<<wg, 256, 0, ctx->stream>>>(ctx->candb, ctx->Lf, ctx->FLf, ctx->edgeb, h, w, active);
+      k_edge_from_cand<<<lg, 256, 0, ctx->stream>>>(ctx->candb, ctx->Lf, ctx->FLf, ctx->edgeb, h, w, ctx->wl_fg, ctx->counters, C_NFGW, active);
       KCHK("k_edge_from_cand"); }
     return 0;
 }
@@ -396,25 +410,29 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
         return fail(ctx, LFDMI_ERR_UNSUPPORTED, "contoursMode: only RETR_LIST / RETR_CCOMP / RETR_TREE");
     dim3 wg = word_grid(h, w, nc);
     size_t BW = (size_t)h * LFD_WQ(w);
+    dim3 lg(WORDLIST_BLOCKS, nc);
     { Span sp(ctx, KID_RUNS_INIT_BG);
-      k_runs_init<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->Lb, ctx->YMb, ctx->FLb, h, w, active);
+      k_collect_words<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->wl_bg, ctx->counters, C_NBGW, h, w, active);
+      KCHK("k_collect_words(bg)");
+      k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->Lb, ctx->YMb, ctx->FLb, h, w, ctx->wl_bg, ctx->counters, C_NBGW, active);
       KCHK("k_runs_init(bg)"); }
     { Span sp(ctx, KID_RUNS_MERGE4);
-      k_runs_merge4_bg<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lb, h, w, active);
+      k_runs_merge4_bg<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lb, h, w, ctx->wl_bg, ctx->counters, C_NBGW, active);
       KCHK("k_runs_merge4_bg"); }
     { Span sp(ctx, KID_RUNS_FLATTEN_BG);
-      k_runs_flatten<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, nullptr, ctx->Lb, ctx->YMb, ctx->FLb, h, w, active);
+      k_runs_flatten<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, nullptr, ctx->Lb, ctx->YMb, ctx->FLb, h, w, ctx->wl_bg, ctx->counters, C_NBGW, active);
       KCHK("k_runs_flatten(bg)");
-      k_bg_extent<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lb, ctx->YMb, ctx->FLb, h, w, active);
+      k_bg_extent<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lb, ctx->YMb, ctx->FLb, h, w, ctx->wl_bg, ctx->counters, C_NBGW, active);
       KCHK("k_bg_extent"); }
     HIPCHK(hipMemsetAsync(ctx->boxb, 0, (size_t)nc * BW * sizeof(u64), ctx->stream));
     { Span sp(ctx, KID_KEYS);
-    k_keys<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lf, ctx->YMf, ctx->Lb, ctx->YMb, ctx->FLb, ctx->SBf, ctx->SBb,
-                                         ctx->PAb, ctx->keys, ctx->bigkeys, ctx->rowext, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, active);
+    k_keys<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lf, ctx->YMf, ctx->Lb, ctx->YMb, ctx->FLb, ctx->SBf, ctx->SBb,
+                                         ctx->PAb, ctx->keys, ctx->bigkeys, ctx->rowext, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap,
+                                         ctx->wl_fg, ctx->wl_bg, active);
     KCHK("k_keys"); }
     { Span sp(ctx, KID_EXTREMES);
-    k_extremes<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lf, ctx->Lb, ctx->FLb, ctx->SBf, ctx->SBb, ctx->PAb, ctx->rowext,
-                                             h, w, ctx->slot_cap, active);
+    k_extremes<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lf, ctx->Lb, ctx->FLb, ctx->SBf, ctx->SBb, ctx->PAb, ctx->rowext,
+                                             h, w, ctx->slot_cap, ctx->wl_fg, ctx->counters, active);
     KCHK("k_extremes"); }
     { Span sp(ctx, KID_RECTS);
     k_rects<<<dim3(256, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, ctx->hullbuf, ctx->quads, ctx->counters, h, w,
@@ -482,9 +500,19 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         if (nsplit > 1)
             HIPCHK(hipMemsetAsync(ctx->accum, 0, (size_t)nc * 2 * ctx->acc_cap * sizeof(int), ctx->stream));
         Span sp(ctx, KID_VOTE, need_detect);
-        k_hough_vote<<<dim3(nslabs * nsplit, n_img, nc), VOTE_THREADS, ((size_t)nr << aw_log2) * 4 + 256, ctx->stream>>>(
-            ctx->pix_equ, ctx->pix_box, ctx->counters, ctx->tab, ctx->accum, na, nr, aw_log2, nsplit, ctx->list_cap, ctx->acc_cap,
-            active, need_detect);
+        dim3 vgrid(nslabs * nsplit, n_img, nc);
+        size_t vlds = ((size_t)nr << aw_log2) * 4 + 256;
+#define LFD_LAUNCH_VOTE(L)                                                                                          \
+    case L:                                                                                                         \
+        k_hough_vote<L><<<vgrid, VOTE_THREADS, vlds, ctx->stream>>>(ctx->pix_equ, ctx->pix_box, ctx->counters, ctx->tab, \
+                                                                   ctx->accum, na, nr, nsplit, ctx->list_cap,       \
+                                                                   ctx->acc_cap, active, need_detect);              \
+        break;
+        switch (aw_log2) {
+            LFD_LAUNCH_VOTE(6) LFD_LAUNCH_VOTE(5) LFD_LAUNCH_VOTE(4) LFD_LAUNCH_VOTE(3) LFD_LAUNCH_VOTE(2)
+            LFD_LAUNCH_VOTE(1) LFD_LAUNCH_VOTE(0)
+        }
+#undef LFD_LAUNCH_VOTE
         KCHK("k_hough_vote");
     }
     { Span sp(ctx, KID_PEAKS, need_detect);
@@ -619,6 +647,7 @@ extern "C" int lfdmi_canny(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int
         int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
         const void *d;
         RET(in_ptr(ctx, src, (size_t)c0 * N, (size_t)nc * N, loc, &d));
+        RET(zero_counters(ctx, nc));
         RET(run_canny(ctx, (const uint8_t *)d, nc, h, w, low, high, nullptr));
         RET(expand_bits(ctx, ctx->edgeb, ctx->tmp, nc, h, w));
         RET(out_copy(ctx, dst, (size_t)c0 * N, ctx->tmp, (size_t)nc * N, loc));
