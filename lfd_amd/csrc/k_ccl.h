@@ -32,33 +32,40 @@ __device__ __forceinline__ u64 start_bits(const u64 *row, int wq, int val, int W
     return c & ~((c << 1) | prev_msb);
 }
 
-// mode 1: words with candidate bits.  mode 0 (background runs of the edge image): words where a
-// 0-run can start or a vertical 0-0 contact stretch can begin: an edge bit in this word or at
-// the end of the previous word, in this row or the row above, or the first word of a row.
+// One pass over the candidate bit rows builds both work lists of a frame:
+//   fg: words holding candidate bits (edge runs are a subset of candidate runs);
+//   bg: words where a 0-run of the edge image can start or a vertical 0-0 contact stretch can
+//       begin -- an edge bit in this word or at the end of the previous word, in this row or the
+//       row above -- or the first word of a row.  Candidate bits are a superset of edge bits, so
+//       testing them gives a (harmless) superset of the words the hole kernels need.
 __global__ void __launch_bounds__(256)
-k_collect_words(const u64 *bits, int mode, int *wlist, int *counters, int cidx, int h, int w, const int *active) {
+k_collect_words(const u64 *cand, int *wl_fg, int *wl_bg, int *counters, int h, int w, const int *active) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     int wq = LFD_WQ(w);
     int idx = blockIdx.x * 256 + threadIdx.x;
-    bool take = false;
+    bool tf = false, tb = false;
     if (idx < h * wq) {
-        const u64 *b = bits + (size_t)g * h * wq;
-        if (mode) take = b[idx] != 0;
-        else {
-            int y = idx / wq, q = idx - y * wq;
-            u64 m = b[idx];
-            if (q > 0) m |= b[idx - 1] >> 63;
-            if (y > 0) { m |= b[idx - wq]; if (q > 0) m |= b[idx - wq - 1] >> 63; }
-            take = (m != 0) || (q == 0);
-        }
+        const u64 *b = cand + (size_t)g * h * wq;
+        int y = idx / wq, q = idx - y * wq;
+        u64 m = b[idx];
+        tf = m != 0;
+        if (q > 0) m |= b[idx - 1] >> 63;
+        if (y > 0) { m |= b[idx - wq]; if (q > 0) m |= b[idx - wq - 1] >> 63; }
+        tb = (m != 0) || (q == 0);
     }
-    u64 bal = __ballot(take);
     int lane = lfd_lane();
-    int base = 0;
-    if (lane == 0 && bal) base = atomicAdd(&counters[g * C_COUNT + cidx], __popcll(bal));
-    base = __shfl(base, 0);
-    if (take) wlist[(size_t)g * h * wq + base + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
+    u64 bf = __ballot(tf), bb = __ballot(tb);
+    int basef = 0, baseb = 0;
+    if (lane == 0) {
+        if (bf) basef = atomicAdd(&counters[g * C_COUNT + C_NFGW], __popcll(bf));
+        if (bb) baseb = atomicAdd(&counters[g * C_COUNT + C_NBGW], __popcll(bb));
+    }
+    basef = __shfl(basef, 0);
+    baseb = __shfl(baseb, 0);
+    u64 lt = (1ull << lane) - 1ull;
+    if (tf) wl_fg[(size_t)g * h * wq + basef + __popcll(bf & lt)] = idx;
+    if (tb) wl_bg[(size_t)g * h * wq + baseb + __popcll(bb & lt)] = idx;
 }
 
 // every run kernel walks its frame's work list with a fixed grid

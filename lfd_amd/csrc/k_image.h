@@ -286,8 +286,8 @@ k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, 
     const int IH = MORPH_TH + kh - 1;
     const int IWB = MORPH_TW + 2 * MORPH_HALO; // bytes per staged row
     uint8_t *tin = smv;                       // IH x IWB
-    uint8_t *tmp = smv + IH * IWB;            // IH x MORPH_TW
-    uint8_t *tout = tmp + IH * MORPH_TW;      // MORPH_TH x MORPH_TW
+    uint8_t *tmp = smv + IH * IWB;            // IH x MORPH_TW x 2 (split even/odd bytes)
+    uint8_t *tout = tmp + IH * MORPH_TW * 2;  // MORPH_TH x MORPH_TW
     __shared__ uint8_t slut[256];
     __shared__ int rowflag[MORPH_TH + LFDMI_MAX_MORPH_K]; // dilation: staged row holds a non-zero byte
     const int fill = OP ? 255 : 0;
@@ -331,37 +331,64 @@ k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, 
         }
         return;
     }
-    for (int ry = wv; ry < IH; ry += 4) {
-        int m = fill;
+    // Four pixels per lane: a dword of the tile is split into its even and odd bytes, each as
+    // two 16-bit lanes (0x00FF00FF masks), so that one v_pk_max_u16 / v_pk_min_u16 handles two
+    // pixels and LDS traffic is dwords, not bytes.  tmp keeps the horizontal result in that split
+    // form: (IH x 16) even words followed by (IH x 16) odd words.
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    uint32_t *tinw = (uint32_t *)tin;
+    uint32_t *tmpE = (uint32_t *)tmp, *tmpO = tmpE + IH * (MORPH_TW / 4);
+    const uint32_t fsplit = OP ? 0x00FF00FFu : 0u;
+    for (int it = threadIdx.x; it < IH * (MORPH_TW / 4); it += 256) {
+        int ry = it >> 4, j = it & 15;
+        uint32_t aE = fsplit, aO = fsplit;
         if (OP || rowflag[ry]) { // an all-zero staged row dilates to zeros
-            const uint8_t *row = tin + ry * IWB + (MORPH_HALO - ax) + lane;
-            for (int dx = 0; dx < kw; dx++) {
-                int v = row[dx];
-                m = OP ? min(m, v) : max(m, v);
+            int o = MORPH_HALO - ax + 4 * j; // byte offset of the window's first column
+            const uint32_t *rw = tinw + ry * (IWB / 4);
+            int qi = o >> 2;
+            uint32_t lo = rw[qi], hi = rw[qi + 1];
+            for (int dx = 0; dx < kw; dx++, o++) {
+                if ((o >> 2) != qi) { qi = o >> 2; lo = hi; hi = rw[qi + 1]; }
+                uint32_t sft = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o & 3));
+                us2 e = __builtin_bit_cast(us2, sft & 0x00FF00FFu), od = __builtin_bit_cast(us2, (sft >> 8) & 0x00FF00FFu);
+                us2 ce = __builtin_bit_cast(us2, aE), co = __builtin_bit_cast(us2, aO);
+                ce = OP ? __builtin_elementwise_min(ce, e) : __builtin_elementwise_max(ce, e);
+                co = OP ? __builtin_elementwise_min(co, od) : __builtin_elementwise_max(co, od);
+                aE = __builtin_bit_cast(uint32_t, ce);
+                aO = __builtin_bit_cast(uint32_t, co);
             }
         }
-        tmp[ry * MORPH_TW + lane] = (uint8_t)m;
+        tmpE[it] = aE;
+        tmpO[it] = aO;
     }
     __syncthreads();
-    for (int oy = wv; oy < MORPH_TH; oy += 4) {
-        int m = fill;
+    for (int it = threadIdx.x; it < MORPH_TH * (MORPH_TW / 4); it += 256) {
+        int oy = it >> 4, j = it & 15;
+        uint32_t aE = fsplit, aO = fsplit;
         bool live = OP != 0;
         if (!OP) for (int dy = 0; dy < kh; dy++) live = live || rowflag[oy + dy];
         if (live)
             for (int dy = 0; dy < kh; dy++) {
-                int v = tmp[(oy + dy) * MORPH_TW + lane];
-                m = OP ? min(m, v) : max(m, v);
+                us2 e = __builtin_bit_cast(us2, tmpE[(oy + dy) * 16 + j]), od = __builtin_bit_cast(us2, tmpO[(oy + dy) * 16 + j]);
+                us2 ce = __builtin_bit_cast(us2, aE), co = __builtin_bit_cast(us2, aO);
+                ce = OP ? __builtin_elementwise_min(ce, e) : __builtin_elementwise_max(ce, e);
+                co = OP ? __builtin_elementwise_min(co, od) : __builtin_elementwise_max(co, od);
+                aE = __builtin_bit_cast(uint32_t, ce);
+                aO = __builtin_bit_cast(uint32_t, co);
             }
-        int gy = y0 + oy, gx = x0 + lane;
-        bool valid = gy < h && gx < w;
-        int out = lut ? slut[m] : m;
-        tout[oy * MORPH_TW + lane] = (uint8_t)out;
-        if (bits) {
-            u64 bal = __ballot(valid && out != 0);
-            if (lane == 0 && gy < h) bits[(size_t)g * h * wq + (size_t)gy * wq + blockIdx.x] = bal;
-        }
+        uint32_t word = aE | (aO << 8);
+        if (lut)
+            word = (uint32_t)slut[word & 0xff] | ((uint32_t)slut[(word >> 8) & 0xff] << 8) |
+                   ((uint32_t)slut[(word >> 16) & 0xff] << 16) | ((uint32_t)slut[word >> 24] << 24);
+        ((uint32_t *)tout)[it] = word;
     }
     __syncthreads();
+    if (bits)
+        for (int oy = wv; oy < MORPH_TH; oy += 4) {
+            int gy = y0 + oy, gx = x0 + lane;
+            u64 bal = __ballot(gy < h && gx < w && tout[oy * MORPH_TW + lane] != 0);
+            if (lane == 0 && gy < h) bits[(size_t)g * h * wq + (size_t)gy * wq + blockIdx.x] = bal;
+        }
     if (threadIdx.x < MORPH_TH * 4) {
         int row = threadIdx.x >> 2, c16 = threadIdx.x & 3;
         int gy = y0 + row, gx = x0 + 16 * c16;
@@ -439,6 +466,123 @@ k_u8_from_bits(const u64 *bits, uint8_t *dst, int h, int w) {
 // ------------------------------------------------------------------------------------------
 #define CANNY_TW 64
 #define CANNY_TH 32
+#define CANNY_HALO 16               // staged columns left/right of the tile (aligned 16-byte pieces)
+#define CANNY_MOFF 12               // first staged column that gets a magnitude (tile column -4)
+#define CANNY_MW 72                 // magnitudes per row: tile columns -4 .. 67
+
+// Frames whose width is a multiple of 16: 16-byte tile loads, all-zero-tile exit before any LDS
+// traffic, Sobel/magnitude computed for four pixels per lane from dword LDS reads.
+__global__ void __launch_bounds__(256)
+k_canny_nms_v(const uint8_t *img, u64 *cand, u64 *strong, int h, int w, int low, int high,
+              const int *active) {
+    int g = blockIdx.z;
+    if (active && !active[g]) return;
+    const int PH = CANNY_TH + 4, PWB = CANNY_TW + 2 * CANNY_HALO, MH = CANNY_TH + 2;
+    __shared__ __attribute__((aligned(16))) uint8_t px[PH * PWB]; // rows y0-2 .. y0+TH+1, cols x0-16 .. x0+79
+    __shared__ __attribute__((aligned(16))) int mg[MH * CANNY_MW];
+    __shared__ __attribute__((aligned(16))) int dxy[MH * CANNY_MW];
+    __shared__ int rowflag[PH];
+    int x0 = blockIdx.x * CANNY_TW, y0 = blockIdx.y * CANNY_TH;
+    const uint8_t *s = img + (size_t)g * h * w;
+    if (threadIdx.x < PH) rowflag[threadIdx.x] = 0;
+    __syncthreads();
+    // one 16-byte piece per thread (36 rows x 6 pieces = 216), BORDER_REPLICATE by clamping
+    uint4 v = make_uint4(0, 0, 0, 0);
+    int ty = threadIdx.x / 6, wx = threadIdx.x - ty * 6;
+    bool mine = threadIdx.x < PH * 6;
+    if (mine) {
+        int gy = min(max(y0 - 2 + ty, 0), h - 1), gx = x0 - CANNY_HALO + 16 * wx;
+        if (gx >= 0 && gx < w) v = *(const uint4 *)(s + (size_t)gy * w + gx);
+        else {
+            uint32_t e = s[(size_t)gy * w + (gx < 0 ? 0 : w - 1)];
+            e |= e << 8; e |= e << 16;
+            v = make_uint4(e, e, e, e);
+        }
+    }
+    uint32_t nzv = v.x | v.y | v.z | v.w;
+    int wq = LFD_WQ(w);
+    // an all-zero tile (sky) has zero gradient everywhere: no candidate when low >= 0
+    if (!__syncthreads_or(nzv != 0) && low >= 0) {
+        if (threadIdx.x < CANNY_TH && y0 + threadIdx.x < h) {
+            size_t o = (size_t)g * h * wq + (size_t)(y0 + threadIdx.x) * wq + blockIdx.x;
+            cand[o] = 0ull;
+            strong[o] = 0ull;
+        }
+        return;
+    }
+    if (mine) {
+        ((uint4 *)px)[threadIdx.x] = v;
+        if (nzv) rowflag[ty] = 1;
+    }
+    __syncthreads();
+    // Sobel + L1 magnitude, 4 pixels per lane: staged bytes 12..83 of rows 1..MH (tile cols -4..67)
+    const uint32_t *pw = (const uint32_t *)px;
+    for (int it = threadIdx.x; it < MH * (CANNY_MW / 4); it += 256) {
+        int my = it / (CANNY_MW / 4), k = it - my * (CANNY_MW / 4); // k: word 3 + k of the staged row
+        int gy = y0 - 1 + my;
+        int4 m4 = make_int4(0, 0, 0, 0), d4 = make_int4(0, 0, 0, 0);
+        if ((rowflag[my] | rowflag[my + 1] | rowflag[my + 2]) && gy >= 0 && gy < h) {
+            int b[3][6]; // bytes -1..4 around the word, for the three rows
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const uint32_t *rw = pw + (my + r) * (PWB / 4) + 3 + k;
+                uint32_t wm = rw[-1], wc = rw[0], wp = rw[1];
+                b[r][0] = wm >> 24; b[r][1] = wc & 0xff; b[r][2] = (wc >> 8) & 0xff;
+                b[r][3] = (wc >> 16) & 0xff; b[r][4] = wc >> 24; b[r][5] = wp & 0xff;
+            }
+            int mm[4], dd[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int gx = x0 - 4 + 4 * k + i;
+                int dx = (b[0][i + 2] - b[0][i]) + 2 * (b[1][i + 2] - b[1][i]) + (b[2][i + 2] - b[2][i]);
+                int dy = (b[2][i] - b[0][i]) + 2 * (b[2][i + 1] - b[0][i + 1]) + (b[2][i + 2] - b[0][i + 2]);
+                bool in = gx >= 0 && gx < w;
+                mm[i] = in ? abs(dx) + abs(dy) : 0;
+                dd[i] = in ? ((dx & 0xffff) | (dy << 16)) : 0;
+            }
+            m4 = make_int4(mm[0], mm[1], mm[2], mm[3]);
+            d4 = make_int4(dd[0], dd[1], dd[2], dd[3]);
+        }
+        ((int4 *)mg)[it] = m4;
+        ((int4 *)dxy)[it] = d4;
+    }
+    __syncthreads();
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int oy = wv; oy < CANNY_TH; oy += 4) {
+        int gy = y0 + oy, gx = x0 + lane;
+        bool keep = false, str = false;
+        if (gy < h && gx < w) {
+            const int *mc = mg + (oy + 1) * CANNY_MW + (lane + 4);
+            int m = mc[0];
+            if (m > low) {
+                int d = dxy[(oy + 1) * CANNY_MW + (lane + 4)];
+                int xs = (int)(short)(d & 0xffff), ys = d >> 16;
+                int ax = abs(xs), ay = abs(ys) << 15;
+                int tg22x = ax * 13573;
+                if (ay < tg22x) {
+                    keep = (m > mc[-1]) && (m >= mc[1]);
+                } else {
+                    int tg67x = tg22x + (ax << 16);
+                    if (ay > tg67x) {
+                        keep = (m > mc[-CANNY_MW]) && (m >= mc[CANNY_MW]);
+                    } else {
+                        int sgn = ((xs ^ ys) < 0) ? -1 : 1;
+                        keep = (m > mc[-CANNY_MW - sgn]) && (m > mc[CANNY_MW + sgn]);
+                    }
+                }
+                str = keep && (m > high);
+            }
+        }
+        u64 bc = __ballot(keep), bs = __ballot(str);
+        if (lane == 0 && gy < h) {
+            size_t o = (size_t)g * h * wq + (size_t)gy * wq + blockIdx.x;
+            cand[o] = bc;
+            strong[o] = bs;
+        }
+    }
+}
+
+// generic widths
 
 __global__ void __launch_bounds__(256)
 k_canny_nms(const uint8_t *img, u64 *cand, u64 *strong, int h, int w, int low, int high,

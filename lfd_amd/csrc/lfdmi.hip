@@ -342,7 +342,8 @@ static int run_morph(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, u64 *bits
     Span sp(ctx, op ? KID_ERODE : KID_DILATE);
     if (all_ones(kernel, kh, kw) && (w % 16) == 0) {
         int IH = MORPH_TH + kh - 1;
-        size_t lds = (size_t)IH * (MORPH_TW + 2 * MORPH_HALO) + (size_t)IH * MORPH_TW + (size_t)MORPH_TH * MORPH_TW;
+        // staged tile + split horizontal result (2 dwords per 4 px) + output tile
+        size_t lds = (size_t)IH * (MORPH_TW + 2 * MORPH_HALO) + (size_t)IH * MORPH_TW * 2 + (size_t)MORPH_TH * MORPH_TW;
         dim3 grid((w + MORPH_TW - 1) / MORPH_TW, (h + MORPH_TH - 1) / MORPH_TH, nc);
         if (op == 0) k_morph_rect_v<0><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active);
         else k_morph_rect_v<1><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active);
@@ -373,7 +374,8 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
     {
         Span sp(ctx, KID_CANNY_NMS);
         dim3 grid((w + CANNY_TW - 1) / CANNY_TW, (h + CANNY_TH - 1) / CANNY_TH, nc);
-        k_canny_nms<<<grid, 256, 0, ctx->stream>>>(img, ctx->candb, ctx->strongb, h, w, low, high, active);
+        if ((w % 16) == 0) k_canny_nms_v<<<grid, 256, 0, ctx->stream>>>(img, ctx->candb, ctx->strongb, h, w, low, high, active);
+        else k_canny_nms<<<grid, 256, 0, ctx->stream>>>(img, ctx->candb, ctx->strongb, h, w, low, high, active);
         KCHK("k_canny_nms");
     }
     dim3 wg = word_grid(h, w, nc);
@@ -381,8 +383,8 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
     size_t BW = (size_t)h * LFD_WQ(w);
     HIPCHK(hipMemsetAsync(ctx->edgeb, 0, (size_t)nc * BW * sizeof(u64), ctx->stream));
     { Span sp(ctx, KID_RUNS_INIT_FG);
-      k_collect_words<<<wg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->wl_fg, ctx->counters, C_NFGW, h, w, active);
-      KCHK("k_collect_words(fg)");
+      k_collect_words<<<wg, 256, 0, ctx->stream>>>(ctx->candb, ctx->wl_fg, ctx->wl_bg, ctx->counters, h, w, active);
+      KCHK("k_collect_words");
       k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->Lf, ctx->YMf, ctx->FLf, h, w, ctx->wl_fg, ctx->counters, C_NFGW, active);
       KCHK("k_runs_init"); }
     { Span sp(ctx, KID_RUNS_MERGE8);
@@ -412,8 +414,6 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     size_t BW = (size_t)h * LFD_WQ(w);
     dim3 lg(WORDLIST_BLOCKS, nc);
     { Span sp(ctx, KID_RUNS_INIT_BG);
-      k_collect_words<<<wg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->wl_bg, ctx->counters, C_NBGW, h, w, active);
-      KCHK("k_collect_words(bg)");
       k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->Lb, ctx->YMb, ctx->FLb, h, w, ctx->wl_bg, ctx->counters, C_NBGW, active);
       KCHK("k_runs_init(bg)"); }
     { Span sp(ctx, KID_RUNS_MERGE4);
