@@ -168,9 +168,10 @@ class Context:
         self.device, self.max_h, self.max_w, self.max_inflight = device, max_h, max_w, max_inflight
 
     def close(self):
-        if getattr(self, "_h", None):
-            self._lib.lfdmi_ctx_destroy(self._h)
-            self._h = C.c_void_p()
+        h = getattr(self, "_h", None)
+        if h:
+            self._h = None
+            self._lib.lfdmi_ctx_destroy(h)
 
     __del__ = close
 

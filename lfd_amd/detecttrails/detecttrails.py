@@ -27,7 +27,7 @@ from .removestars import read_photoObj_arrays
 RETR_EXTERNAL, RETR_LIST, RETR_CCOMP, RETR_TREE = 0, 1, 2, 3
 CHAIN_APPROX_NONE, CHAIN_APPROX_SIMPLE, CHAIN_APPROX_TC89_L1, CHAIN_APPROX_TC89_KCOS = 1, 2, 3, 4
 
-__all__ = ["DetectTrails", "process_field", "process_frame_arrays", "default_params"]
+__all__ = ["DetectTrails", "process_field", "process_fields_batched", "process_frame_arrays", "default_params"]
 
 _HEADER_KEYS = ("TAI", "CRPIX1", "CRPIX2", "CRVAL1", "CRVAL2", "CD1_1", "CD1_2", "CD2_1", "CD2_2")
 
@@ -85,6 +85,31 @@ def process_frame_arrays(img, cat, filter, params_bright, params_dim, params_rem
     return False, None, rec
 
 
+def _load_frame(run, camcol, filter, field):
+    """Frame image (float32, C-contiguous), results-row head, photoObj columns; raises like the
+    reference when neither the .fits nor the .fits.bz2 exists (detecttrails.py:81-87)."""
+    path = sdssfiles.filename("frame", run=run, camcol=camcol, field=field, filter=filter)
+    if not os.path.exists(path):
+        if not os.path.exists(path + ".bz2"):
+            raise FileNotFoundError(("File {0} or its bz2 compressed version not found. "
+                                     "Are you sure they exist?").format(path))
+        path = path + ".bz2"  # decompressed in memory; no $FITS_DUMP round trip needed
+    img, h = fitslite.read_image(path)
+    img = _np.ascontiguousarray(img, dtype=_np.float32)
+    head = " ".join(str(x) for x in (run, camcol, filter, field, *(h[k] for k in _HEADER_KEYS)))
+    cat = read_photoObj_arrays(sdssfiles.filename("photoObj", run=run, camcol=camcol, field=field))
+    return img, head, cat
+
+
+def _log_error(errors, ids, exc, debug):
+    """errors.txt entry of the reference (detecttrails.py:133-139): ids, 3-frame traceback, message."""
+    if debug:
+        traceback.print_exception(type(exc), exc, exc.__traceback__, limit=3)
+    errors.write("{} {} {} {}\n".format(*ids))
+    traceback.print_exception(type(exc), exc, exc.__traceback__, limit=3, file=errors)
+    errors.write(str(exc) + "\n\n")
+
+
 def process_field(results, errors, run, camcol, filter, field, params_bright, params_dim,
                   params_removestars):
     """One frame end to end (reference: detecttrails.py:30-143): locate the frame (or its .bz2),
@@ -92,26 +117,67 @@ def process_field(results, errors, run, camcol, filter, field, params_bright, pa
     crval1 crval2 cd11 cd12 cd21 cd22 x1 y1 x2 y2`` to ``results``; every exception is logged
     to ``errors`` (ids, 3-frame traceback, message) and swallowed."""
     try:
-        path = sdssfiles.filename("frame", run=run, camcol=camcol, field=field, filter=filter)
-        if not os.path.exists(path):
-            if not os.path.exists(path + ".bz2"):
-                raise FileNotFoundError(("File {0} or its bz2 compressed version not found. "
-                                         "Are you sure they exist?").format(path))
-            path = path + ".bz2"  # decompressed in memory; no $FITS_DUMP round trip needed
-        img, h = fitslite.read_image(path)
-        img = _np.ascontiguousarray(img, dtype=_np.float32)
-        head = " ".join(str(x) for x in (run, camcol, filter, field, *(h[k] for k in _HEADER_KEYS)))
-        cat = read_photoObj_arrays(sdssfiles.filename("photoObj", run=run, camcol=camcol, field=field))
+        img, head, cat = _load_frame(run, camcol, filter, field)
         detection, res, _ = process_frame_arrays(img, cat, filter, params_bright, params_dim,
                                                  params_removestars)
         if detection:
             results.write(f"{head} {res['x1']} {res['y1']} {res['x2']} {res['y2']}\n")
     except Exception as e:  # noqa: BLE001 - the reference swallows everything per frame
-        if params_bright.get("debug") or params_dim.get("debug"):
-            traceback.print_exc(limit=3)
-        errors.write(f"{run} {camcol} {filter} {field}\n")
-        traceback.print_exc(limit=3, file=errors)
-        errors.write(str(e) + "\n\n")
+        _log_error(errors, (run, camcol, filter, field), e, params_bright.get("debug") or params_dim.get("debug"))
+
+
+def process_fields_batched(results, errors, ids, params_bright, params_dim, params_removestars):
+    """Same outcome as calling process_field for every (run, camcol, filter, field) in ``ids``, in order,
+    but all frames that load go through ONE lfdmi_detect_batch call (frames with different
+    filters use different magnitude caps, so the batch is grouped by filter)."""
+    loaded = []
+    for key in ids:
+        try:
+            loaded.append((key,) + _load_frame(*key))
+        except Exception as e:  # noqa: BLE001
+            loaded.append((key, e))
+    rows = {}
+    debug = params_bright.get("debug") or params_dim.get("debug")
+    by_filter = {}
+    for item in loaded:
+        if len(item) == 4:
+            by_filter.setdefault(item[0][2], []).append(item)
+    from .. import synth
+    for flt, items in by_filter.items():
+        shapes = {it[1].shape for it in items}
+        for shape in shapes:
+            group = [it for it in items if it[1].shape == shape]
+            try:
+                for it in group:
+                    from .removestars import _check_finite
+                    _check_finite(it[3])
+                frames = _np.stack([it[1] for it in group])
+                packed = synth.pack_catalogs([it[3] for it in group])
+                ctx = get_context(*shape, inflight=min(32, len(group)))
+                recs = ctx.detect_batch(frames, params_bright, params_dim, packed, _rs_struct(flt, params_removestars))
+                for it, rec in zip(group, recs):
+                    rows[it[0]] = rec
+            except Exception as e:  # noqa: BLE001 - fall back to per-frame handling of this group
+                for it in group:
+                    rows[it[0]] = e
+    for item in loaded:
+        key = item[0]
+        try:
+            if len(item) == 2:
+                raise item[1]
+            rec = rows[key]
+            if isinstance(rec, Exception):
+                raise rec
+            status = int(rec["status"])
+            if status == _native.ERR_NOLINES:
+                raise TypeError("'NoneType' object is not subscriptable")
+            if status:
+                raise _native.NativeError(status, "frame failed on the device")
+            if rec["found"]:
+                res = dictify_hough(item[1].shape, (_np.float32(rec["rho"]), _np.float32(rec["theta"])))
+                results.write(f"{item[2]} {res['x1']} {res['y1']} {res['x2']} {res['y2']}\n")
+        except Exception as e:  # noqa: BLE001
+            _log_error(errors, key, e, debug)
 
 
 class DetectTrails:
@@ -222,9 +288,31 @@ class DetectTrails:
         elif pick == "field":
             yield self._run, self._camcol, self._filter, self._field
 
-    def process(self):
-        """Run process_field over the selection; results and errors files are opened in append mode."""
-        with open(self.results, "a") as results, open(self.errors, "a") as errors:
-            for run, camcol, flt, field in self._frames():
-                process_field(results, errors, run, camcol, flt, field, self.params_bright,
-                              self.params_dim, self.params_removestars)
+    def process(self, batch=1, rank=None, world_size=None):
+        """Run the selection; results and errors files are opened in append mode.
+
+        ``batch`` > 1 sends that many frames to the GPU per call (same rows, same order).
+        With ``world_size`` > 1 (default: $RANK / $WORLD_SIZE, i.e. one process per GPU under
+        torchrun) every rank processes frames ``rank, rank + world_size, ...`` of the selection and
+        appends to ``<results>.rank<r>`` / ``<errors>.rank<r>`` -- the replacement for splitting runs
+        into PBS jobs (lfd/createjobs)."""
+        rank = int(os.environ.get("RANK", 0)) if rank is None else rank
+        world_size = int(os.environ.get("WORLD_SIZE", 1)) if world_size is None else world_size
+        suffix = f".rank{rank}" if world_size > 1 else ""
+        with open(self.results + suffix, "a") as results, open(self.errors + suffix, "a") as errors:
+            pending = []
+            for i, key in enumerate(self._frames()):
+                if i % world_size != rank:
+                    continue
+                if batch <= 1:
+                    process_field(results, errors, *key, self.params_bright, self.params_dim,
+                                  self.params_removestars)
+                    continue
+                pending.append(key)
+                if len(pending) == batch:
+                    process_fields_batched(results, errors, pending, self.params_bright, self.params_dim,
+                                           self.params_removestars)
+                    pending = []
+            if pending:
+                process_fields_batched(results, errors, pending, self.params_bright, self.params_dim,
+                                       self.params_removestars)

@@ -169,7 +169,8 @@ def _card(key, val, comment=""):
     elif isinstance(val, (int, np.integer)):
         v = f"{int(val):>20}"
     elif isinstance(val, (float, np.floating)):
-        v = f"{float(val):>20.12G}"
+        t = repr(float(val)).upper()          # keeps a decimal point or exponent: stays a float on read
+        v = f"{t:>20}"
     else:
         s = "'" + str(val).replace("'", "''").ljust(8) + "'"
         v = f"{s:<20}"

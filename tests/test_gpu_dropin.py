@@ -1,0 +1,93 @@
+"""The drop-in driver end to end on the GPU: a synthetic $BOSS tree of FITS frames and photoObj
+tables -> DetectTrails(...).process() -> results.txt rows equal to the CPU oracle's, for the
+per-frame and the batched code paths (reference flow: detecttrails.py:30-143, :344-407)."""
+import bz2
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HDR = {"TAI": 4649973000.5, "CRPIX1": 1025.0, "CRPIX2": 745.0, "CRVAL1": 10.5, "CRVAL2": -1.25,
+       "CD1_1": 1e-4, "CD1_2": 2e-5, "CD2_1": -2e-5, "CD2_2": 1e-4}
+
+
+def build_tree(root, fields, shape=(512, 768)):
+    from lfd_amd import synth
+    from lfd_amd.detecttrails import fitslite, sdssfiles
+    redux = root / "photo" / "redux"
+    redux.mkdir(parents=True)
+    (redux / "runList.par").write_text(
+        "typedef struct {\n int run;\n char rerun[];\n int exist;\n int done;\n int calib;\n int startfield;\n"
+        " int endfield;\n char machine[];\n char disk[];\n} RUNDATA;\n\n"
+        f"RUNDATA 94 301 1 1 1 {fields[0]} {fields[-1] + 1} m d\n")
+    os.environ["PHOTO_REDUX"] = str(redux)
+    os.environ["BOSS_PHOTOOBJ"] = str(root / "photoObj")
+    sdssfiles._runlist_cache.clear()
+    truth = {}
+    for i, field in enumerate(fields):
+        img, cat, t = synth.make_portable_frame(field, shape)
+        fpath = sdssfiles.filename("frame", 94, 1, field, "r")
+        os.makedirs(os.path.dirname(fpath), exist_ok=True)
+        if i == 1:      # one frame only as .bz2 (detecttrails.py:81-109)
+            tmp = fpath + ".tmp"
+            fitslite.write_image(tmp, img, HDR)
+            with open(tmp, "rb") as f, open(fpath + ".bz2", "wb") as g:
+                g.write(bz2.compress(f.read()))
+            os.remove(tmp)
+        else:
+            fitslite.write_image(fpath, img, HDR)
+        if i != 2:      # one field has no catalogue -> an errors.txt entry
+            ppath = sdssfiles.filename("photoObj", 94, 1, field)
+            os.makedirs(os.path.dirname(ppath), exist_ok=True)
+            cols = dict(cat)
+            cols["OBJC_TYPE"] = np.zeros(len(cat["NOBSERVE"]), np.int32)
+            cols["TYPE"] = np.zeros((len(cat["NOBSERVE"]), 5), np.int32)
+            fitslite.write_table(ppath, cols)
+        truth[field] = (img, cat)
+    return truth
+
+
+def expected_rows(oracle, truth, skip):
+    from lfd_amd import results
+    from lfd_amd.detecttrails import default_params
+    pb, pd, prs = default_params()
+    rs = oracle.rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
+    rows = []
+    for field, (img, cat) in truth.items():
+        if field in skip:
+            continue
+        rec = oracle.detect_frame(img.copy(), pb, pd, cat, rs)
+        if rec["found"]:
+            rows.append(results.format_result_row(94, 1, "r", field, HDR, rec))
+    return rows
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_detecttrails_process(tmp_path, oracle, batch):
+    from lfd_amd.detecttrails import DetectTrails
+    fields = list(range(0, 7))
+    truth = build_tree(tmp_path, fields)
+    want = expected_rows(oracle, truth, skip={fields[2]})
+    assert len(want) >= 2
+    dt = DetectTrails(run=94, camcol=1, filter="r", savepath=str(tmp_path))
+    dt.process(batch=batch)
+    got = [l.strip() for l in open(dt.results) if l.strip()]
+    assert got == want
+    err = open(dt.errors).read()
+    assert err.count("\n\n") == 1 and err.startswith(f"94 1 r {fields[2]}\n") and "FileNotFoundError" in err
+
+
+def test_rank_sharding_of_the_driver(tmp_path, oracle):
+    """world_size = 2 in one process: the two ranks' files together hold the single-process rows."""
+    from lfd_amd.detecttrails import DetectTrails
+    fields = list(range(0, 6))
+    truth = build_tree(tmp_path, fields)
+    want = expected_rows(oracle, truth, skip={fields[2]})
+    for r in (0, 1):
+        DetectTrails(run=94, camcol=1, filter="r", savepath=str(tmp_path)).process(batch=2, rank=r, world_size=2)
+    got = []
+    for r in (0, 1):
+        got += [l.strip() for l in open(tmp_path / f"results.txt.rank{r}") if l.strip()]
+    assert sorted(got) == sorted(want)
