@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=24, help="frames timed through the CPU oracle (0 = skip)")
     ap.add_argument("--gen-workers", type=int, default=-1)
     ap.add_argument("--no-removestars", action="store_true")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="hand the frames over as host buffers (PCIe-inclusive rate; never the headline value)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -113,8 +115,14 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     det = BatchDetector(local_rank, (h, w), args.inflight, stream=stream, lanes=args.lanes)
 
-    def step():
-        return det.detect(dframes, pb, pd, cat, rs)
+    if args.host_frames:
+        hcat = None if args.no_removestars else packed
+
+        def step():
+            return det.detect(host, pb, pd, hcat, rs)
+    else:
+        def step():
+            return det.detect(dframes, pb, pd, cat, rs)
 
     def fence():
         torch.cuda.synchronize()
@@ -156,7 +164,8 @@ def main():
                 tj = json.load(f)
             c = tj["config"]
             if (c["frames_per_gpu"], c["inflight"], c["lanes"], c["shape"]) == (n, args.inflight, args.lanes, [h, w]):
-                key = {"k_morph(dilate)": "k_morph_rect_v<0>", "k_morph(erode)": "k_morph_rect_v<1>"}.get(name, name.split("(")[0])
+                key = {"k_morph(dilate)": "k_morph_rect_v<0>", "k_morph(erode)": "k_morph_rect_v<1>",
+                       "k_canny_nms": "k_canny_nms_v", "k_hough_vote": "k_hough_vote<6>"}.get(name, name.split("(")[0])
                 traffic = tj["kernels"][key]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None
@@ -168,7 +177,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: full removestars+bright+dim pipe, batch=%d synthetic SDSS "
-                                   "2048x1489 float32 frames per GPU, device-resident" % n,
+                                   "2048x1489 float32 frames per GPU, %s" % (n, "HOST-resident (PCIe-inclusive)" if args.host_frames else "device-resident"),
                        "frames_per_gpu": n, "inflight": args.inflight, "lanes": args.lanes, "shape": [h, w],
                        "removestars": not args.no_removestars, "parallelism": "frame-parallel x%d" % world,
                        "found_bright": found_b, "found_dim": found_d, "frame_errors": errors,

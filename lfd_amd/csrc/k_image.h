@@ -290,7 +290,6 @@ k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, 
     uint8_t *tout = tmp + IH * MORPH_TW * 2;  // MORPH_TH x MORPH_TW
     __shared__ uint8_t slut[256];
     __shared__ int rowflag[MORPH_TH + LFDMI_MAX_MORPH_K]; // dilation: staged row holds a non-zero byte
-    const int fill = OP ? 255 : 0;
     const uint32_t fillw = OP ? 0xffffffffu : 0u;
     int x0 = blockIdx.x * MORPH_TW, y0 = blockIdx.y * MORPH_TH;
     int ay = kh / 2, ax = kw / 2;

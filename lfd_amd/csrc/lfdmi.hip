@@ -410,7 +410,6 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
         return fail(ctx, LFDMI_ERR_UNSUPPORTED, "contoursMethod: only CHAIN_APPROX_NONE / CHAIN_APPROX_SIMPLE");
     if (mode != LFDMI_RETR_LIST && mode != LFDMI_RETR_CCOMP && mode != LFDMI_RETR_TREE)
         return fail(ctx, LFDMI_ERR_UNSUPPORTED, "contoursMode: only RETR_LIST / RETR_CCOMP / RETR_TREE");
-    dim3 wg = word_grid(h, w, nc);
     size_t BW = (size_t)h * LFD_WQ(w);
     dim3 lg(WORDLIST_BLOCKS, nc);
     { Span sp(ctx, KID_RUNS_INIT_BG);
