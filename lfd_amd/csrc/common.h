@@ -19,6 +19,8 @@ enum {
     C_NBIG = 9,      // keys tall enough for the wave-per-key hull path
     C_NFGW = 10,     // bit-row words holding Canny candidates (work list of the edge-run kernels)
     C_NBGW = 11,     // bit-row words where a background run can start or join (work list of the hole kernels)
+    C_NRUNF = 12,    // candidate runs in the frame (compact run ids 0 .. n-1)
+    C_NRUNB = 13,    // background runs of the edge image
     C_COUNT = 16
 };
 

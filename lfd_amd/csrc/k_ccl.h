@@ -7,9 +7,15 @@
 //   * the hull of an outer border == the hull of all pixels of S1,
 //   * a hole border == the pixels of the surrounding component A that are 4-adjacent to the
 //     hole B, where A is the component of the pixel right above B's raster-first pixel,
-// so labelling runs of the bit rows (union-find over run starts, labels indexed by the pixel
-// index of the run start, root = raster-first run) replaces the sequential Suzuki-Abe trace.
-// Work is proportional to the number of runs (~ edge pixels + rows), not to the image area.
+// so labelling runs of the bit rows (union-find over runs, root = raster-first run) replaces the
+// sequential Suzuki-Abe trace.  Work is proportional to the number of runs (~ edge pixels +
+// rows), not to the image area.
+//
+// Runs carry COMPACT ids: k_scan_runs stores, per 64-bit word, how many runs start before it
+// (exclusive scan in raster order), so the run that holds pixel (y, x) is
+//   scan[word] + popcount(start bits of the word at columns <= x) - 1
+// -- an O(1) lookup -- and all label arrays have one entry per run (a few thousand per frame,
+// cache resident) instead of one per pixel (12 MB per array, every lookup an HBM miss).
 // One thread per ACTIVE 64-bit word of a bit row: k_collect_words compacts the few words that
 // hold any work (a few % of a sky frame) into a per-frame list, so every lane of the run
 // kernels has a word to chew on and their dependent, cache-missing label loads overlap
@@ -68,6 +74,7 @@ k_collect_words(const u64 *cand, int *wl_fg, int *wl_bg, int *counters, int h, i
     if (tb) wl_bg[(size_t)g * h * wq + baseb + __popcll(bb & lt)] = idx;
 }
 
+
 // every run kernel walks its frame's work list with a fixed grid
 #define LFD_WORDLIST_LOOP(cidx_)                                                          \
     int g = blockIdx.y;                                                                   \
@@ -78,37 +85,101 @@ k_collect_words(const u64 *cand, int *wl_fg, int *wl_bg, int *counters, int h, i
     for (int it_ = blockIdx.x * 256 + threadIdx.x; it_ < nwork_; it_ += gridDim.x * 256)
 
 #define WORDLIST_BLOCKS 48
+#define SCAN_THREADS 1024
 
-// L[p] = p, YM[p] = row, FL[p] = 0 for every run start p
+// scan[word] = number of `val`-runs that start in earlier words of the frame (raster order);
+// counters[cidx] = total number of runs.  One workgroup per frame; lane = word (coalesced),
+// 64-word segments: per-segment totals by wave reduction, a scan of the (< 2048) segment totals
+// in LDS, then a wave-level scan inside each segment.
+#define SCAN_MAX_SEG 4096
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_scan_runs(const u64 *bits, int val, int *scan, int *counters, int cidx, int h, int w, int run_cap, const int *active) {
+    int g = blockIdx.x;
+    if (active && !active[g]) return;
+    const int wq = LFD_WQ(w), nw = h * wq;
+    const int nseg = (nw + 63) >> 6;
+    const u64 *b = bits + (size_t)g * nw;
+    int *sc = scan + (size_t)g * nw;
+    __shared__ int segtot[SCAN_MAX_SEG];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = SCAN_THREADS / 64;
+    for (int seg = wv; seg < nseg; seg += nwv) {
+        int i = (seg << 6) + lane, c = 0;
+        if (i < nw) { int y = i / wq; c = __popcll(start_bits(b + (size_t)y * wq, i - y * wq, val, w)); }
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+        if (lane == 0) segtot[seg] = c;
+    }
+    __syncthreads();
+    // exclusive scan of the segment totals (nseg <= SCAN_MAX_SEG; each thread owns up to 4 entries)
+    __shared__ int part[SCAN_THREADS];
+    const int per = (nseg + SCAN_THREADS - 1) / SCAN_THREADS;
+    int s0 = threadIdx.x * per, s1 = min(nseg, s0 + per), local = 0;
+    for (int k = s0; k < s1; k++) local += segtot[k];
+    part[threadIdx.x] = local;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+        int v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - local;
+    for (int k = s0; k < s1; k++) { int t = segtot[k]; segtot[k] = run; run += t; }
+    __syncthreads();
+    for (int seg = wv; seg < nseg; seg += nwv) {
+        int i = (seg << 6) + lane, c = 0;
+        if (i < nw) { int y = i / wq; c = __popcll(start_bits(b + (size_t)y * wq, i - y * wq, val, w)); }
+        int incl = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (i < nw) sc[i] = segtot[seg] + incl - c;
+    }
+    if (threadIdx.x == SCAN_THREADS - 1) {
+        counters[g * C_COUNT + cidx] = part[threadIdx.x];
+        if (part[threadIdx.x] > run_cap) counters[g * C_COUNT + C_OVERFLOW] = 1;
+    }
+}
+
+// id of the `val`-run holding pixel (y, x) (the pixel must have that value)
+__device__ __forceinline__ int run_id(const int *scan_frame, const u64 *frame_bits, int y, int x, int val, int wq, int W) {
+    int q = x >> 6, b = x & 63;
+    u64 s = start_bits(frame_bits + (size_t)y * wq, q, val, W);
+    u64 m = (b == 63) ? ~0ull : ((2ull << b) - 1ull);
+    return scan_frame[y * wq + q] + __popcll(s & m) - 1;
+}
+
+// L[id] = id, YM[id] = ROW[id] = row, FL[id] = 0 for every run
 __global__ void __launch_bounds__(256)
-k_runs_init(const u64 *bits, int val, int *L, int *YM, int *FL, int h, int w, const int *wlist,
-            const int *counters, int cidx, const int *active) {
+k_runs_init(const u64 *bits, int val, const int *scan, int *L, int *YM, int *FL, int *ROW, int h, int w, int run_cap,
+            const int *wlist, const int *counters, int cidx, const int *active) {
     LFD_WORDLIST_LOOP(cidx) {
         int idx = wl_[it_];
         int y = idx / wq, q = idx - y * wq;
         const u64 *row = bits + (size_t)g * h * wq + (size_t)y * wq;
-        u64 s = start_bits(row, q, val, w);
-        size_t N = (size_t)h * w;
-        while (s) {
-            int b = __ffsll((long long)s) - 1;
-            s &= s - 1;
-            int p = y * w + (q << 6) + b;
-            L[g * N + p] = p;
-            YM[g * N + p] = y;
-            FL[g * N + p] = 0;
+        int n = __popcll(start_bits(row, q, val, w));
+        int id0 = scan[(size_t)g * h * wq + idx];
+        size_t o = (size_t)g * run_cap;
+        for (int k = 0; k < n && id0 + k < run_cap; k++) {
+            L[o + id0 + k] = id0 + k;
+            YM[o + id0 + k] = y;
+            ROW[o + id0 + k] = y;
+            FL[o + id0 + k] = 0;
         }
     }
 }
 
 // 8-connectivity between runs of 1-bits in rows y and y-1
 __global__ void __launch_bounds__(256)
-k_runs_merge8(const u64 *bits, int *L, int h, int w, const int *wlist, const int *counters, int cidx,
-              const int *active) {
+k_runs_merge8(const u64 *bits, const int *scan, int *L, int h, int w, int run_cap, const int *wlist, const int *counters,
+              int cidx, const int *active) {
     LFD_WORDLIST_LOOP(cidx) {
     int idx = wl_[it_];
     int y = idx / wq, q = idx - y * wq;
     if (y == 0) continue;
-    const u64 *row = bits + (size_t)g * h * wq + (size_t)y * wq;
+    const u64 *fb = bits + (size_t)g * h * wq;
+    const int *sf = scan + (size_t)g * h * wq;
+    const u64 *row = fb + (size_t)y * wq;
     const u64 *up = row - wq;
     u64 c = row[q];
     if (!c) continue;
@@ -116,41 +187,42 @@ k_runs_merge8(const u64 *bits, int *L, int h, int w, const int *wlist, const int
     u64 uprev = q > 0 ? up[q - 1] : 0ull, unext = q + 1 < wq ? up[q + 1] : 0ull;
     u64 uL = (u << 1) | (uprev >> 63); // bit x set <=> up[x-1]
     u64 uR = (u >> 1) | (unext << 63); // bit x set <=> up[x+1]
-    int *Lg = L + (size_t)g * h * w;
+    int *Lg = L + (size_t)g * run_cap;
     u64 v0 = c & u;
     v0 &= ~(v0 << 1); // first column of every vertical-contact stretch
     u64 vm = c & uL & ~u, vp = c & uR & ~u; // diagonal contacts not implied by a vertical one
-    vm &= ~(vm << 1);
     while (v0) {
         int b = __ffsll((long long)v0) - 1;
         v0 &= v0 - 1;
         int x = (q << 6) + b;
-        uf_union(Lg, y * w + run_start(row, x, 1), (y - 1) * w + run_start(up, x, 1));
+        uf_union(Lg, run_id(sf, fb, y, x, 1, wq, w), run_id(sf, fb, y - 1, x, 1, wq, w));
     }
     while (vm) {
         int b = __ffsll((long long)vm) - 1;
         vm &= vm - 1;
         int x = (q << 6) + b;
-        uf_union(Lg, y * w + run_start(row, x, 1), (y - 1) * w + run_start(up, x - 1, 1));
+        uf_union(Lg, run_id(sf, fb, y, x, 1, wq, w), run_id(sf, fb, y - 1, x - 1, 1, wq, w));
     }
     while (vp) {
         int b = __ffsll((long long)vp) - 1;
         vp &= vp - 1;
         int x = (q << 6) + b;
-        uf_union(Lg, y * w + run_start(row, x, 1), (y - 1) * w + run_start(up, x + 1, 1));
+        uf_union(Lg, run_id(sf, fb, y, x, 1, wq, w), run_id(sf, fb, y - 1, x + 1, 1, wq, w));
     }
     }
 }
 
 // 4-connectivity between runs of 0-bits in rows y and y-1
 __global__ void __launch_bounds__(256)
-k_runs_merge4_bg(const u64 *bits, int *L, int h, int w, const int *wlist, const int *counters, int cidx,
-                 const int *active) {
+k_runs_merge4_bg(const u64 *bits, const int *scan, int *L, int h, int w, int run_cap, const int *wlist,
+                 const int *counters, int cidx, const int *active) {
     LFD_WORDLIST_LOOP(cidx) {
     int idx = wl_[it_];
     int y = idx / wq, q = idx - y * wq;
     if (y == 0) continue;
-    const u64 *row = bits + (size_t)g * h * wq + (size_t)y * wq;
+    const u64 *fb = bits + (size_t)g * h * wq;
+    const int *sb = scan + (size_t)g * h * wq;
+    const u64 *row = fb + (size_t)y * wq;
     const u64 *up = row - wq;
     u64 v = ~row[q] & ~up[q] & valid_mask(q, w);
     // first column of every stretch; a stretch continuing from the previous word (both rows 0
@@ -158,43 +230,41 @@ k_runs_merge4_bg(const u64 *bits, int *L, int h, int w, const int *wlist, const 
     u64 cont = 0;
     if (q > 0) cont = (~row[q - 1] & ~up[q - 1]) >> 63;
     u64 st = v & ~((v << 1) | cont);
-    int *Lg = L + (size_t)g * h * w;
+    int *Lg = L + (size_t)g * run_cap;
     while (st) {
         int b = __ffsll((long long)st) - 1;
         st &= st - 1;
         int x = (q << 6) + b;
-        int sa = run_start(row, x, 0), sb = run_start(up, x, 0);
+        int ia = run_id(sb, fb, y, x, 0, wq, w), ib = run_id(sb, fb, y - 1, x, 0, wq, w);
         // two runs that both start at column 0 touch the frame: each is flagged "outside" on its
         // own, joining them would only build a 1 489-link chain down the left image border
-        if (sa == 0 && sb == 0) continue;
-        uf_union(Lg, y * w + sa, (y - 1) * w + sb);
+        bool a0 = (ia == sb[y * wq]) && !(row[0] & 1ull), b0 = (ib == sb[(y - 1) * wq]) && !(up[0] & 1ull);
+        if (a0 && b0) continue;
+        uf_union(Lg, ia, ib);
     }
     }
 }
 
-// Path-compress every run start to its root; YM[root] = last row of the component;
-// FL[root] = 1 if (val==1) any pixel of the run is set in `mark` (strong edge pixels), or
-// (val==0) the run touches the image frame (the 0-component is the outside).
+// Path-compress every run to its root; YM[root] = last row of the component (edge components
+// only; holes get theirs in k_bg_extent -- the outside is one giant component and every one of
+// its runs would hammer the same word); FL[root] = 1 if (val==1) any pixel of the run is set in
+// `mark` (strong edge pixels), or (val==0) the run touches the image frame (outside).
 __global__ void __launch_bounds__(256)
-k_runs_flatten(const u64 *bits, int val, const u64 *mark, int *L, int *YM, int *FL, int h, int w,
-               const int *wlist, const int *counters, int cidx, const int *active) {
+k_runs_flatten(const u64 *bits, int val, const u64 *mark, const int *scan, int *L, int *YM, int *FL, int h, int w,
+               int run_cap, const int *wlist, const int *counters, int cidx, const int *active) {
     LFD_WORDLIST_LOOP(cidx) {
     int idx = wl_[it_];
     int y = idx / wq, q = idx - y * wq;
     const u64 *row = bits + (size_t)g * h * wq + (size_t)y * wq;
     u64 s = start_bits(row, q, val, w);
-    size_t N = (size_t)h * w;
-    int *Lg = L + g * N, *YMg = YM + g * N, *FLg = FL + g * N;
-    while (s) {
+    int id = scan[(size_t)g * h * wq + idx];
+    int *Lg = L + (size_t)g * run_cap, *YMg = YM + (size_t)g * run_cap, *FLg = FL + (size_t)g * run_cap;
+    for (; s && id < run_cap; id++) {
         int b = __ffsll((long long)s) - 1;
         s &= s - 1;
         int xs = (q << 6) + b;
-        int p = y * w + xs;
-        int root = uf_find(Lg, p);
-        if (root != p) Lg[p] = root;
-        // last row of the component: needed for edge components here; for 0-components only
-        // holes need it (k_bg_extent) -- the outside is one giant component and every one of
-        // its runs would hammer the same word
+        int root = uf_find(Lg, id);
+        if (root != id) Lg[id] = root;
         if (val) atomicMax(&YMg[root], y);
         int xe = run_end(row, xs, val, w);
         bool flag;
@@ -217,43 +287,42 @@ k_runs_flatten(const u64 *bits, int val, const u64 *mark, int *L, int *YM, int *
 
 // last row of every hole (0-component that does not touch the frame); runs after k_runs_flatten
 __global__ void __launch_bounds__(256)
-k_bg_extent(const u64 *bits, const int *L, int *YM, const int *FL, int h, int w, const int *wlist,
-            const int *counters, int cidx, const int *active) {
+k_bg_extent(const u64 *bits, const int *scan, const int *L, int *YM, const int *FL, int h, int w, int run_cap,
+            const int *wlist, const int *counters, int cidx, const int *active) {
     LFD_WORDLIST_LOOP(cidx) {
     int idx = wl_[it_];
     int y = idx / wq, q = idx - y * wq;
     const u64 *row = bits + (size_t)g * h * wq + (size_t)y * wq;
-    u64 s = start_bits(row, q, 0, w);
-    size_t N = (size_t)h * w;
-    while (s) {
-        int b = __ffsll((long long)s) - 1;
-        s &= s - 1;
-        int root = L[g * N + y * w + (q << 6) + b];
-        if (!FL[g * N + root]) atomicMax(&YM[g * N + root], y);
+    int n = __popcll(start_bits(row, q, 0, w));
+    int id0 = scan[(size_t)g * h * wq + idx];
+    size_t o = (size_t)g * run_cap;
+    for (int k = 0; k < n && id0 + k < run_cap; k++) {
+        int root = L[o + id0 + k];
+        if (!FL[o + root]) atomicMax(&YM[o + root], y);
     }
     }
 }
 
 // hysteresis result: edge = candidate runs whose component holds a strong pixel
+// (words without candidates are zero in `edge`: cleared by the caller)
 __global__ void __launch_bounds__(256)
-k_edge_from_cand(const u64 *cand, const int *L, const int *FL, u64 *edge, int h, int w,
+k_edge_from_cand(const u64 *cand, const int *scan, const int *L, const int *FL, u64 *edge, int h, int w, int run_cap,
                  const int *wlist, const int *counters, int cidx, const int *active) {
-    // words without candidates are zero in `edge` (cleared by the caller)
     LFD_WORDLIST_LOOP(cidx) {
     int idx = wl_[it_];
     int y = idx / wq, q = idx - y * wq;
-    const u64 *row = cand + (size_t)g * h * wq + (size_t)y * wq;
-    size_t N = (size_t)h * w;
-    const int *Lg = L + g * N, *FLg = FL + g * N;
+    const u64 *fb = cand + (size_t)g * h * wq;
+    const u64 *row = fb + (size_t)y * wq;
+    const int *sf = scan + (size_t)g * h * wq;
+    size_t o = (size_t)g * run_cap;
     u64 c = row[q], rem = c, res = 0;
     while (rem) {
         int b = __ffsll((long long)rem) - 1;
         u64 inv = ~(c >> b);
         int len = inv ? (__ffsll((long long)inv) - 1) : (64 - b);
         u64 seg = (len >= 64 ? ~0ull : ((1ull << len) - 1)) << b;
-        int start = (b == 0) ? run_start(row, q << 6, 1) : ((q << 6) + b);
-        int root = Lg[y * w + start];
-        if (FLg[root]) res |= seg;
+        int id = run_id(sf, fb, y, (q << 6) + b, 1, wq, w);
+        if (id >= 0 && id < run_cap && FL[o + L[o + id]]) res |= seg;
         rem &= ~seg;
     }
     edge[(size_t)g * h * wq + (size_t)y * wq + q] = res;

@@ -14,57 +14,67 @@
 #define KEY_HOLE_BIT (1 << 30)
 #define BIG_KEY_ROWS 48 // keys with more rows than this get a whole wave (k_rects_big)
 
+// Run tables of one frame slot (compact ids, see k_ccl.h)
+struct RunTabs {
+    const u64 *cand, *edge;          // bit rows (edge runs are candidate runs: fg ids come from cand)
+    const int *scanf, *scanb;        // per-word exclusive run counts
+    int *Lf, *YMf, *SBf, *ROWf;      // edge-run labels, last row / slot base per root, row per run
+    int *Lb, *YMb, *FLb, *SBb, *PAb, *ROWb; // background runs: label, last row, outside flag, slot base, parent, row
+    int run_cap;
+};
+
 __global__ void __launch_bounds__(256)
-k_keys(const u64 *edge, const int *Lf, const int *YMf, const int *Lb, const int *YMb,
-       const int *FLb, int *SBf, int *SBb, int *PAb, int4 *keys, int *bigkeys, int2 *rowext,
-       int *counters, int h, int w, int key_cap, int slot_cap, const int *wlist_fg, const int *wlist_bg,
-       const int *active) {
+k_keys(RunTabs t, int4 *keys, int *bigkeys, int2 *rowext, int *counters, int h, int w, int key_cap, int slot_cap,
+       const int *wlist_fg, const int *wlist_bg, const int *active) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     int wq = LFD_WQ(w);
-    size_t N = (size_t)h * w;
+    size_t fo = (size_t)g * h * wq, ro = (size_t)g * t.run_cap;
     int *cnt = counters + g * C_COUNT;
     int4 *kg = keys + (size_t)g * key_cap;
     int2 *re = rowext + (size_t)g * slot_cap;
     // edge components come from the candidate-word list, holes from the background-word list
     for (int val = 1; val >= 0; val--) {
         const int nwork = cnt[val ? C_NFGW : C_NBGW];
-        const int *wl = (val ? wlist_fg : wlist_bg) + (size_t)g * h * wq;
+        const int *wl = (val ? wlist_fg : wlist_bg) + fo;
         for (int it = blockIdx.x * 256 + threadIdx.x; it < nwork; it += gridDim.x * 256) {
-        int idx = wl[it];
-        int y = idx / wq, q = idx - y * wq;
-        const u64 *row = edge + (size_t)g * h * wq + (size_t)y * wq;
-        u64 s = start_bits(row, q, val, w);
-        while (s) {
-            int b = __ffsll((long long)s) - 1;
-            s &= s - 1;
-            int x = (q << 6) + b;
-            int p = y * w + x;
-            int ymin, extent, parent = -1;
-            if (val) {
-                if (Lf[g * N + p] != p) continue;
-                ymin = y;
-                extent = YMf[g * N + p] - y + 1;
-            } else {
-                if (Lb[g * N + p] != p || FLb[g * N + p]) continue;
-                // hole: border rows run from the row above its first pixel to the row below its last
-                ymin = y - 1;
-                extent = YMb[g * N + p] - y + 3;
-                parent = Lf[g * N + (size_t)(y - 1) * w + run_start(row - wq, x, 1)];
+            int idx = wl[it];
+            int y = idx / wq, q = idx - y * wq;
+            const u64 *row = t.edge + fo + (size_t)y * wq;
+            u64 s = start_bits(row, q, val, w);
+            // edge runs are numbered among the candidate runs; background runs have their own scan
+            int bid = val ? 0 : t.scanb[fo + idx];
+            for (; s; bid++) {
+                int b = __ffsll((long long)s) - 1;
+                s &= s - 1;
+                int x = (q << 6) + b;
+                int id, ymin, extent, parent = -1;
+                if (val) {
+                    id = run_id(t.scanf + fo, t.cand + fo, y, x, 1, wq, w);
+                    if (id < 0 || id >= t.run_cap || t.Lf[ro + id] != id) continue;
+                    ymin = y;
+                    extent = t.YMf[ro + id] - y + 1;
+                } else {
+                    id = bid;
+                    if (id >= t.run_cap || t.Lb[ro + id] != id || t.FLb[ro + id]) continue;
+                    // hole: border rows run from the row above its first pixel to the row below its last
+                    ymin = y - 1;
+                    extent = t.YMb[ro + id] - y + 3;
+                    parent = t.Lf[ro + run_id(t.scanf + fo, t.cand + fo, y - 1, x, 1, wq, w)];
+                }
+                int base = atomicAdd(&cnt[C_NSLOTS], extent);
+                int ki = atomicAdd(&cnt[C_NKEYS], 1);
+                if (base + extent > slot_cap || ki >= key_cap) {
+                    cnt[C_OVERFLOW] = 1;
+                    if (val) t.SBf[ro + id] = -1; else t.SBb[ro + id] = -1;
+                    continue;
+                }
+                if (val) t.SBf[ro + id] = base;
+                else { t.SBb[ro + id] = base; t.PAb[ro + id] = parent; }
+                kg[ki] = make_int4(id, extent | (val ? 0 : KEY_HOLE_BIT), ymin, base);
+                if (extent > BIG_KEY_ROWS) bigkeys[(size_t)g * key_cap + atomicAdd(&cnt[C_NBIG], 1)] = ki;
+                for (int r = 0; r < extent; r++) re[base + r] = make_int2(0x7fffffff, -1);
             }
-            int base = atomicAdd(&cnt[C_NSLOTS], extent);
-            int ki = atomicAdd(&cnt[C_NKEYS], 1);
-            if (base + extent > slot_cap || ki >= key_cap) {
-                cnt[C_OVERFLOW] = 1;
-                if (val) SBf[g * N + p] = -1; else SBb[g * N + p] = -1;
-                continue;
-            }
-            if (val) SBf[g * N + p] = base;
-            else { SBb[g * N + p] = base; PAb[g * N + p] = parent; }
-            kg[ki] = make_int4(p, extent | (val ? 0 : KEY_HOLE_BIT), ymin, base);
-            if (extent > BIG_KEY_ROWS) bigkeys[(size_t)g * key_cap + atomicAdd(&cnt[C_NBIG], 1)] = ki;
-            for (int r = 0; r < extent; r++) re[base + r] = make_int2(0x7fffffff, -1);
-        }
         }
     }
 }
@@ -77,39 +87,41 @@ __device__ __forceinline__ void slot_update(int2 *re, int slot, int xa, int xb) 
 // Every edge run contributes to the outer-border key of its component, and to the hole-border
 // key of every hole it is 4-adjacent to (if its component is that hole's surrounding one).
 __global__ void __launch_bounds__(256)
-k_extremes(const u64 *edge, const int *Lf, const int *Lb, const int *FLb, const int *SBf,
-           const int *SBb, const int *PAb, int2 *rowext, int h, int w, int slot_cap,
-           const int *wlist, const int *counters, const int *active) {
+k_extremes(RunTabs t, int2 *rowext, int h, int w, int slot_cap, const int *wlist, const int *counters,
+           const int *active) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     int wq = LFD_WQ(w);
+    size_t fo = (size_t)g * h * wq, ro = (size_t)g * t.run_cap;
     const int nwork = counters[g * C_COUNT + C_NFGW];
-    const int *wl = wlist + (size_t)g * h * wq;
+    const int *wl = wlist + fo;
+    const u64 *eb = t.edge + fo;
+    const int *sb = t.scanb + fo;
+    const int *Lbg = t.Lb + ro, *FLbg = t.FLb + ro, *SBbg = t.SBb + ro, *PAbg = t.PAb + ro, *ROWbg = t.ROWb + ro;
+    int2 *re = rowext + (size_t)g * slot_cap;
     for (int it = blockIdx.x * 256 + threadIdx.x; it < nwork; it += gridDim.x * 256) {
     int idx = wl[it];
     int y = idx / wq, q = idx - y * wq;
-    const u64 *row = edge + (size_t)g * h * wq + (size_t)y * wq;
-    size_t N = (size_t)h * w;
-    const int *Lfg = Lf + g * N, *Lbg = Lb + g * N, *FLbg = FLb + g * N, *SBfg = SBf + g * N,
-              *SBbg = SBb + g * N, *PAbg = PAb + g * N;
-    int2 *re = rowext + (size_t)g * slot_cap;
+    const u64 *row = eb + (size_t)y * wq;
     u64 s = start_bits(row, q, 1, w);
     while (s) {
         int b = __ffsll((long long)s) - 1;
         s &= s - 1;
         int xs = (q << 6) + b;
         int xe = run_end(row, xs, 1, w);
-        int A = Lfg[y * w + xs];
-        int baseA = SBfg[A];
-        if (baseA >= 0) slot_update(re, baseA + (y - A / w), xs, xe);
+        int fid = run_id(t.scanf + fo, t.cand + fo, y, xs, 1, wq, w);
+        if (fid < 0 || fid >= t.run_cap) continue;
+        int A = t.Lf[ro + fid];
+        int baseA = t.SBf[ro + A];
+        if (baseA >= 0) slot_update(re, baseA + (y - t.ROWf[ro + A]), xs, xe);
         // same-row neighbours
         if (xs > 0) {
-            int B = Lbg[y * w + run_start(row, xs - 1, 0)];
-            if (!FLbg[B] && PAbg[B] == A && SBbg[B] >= 0) slot_update(re, SBbg[B] + (y - (B / w - 1)), xs, xs);
+            int B = Lbg[run_id(sb, eb, y, xs - 1, 0, wq, w)];
+            if (!FLbg[B] && PAbg[B] == A && SBbg[B] >= 0) slot_update(re, SBbg[B] + (y - (ROWbg[B] - 1)), xs, xs);
         }
         if (xe < w - 1) {
-            int B = Lbg[y * w + xe + 1];
-            if (!FLbg[B] && PAbg[B] == A && SBbg[B] >= 0) slot_update(re, SBbg[B] + (y - (B / w - 1)), xe, xe);
+            int B = Lbg[run_id(sb, eb, y, xe + 1, 0, wq, w)];
+            if (!FLbg[B] && PAbg[B] == A && SBbg[B] >= 0) slot_update(re, SBbg[B] + (y - (ROWbg[B] - 1)), xe, xe);
         }
         // rows above and below: 0-runs overlapping [xs, xe]
         for (int dy = -1; dy <= 1; dy += 2) {
@@ -120,11 +132,10 @@ k_extremes(const u64 *edge, const int *Lf, const int *Lb, const int *FLb, const 
             while (x <= xe) {
                 if (get_bit(orow, x)) { x = run_end(orow, x, 1, w) + 1; continue; }
                 int ge = run_end(orow, x, 0, w);
-                int gs0 = run_start(orow, x, 0);
                 if (ge > xe) ge = xe;
-                int B = Lbg[yy * w + gs0];
+                int B = Lbg[run_id(sb, eb, yy, x, 0, wq, w)];
                 if (!FLbg[B] && PAbg[B] == A && SBbg[B] >= 0)
-                    slot_update(re, SBbg[B] + (y - (B / w - 1)), x, ge);
+                    slot_update(re, SBbg[B] + (y - (ROWbg[B] - 1)), x, ge);
                 x = ge + 1;
             }
         }

@@ -48,8 +48,11 @@ struct lfdmi_ctx {
     int *hist = nullptr;
     u64 *candb = nullptr, *strongb = nullptr, *edgeb = nullptr, *equb = nullptr, *boxb = nullptr;
     // run labels (indexed by pixel index of a run start)
+    // run tables (compact run ids, run_cap entries per slot) and per-word run-count scans
     int *Lf = nullptr, *YMf = nullptr, *FLf = nullptr, *Lb = nullptr, *YMb = nullptr, *FLb = nullptr;
-    int *SBf = nullptr, *SBb = nullptr, *PAb = nullptr;
+    int *SBf = nullptr, *SBb = nullptr, *PAb = nullptr, *ROWf = nullptr, *ROWb = nullptr;
+    int *scanf_ = nullptr, *scanb_ = nullptr;
+    int run_cap = 0;
     int4 *keys = nullptr;
     int *bigkeys = nullptr;
     int *wl_fg = nullptr, *wl_bg = nullptr; // work lists of active bit-row words
@@ -188,8 +191,12 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     RET(dmalloc(ctx, &ctx->edgeb, G * BW));
     RET(dmalloc(ctx, &ctx->equb, G * BW));
     RET(dmalloc(ctx, &ctx->boxb, G * BW));
-    for (int **p : {&ctx->Lf, &ctx->YMf, &ctx->FLf, &ctx->Lb, &ctx->YMb, &ctx->FLb, &ctx->SBf, &ctx->SBb, &ctx->PAb})
-        RET(dmalloc(ctx, p, G * N));
+    ctx->run_cap = max_h * (max_w / 2 + 1) + 16; // most runs a bit image can hold
+    for (int **p : {&ctx->Lf, &ctx->YMf, &ctx->FLf, &ctx->Lb, &ctx->YMb, &ctx->FLb, &ctx->SBf, &ctx->SBb, &ctx->PAb,
+                    &ctx->ROWf, &ctx->ROWb})
+        RET(dmalloc(ctx, p, G * ctx->run_cap));
+    RET(dmalloc(ctx, &ctx->scanf_, G * BW));
+    RET(dmalloc(ctx, &ctx->scanb_, G * BW));
     RET(dmalloc(ctx, &ctx->keys, G * ctx->key_cap));
     RET(dmalloc(ctx, &ctx->bigkeys, G * ctx->key_cap));
     RET(dmalloc(ctx, &ctx->wl_fg, G * BW));
@@ -268,7 +275,8 @@ extern "C" const char *lfdmi_timing_name(int i) { return (i >= 0 && i < TG_COUNT
 static int check_shape(lfdmi_ctx *ctx, int n, int h, int w) {
     if (!ctx) return LFDMI_ERR_ARG;
     if (n < 0 || h <= 0 || w <= 0) return fail(ctx, LFDMI_ERR_ARG, "bad shape");
-    if ((size_t)h * w > ctx->N || h > 65535 || w > 65535 || LFD_WQ(w) * (size_t)h > (size_t)ctx->wq * ctx->H)
+    if ((size_t)h * w > ctx->N || h > 65535 || w > 65535 || LFD_WQ(w) * (size_t)h > (size_t)ctx->wq * ctx->H ||
+        (LFD_WQ(w) * (size_t)h + 63) / 64 > SCAN_MAX_SEG)
         return fail(ctx, LFDMI_ERR_CAPACITY, "frame larger than the context was created for");
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, LFDMI_ERR_HIP, "hipSetDevice");
     (void)hipGetLastError(); // a failed earlier call must not poison this one
@@ -382,19 +390,25 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
     dim3 lg(WORDLIST_BLOCKS, nc);
     size_t BW = (size_t)h * LFD_WQ(w);
     HIPCHK(hipMemsetAsync(ctx->edgeb, 0, (size_t)nc * BW * sizeof(u64), ctx->stream));
+    int rc = ctx->run_cap;
     { Span sp(ctx, KID_RUNS_INIT_FG);
       k_collect_words<<<wg, 256, 0, ctx->stream>>>(ctx->candb, ctx->wl_fg, ctx->wl_bg, ctx->counters, h, w, active);
       KCHK("k_collect_words");
-      k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->Lf, ctx->YMf, ctx->FLf, h, w, ctx->wl_fg, ctx->counters, C_NFGW, active);
+      k_scan_runs<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->candb, 1, ctx->scanf_, ctx->counters, C_NRUNF, h, w, rc, active);
+      KCHK("k_scan_runs(fg)");
+      k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->scanf_, ctx->Lf, ctx->YMf, ctx->FLf, ctx->ROWf, h, w, rc,
+                                               ctx->wl_fg, ctx->counters, C_NFGW, active);
       KCHK("k_runs_init"); }
     { Span sp(ctx, KID_RUNS_MERGE8);
-      k_runs_merge8<<<lg, 256, 0, ctx->stream>>>(ctx->candb, ctx->Lf, h, w, ctx->wl_fg, ctx->counters, C_NFGW, active);
+      k_runs_merge8<<<lg, 256, 0, ctx->stream>>>(ctx->candb, ctx->scanf_, ctx->Lf, h, w, rc, ctx->wl_fg, ctx->counters, C_NFGW, active);
       KCHK("k_runs_merge8"); }
     { Span sp(ctx, KID_RUNS_FLATTEN_FG);
-      k_runs_flatten<<<lg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->strongb, ctx->Lf, ctx->YMf, ctx->FLf, h, w, ctx->wl_fg, ctx->counters, C_NFGW, active);
+      k_runs_flatten<<<lg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->strongb, ctx->scanf_, ctx->Lf, ctx->YMf, ctx->FLf, h, w, rc,
+                                                  ctx->wl_fg, ctx->counters, C_NFGW, active);
       KCHK("k_runs_flatten"); }
     { Span sp(ctx, KID_EDGE);
-      k_edge_from_cand<<<lg, 256, 0, ctx->stream>>>(ctx->candb, ctx->Lf, ctx->FLf, ctx->edgeb, h, w, ctx->wl_fg, ctx->counters, C_NFGW, active);
+      k_edge_from_cand<<<lg, 256, 0, ctx->stream>>>(ctx->candb, ctx->scanf_, ctx->Lf, ctx->FLf, ctx->edgeb, h, w, rc, ctx->wl_fg,
+                                                    ctx->counters, C_NFGW, active);
       KCHK("k_edge_from_cand"); }
     return 0;
 }
@@ -412,26 +426,35 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
         return fail(ctx, LFDMI_ERR_UNSUPPORTED, "contoursMode: only RETR_LIST / RETR_CCOMP / RETR_TREE");
     size_t BW = (size_t)h * LFD_WQ(w);
     dim3 lg(WORDLIST_BLOCKS, nc);
+    int rc = ctx->run_cap;
     { Span sp(ctx, KID_RUNS_INIT_BG);
-      k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->Lb, ctx->YMb, ctx->FLb, h, w, ctx->wl_bg, ctx->counters, C_NBGW, active);
+      k_scan_runs<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->scanb_, ctx->counters, C_NRUNB, h, w, rc, active);
+      KCHK("k_scan_runs(bg)");
+      k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->scanb_, ctx->Lb, ctx->YMb, ctx->FLb, ctx->ROWb, h, w, rc,
+                                               ctx->wl_bg, ctx->counters, C_NBGW, active);
       KCHK("k_runs_init(bg)"); }
     { Span sp(ctx, KID_RUNS_MERGE4);
-      k_runs_merge4_bg<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lb, h, w, ctx->wl_bg, ctx->counters, C_NBGW, active);
+      k_runs_merge4_bg<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->scanb_, ctx->Lb, h, w, rc, ctx->wl_bg, ctx->counters, C_NBGW, active);
       KCHK("k_runs_merge4_bg"); }
     { Span sp(ctx, KID_RUNS_FLATTEN_BG);
-      k_runs_flatten<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, nullptr, ctx->Lb, ctx->YMb, ctx->FLb, h, w, ctx->wl_bg, ctx->counters, C_NBGW, active);
+      k_runs_flatten<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, nullptr, ctx->scanb_, ctx->Lb, ctx->YMb, ctx->FLb, h, w, rc,
+                                                  ctx->wl_bg, ctx->counters, C_NBGW, active);
       KCHK("k_runs_flatten(bg)");
-      k_bg_extent<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lb, ctx->YMb, ctx->FLb, h, w, ctx->wl_bg, ctx->counters, C_NBGW, active);
+      k_bg_extent<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->scanb_, ctx->Lb, ctx->YMb, ctx->FLb, h, w, rc, ctx->wl_bg,
+                                               ctx->counters, C_NBGW, active);
       KCHK("k_bg_extent"); }
     HIPCHK(hipMemsetAsync(ctx->boxb, 0, (size_t)nc * BW * sizeof(u64), ctx->stream));
+    RunTabs rt;
+    rt.cand = ctx->candb; rt.edge = ctx->edgeb; rt.scanf = ctx->scanf_; rt.scanb = ctx->scanb_;
+    rt.Lf = ctx->Lf; rt.YMf = ctx->YMf; rt.SBf = ctx->SBf; rt.ROWf = ctx->ROWf;
+    rt.Lb = ctx->Lb; rt.YMb = ctx->YMb; rt.FLb = ctx->FLb; rt.SBb = ctx->SBb; rt.PAb = ctx->PAb; rt.ROWb = ctx->ROWb;
+    rt.run_cap = rc;
     { Span sp(ctx, KID_KEYS);
-    k_keys<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lf, ctx->YMf, ctx->Lb, ctx->YMb, ctx->FLb, ctx->SBf, ctx->SBb,
-                                         ctx->PAb, ctx->keys, ctx->bigkeys, ctx->rowext, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap,
+    k_keys<<<lg, 256, 0, ctx->stream>>>(rt, ctx->keys, ctx->bigkeys, ctx->rowext, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap,
                                          ctx->wl_fg, ctx->wl_bg, active);
     KCHK("k_keys"); }
     { Span sp(ctx, KID_EXTREMES);
-    k_extremes<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->Lf, ctx->Lb, ctx->FLb, ctx->SBf, ctx->SBb, ctx->PAb, ctx->rowext,
-                                             h, w, ctx->slot_cap, ctx->wl_fg, ctx->counters, active);
+    k_extremes<<<lg, 256, 0, ctx->stream>>>(rt, ctx->rowext, h, w, ctx->slot_cap, ctx->wl_fg, ctx->counters, active);
     KCHK("k_extremes"); }
     { Span sp(ctx, KID_RECTS);
     k_rects<<<dim3(256, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, ctx->hullbuf, ctx->quads, ctx->counters, h, w,
