@@ -38,43 +38,12 @@ __device__ __forceinline__ u64 start_bits(const u64 *row, int wq, int val, int W
     return c & ~((c << 1) | prev_msb);
 }
 
-// One pass over the candidate bit rows builds both work lists of a frame:
+// The candidate-pass scan (k_scan_runs below) also builds both work lists of a frame:
 //   fg: words holding candidate bits (edge runs are a subset of candidate runs);
 //   bg: words where a 0-run of the edge image can start or a vertical 0-0 contact stretch can
 //       begin -- an edge bit in this word or at the end of the previous word, in this row or the
 //       row above -- or the first word of a row.  Candidate bits are a superset of edge bits, so
 //       testing them gives a (harmless) superset of the words the hole kernels need.
-__global__ void __launch_bounds__(256)
-k_collect_words(const u64 *cand, int *wl_fg, int *wl_bg, int *counters, int h, int w, const int *active) {
-    int g = blockIdx.y;
-    if (active && !active[g]) return;
-    int wq = LFD_WQ(w);
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    bool tf = false, tb = false;
-    if (idx < h * wq) {
-        const u64 *b = cand + (size_t)g * h * wq;
-        int y = idx / wq, q = idx - y * wq;
-        u64 m = b[idx];
-        tf = m != 0;
-        if (q > 0) m |= b[idx - 1] >> 63;
-        if (y > 0) { m |= b[idx - wq]; if (q > 0) m |= b[idx - wq - 1] >> 63; }
-        tb = (m != 0) || (q == 0);
-    }
-    int lane = lfd_lane();
-    u64 bf = __ballot(tf), bb = __ballot(tb);
-    int basef = 0, baseb = 0;
-    if (lane == 0) {
-        if (bf) basef = atomicAdd(&counters[g * C_COUNT + C_NFGW], __popcll(bf));
-        if (bb) baseb = atomicAdd(&counters[g * C_COUNT + C_NBGW], __popcll(bb));
-    }
-    basef = __shfl(basef, 0);
-    baseb = __shfl(baseb, 0);
-    u64 lt = (1ull << lane) - 1ull;
-    if (tf) wl_fg[(size_t)g * h * wq + basef + __popcll(bf & lt)] = idx;
-    if (tb) wl_bg[(size_t)g * h * wq + baseb + __popcll(bb & lt)] = idx;
-}
-
-
 // every run kernel walks its frame's work list with a fixed grid
 #define LFD_WORDLIST_LOOP(cidx_)                                                          \
     int g = blockIdx.y;                                                                   \
@@ -93,7 +62,8 @@ k_collect_words(const u64 *cand, int *wl_fg, int *wl_bg, int *counters, int h, i
 // in LDS, then a wave-level scan inside each segment.
 #define SCAN_MAX_SEG 4096
 __global__ void __launch_bounds__(SCAN_THREADS)
-k_scan_runs(const u64 *bits, int val, int *scan, int *counters, int cidx, int h, int w, int run_cap, const int *active) {
+k_scan_runs(const u64 *bits, int val, int *scan, int *counters, int cidx, int h, int w, int run_cap, int *wl_fg, int *wl_bg,
+            const int *active) {
     int g = blockIdx.x;
     if (active && !active[g]) return;
     const int wq = LFD_WQ(w), nw = h * wq;
@@ -101,10 +71,37 @@ k_scan_runs(const u64 *bits, int val, int *scan, int *counters, int cidx, int h,
     const u64 *b = bits + (size_t)g * nw;
     int *sc = scan + (size_t)g * nw;
     __shared__ int segtot[SCAN_MAX_SEG];
+    __shared__ int nfg, nbg;
+    if (threadIdx.x == 0) { nfg = 0; nbg = 0; }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = SCAN_THREADS / 64;
+    const u64 lt = (1ull << lane) - 1ull;
     for (int seg = wv; seg < nseg; seg += nwv) {
         int i = (seg << 6) + lane, c = 0;
-        if (i < nw) { int y = i / wq; c = __popcll(start_bits(b + (size_t)y * wq, i - y * wq, val, w)); }
+        bool tf = false, tb = false;
+        if (i < nw) {
+            int y = i / wq, q = i - y * wq;
+            c = __popcll(start_bits(b + (size_t)y * wq, q, val, w));
+            if (wl_fg) { // work lists of the frame (candidate pass only), see the comment above
+                u64 m = b[i];
+                tf = m != 0;
+                if (q > 0) m |= b[i - 1] >> 63;
+                if (y > 0) { m |= b[i - wq]; if (q > 0) m |= b[i - wq - 1] >> 63; }
+                tb = (m != 0) || (q == 0);
+            }
+        }
+        if (wl_fg) {
+            u64 bf = __ballot(tf), bb = __ballot(tb);
+            int basef = 0, baseb = 0;
+            if (lane == 0) {
+                if (bf) basef = atomicAdd(&nfg, __popcll(bf));
+                if (bb) baseb = atomicAdd(&nbg, __popcll(bb));
+            }
+            basef = __shfl(basef, 0);
+            baseb = __shfl(baseb, 0);
+            if (tf) wl_fg[(size_t)g * nw + basef + __popcll(bf & lt)] = i;
+            if (tb) wl_bg[(size_t)g * nw + baseb + __popcll(bb & lt)] = i;
+        }
         for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
         if (lane == 0) segtot[seg] = c;
     }
@@ -138,6 +135,7 @@ k_scan_runs(const u64 *bits, int val, int *scan, int *counters, int cidx, int h,
     if (threadIdx.x == SCAN_THREADS - 1) {
         counters[g * C_COUNT + cidx] = part[threadIdx.x];
         if (part[threadIdx.x] > run_cap) counters[g * C_COUNT + C_OVERFLOW] = 1;
+        if (wl_fg) { counters[g * C_COUNT + C_NFGW] = nfg; counters[g * C_COUNT + C_NBGW] = nbg; }
     }
 }
 

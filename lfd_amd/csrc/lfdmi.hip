@@ -386,15 +386,13 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
         else k_canny_nms<<<grid, 256, 0, ctx->stream>>>(img, ctx->candb, ctx->strongb, h, w, low, high, active);
         KCHK("k_canny_nms");
     }
-    dim3 wg = word_grid(h, w, nc);
     dim3 lg(WORDLIST_BLOCKS, nc);
     size_t BW = (size_t)h * LFD_WQ(w);
     HIPCHK(hipMemsetAsync(ctx->edgeb, 0, (size_t)nc * BW * sizeof(u64), ctx->stream));
     int rc = ctx->run_cap;
     { Span sp(ctx, KID_RUNS_INIT_FG);
-      k_collect_words<<<wg, 256, 0, ctx->stream>>>(ctx->candb, ctx->wl_fg, ctx->wl_bg, ctx->counters, h, w, active);
-      KCHK("k_collect_words");
-      k_scan_runs<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->candb, 1, ctx->scanf_, ctx->counters, C_NRUNF, h, w, rc, active);
+      k_scan_runs<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->candb, 1, ctx->scanf_, ctx->counters, C_NRUNF, h, w, rc, ctx->wl_fg,
+                                                        ctx->wl_bg, active);
       KCHK("k_scan_runs(fg)");
       k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->scanf_, ctx->Lf, ctx->YMf, ctx->FLf, ctx->ROWf, h, w, rc,
                                                ctx->wl_fg, ctx->counters, C_NFGW, active);
@@ -428,7 +426,8 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     dim3 lg(WORDLIST_BLOCKS, nc);
     int rc = ctx->run_cap;
     { Span sp(ctx, KID_RUNS_INIT_BG);
-      k_scan_runs<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->scanb_, ctx->counters, C_NRUNB, h, w, rc, active);
+      k_scan_runs<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->scanb_, ctx->counters, C_NRUNB, h, w, rc, nullptr, nullptr,
+                                                        active);
       KCHK("k_scan_runs(bg)");
       k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->scanb_, ctx->Lb, ctx->YMb, ctx->FLb, ctx->ROWb, h, w, rc,
                                                ctx->wl_bg, ctx->counters, C_NBGW, active);
