@@ -63,7 +63,7 @@ __device__ __forceinline__ u64 start_bits(const u64 *row, int wq, int val, int W
 #define SCAN_MAX_SEG 4096
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_scan_runs(const u64 *bits, int val, int *scan, int *counters, int cidx, int h, int w, int run_cap, int *wl_fg, int *wl_bg,
-            const int *active) {
+            u64 *clear, const int *active) {
     int g = blockIdx.x;
     if (active && !active[g]) return;
     const int wq = LFD_WQ(w), nw = h * wq;
@@ -130,7 +130,12 @@ k_scan_runs(const u64 *bits, int val, int *scan, int *counters, int cidx, int h,
             int t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
-        if (i < nw) sc[i] = segtot[seg] + incl - c;
+        if (i < nw) {
+            sc[i] = segtot[seg] + incl - c;
+            // this pass touches every word anyway: clear the bit image a later kernel fills sparsely
+            // (hipMemsetAsync's fill kernel manages only ~350 GB/s)
+            if (clear) clear[(size_t)g * nw + i] = 0ull;
+        }
     }
     if (threadIdx.x == SCAN_THREADS - 1) {
         counters[g * C_COUNT + cidx] = part[threadIdx.x];

@@ -7,6 +7,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -387,12 +388,10 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
         KCHK("k_canny_nms");
     }
     dim3 lg(WORDLIST_BLOCKS, nc);
-    size_t BW = (size_t)h * LFD_WQ(w);
-    HIPCHK(hipMemsetAsync(ctx->edgeb, 0, (size_t)nc * BW * sizeof(u64), ctx->stream));
     int rc = ctx->run_cap;
     { Span sp(ctx, KID_RUNS_INIT_FG);
       k_scan_runs<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->candb, 1, ctx->scanf_, ctx->counters, C_NRUNF, h, w, rc, ctx->wl_fg,
-                                                        ctx->wl_bg, active);
+                                                        ctx->wl_bg, ctx->edgeb, active);
       KCHK("k_scan_runs(fg)");
       k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->scanf_, ctx->Lf, ctx->YMf, ctx->FLf, ctx->ROWf, h, w, rc,
                                                ctx->wl_fg, ctx->counters, C_NFGW, active);
@@ -422,12 +421,11 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
         return fail(ctx, LFDMI_ERR_UNSUPPORTED, "contoursMethod: only CHAIN_APPROX_NONE / CHAIN_APPROX_SIMPLE");
     if (mode != LFDMI_RETR_LIST && mode != LFDMI_RETR_CCOMP && mode != LFDMI_RETR_TREE)
         return fail(ctx, LFDMI_ERR_UNSUPPORTED, "contoursMode: only RETR_LIST / RETR_CCOMP / RETR_TREE");
-    size_t BW = (size_t)h * LFD_WQ(w);
     dim3 lg(WORDLIST_BLOCKS, nc);
     int rc = ctx->run_cap;
     { Span sp(ctx, KID_RUNS_INIT_BG);
       k_scan_runs<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->scanb_, ctx->counters, C_NRUNB, h, w, rc, nullptr, nullptr,
-                                                        active);
+                                                        ctx->boxb, active);
       KCHK("k_scan_runs(bg)");
       k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->scanb_, ctx->Lb, ctx->YMb, ctx->FLb, ctx->ROWb, h, w, rc,
                                                ctx->wl_bg, ctx->counters, C_NBGW, active);
@@ -442,7 +440,6 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
       k_bg_extent<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->scanb_, ctx->Lb, ctx->YMb, ctx->FLb, h, w, rc, ctx->wl_bg,
                                                ctx->counters, C_NBGW, active);
       KCHK("k_bg_extent"); }
-    HIPCHK(hipMemsetAsync(ctx->boxb, 0, (size_t)nc * BW * sizeof(u64), ctx->stream));
     RunTabs rt;
     rt.cand = ctx->candb; rt.edge = ctx->edgeb; rt.scanf = ctx->scanf_; rt.scanb = ctx->scanb_;
     rt.Lf = ctx->Lf; rt.YMf = ctx->YMf; rt.SBf = ctx->SBf; rt.ROWf = ctx->ROWf;
@@ -517,7 +514,7 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         } }
         // cut each pixel list into pieces so that a launch carries >= ~3 workgroups per CU
         int nsplit = 1;
-        while (nsplit < 8 && nslabs * n_img * nc * nsplit < 3072) nsplit <<= 1;
+        while (nsplit < 8 && nslabs * n_img * nc * nsplit < 1536) nsplit <<= 1; // (the memset is slow: split only small launches)
         if (nsplit > 1)
             HIPCHK(hipMemsetAsync(ctx->accum, 0, (size_t)nc * 2 * ctx->acc_cap * sizeof(int), ctx->stream));
         Span sp(ctx, KID_VOTE, need_detect);
