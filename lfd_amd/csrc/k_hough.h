@@ -14,13 +14,17 @@
 // bit rows -> packed (y << 16 | x) list, order irrelevant (votes commute)
 __global__ void __launch_bounds__(256)
 k_pixlist(const u64 *bits, uint32_t *list, int *counters, int cidx, int h, int w, size_t list_cap,
-          const int *active, int need_detect) {
+          int *accum_clear, int acc_n, size_t acc_stride, const int *active, int need_detect) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     int *cnt = counters + g * C_COUNT;
     if (need_detect && !cnt[C_DETECT]) return;
     int wq = LFD_WQ(w);
     int idx = blockIdx.x * 256 + threadIdx.x;
+    // zero this image's vote accumulator on the way (needed when the vote kernel merges split
+    // lists with atomics; hipMemsetAsync's fill kernel is several times slower)
+    if (accum_clear)
+        for (int k = idx; k < acc_n; k += gridDim.x * 256) accum_clear[(size_t)g * 2 * acc_stride + k] = 0;
     u64 c = 0;
     int y = 0, q = 0;
     if (idx < h * wq) {

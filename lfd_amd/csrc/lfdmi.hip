@@ -505,18 +505,20 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
     int nslabs = (na + AW - 1) / AW;
     dim3 wg = word_grid(h, w, nc);
     {
+        // cut each pixel list into pieces so that a launch carries several workgroups per CU
+        int nsplit = 1;
+        while (nsplit < 4 && nslabs * n_img * nc * nsplit < 6144) nsplit <<= 1;
+        int acc_n = (na + 2) * (nr + 2);
         { Span sp(ctx, KID_PIXLIST, need_detect);
-        k_pixlist<<<wg, 256, 0, ctx->stream>>>(ctx->equb, ctx->pix_equ, ctx->counters, C_NPIX_EQU, h, w, ctx->list_cap, active, need_detect);
+        // per-slot accumulator pairs are 2 * acc_cap apart; the kernel indexes by slot itself
+        k_pixlist<<<wg, 256, 0, ctx->stream>>>(ctx->equb, ctx->pix_equ, ctx->counters, C_NPIX_EQU, h, w, ctx->list_cap,
+                                               nsplit > 1 ? ctx->accum : nullptr, acc_n, ctx->acc_cap, active, need_detect);
         KCHK("k_pixlist(equ)");
         if (n_img > 1) {
-            k_pixlist<<<wg, 256, 0, ctx->stream>>>(ctx->boxb, ctx->pix_box, ctx->counters, C_NPIX_BOX, h, w, ctx->list_cap, active, need_detect);
+            k_pixlist<<<wg, 256, 0, ctx->stream>>>(ctx->boxb, ctx->pix_box, ctx->counters, C_NPIX_BOX, h, w, ctx->list_cap,
+                                                   nsplit > 1 ? ctx->accum + ctx->acc_cap : nullptr, acc_n, ctx->acc_cap, active, need_detect);
             KCHK("k_pixlist(box)");
         } }
-        // cut each pixel list into pieces so that a launch carries >= ~3 workgroups per CU
-        int nsplit = 1;
-        while (nsplit < 8 && nslabs * n_img * nc * nsplit < 1536) nsplit <<= 1; // (the memset is slow: split only small launches)
-        if (nsplit > 1)
-            HIPCHK(hipMemsetAsync(ctx->accum, 0, (size_t)nc * 2 * ctx->acc_cap * sizeof(int), ctx->stream));
         Span sp(ctx, KID_VOTE, need_detect);
         dim3 vgrid(nslabs * nsplit, n_img, nc);
         size_t vlds = ((size_t)nr << aw_log2) * 4 + 256;
