@@ -41,6 +41,8 @@ STAGE_BYTES_PER_PX = {
     # HoughLines reads each of the two images once
     "k_pixlist": 2.0, "k_hough_vote": 2.0, "k_hough_peaks": 2.0, "k_hough_topk": 2.0, "k_hough_sort": 1.0,
     "k_finalize": 0.0, "misc": 0.0,
+    # fused dilate (2N) + Canny NMS (the Canny stage's 2N) tile kernel
+    "k_dilate_canny": 4.0,
 }
 
 
@@ -166,7 +168,8 @@ def main():
             c = tj["config"]
             if (c["frames_per_gpu"], c["inflight"], c["lanes"], c["shape"]) == (n, args.inflight, args.lanes, [h, w]):
                 key = {"k_morph(dilate)": "k_morph_rect_v<0>", "k_morph(erode)": "k_morph_rect_v<1>",
-                       "k_canny_nms": "k_canny_nms_v", "k_hough_vote": "k_hough_vote<6>"}.get(name, name.split("(")[0])
+                       "k_canny_nms": "k_canny_nms_v", "k_hough_vote": "k_hough_vote<6>",
+                       "k_dilate_canny": "k_dilate_canny_v"}.get(name, name.split("(")[0])
                 traffic = tj["kernels"][key]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None

@@ -469,51 +469,12 @@ k_u8_from_bits(const u64 *bits, uint8_t *dst, int h, int w) {
 #define CANNY_MOFF 12               // first staged column that gets a magnitude (tile column -4)
 #define CANNY_MW 72                 // magnitudes per row: tile columns -4 .. 67
 
-// Frames whose width is a multiple of 16: 16-byte tile loads, all-zero-tile exit before any LDS
-// traffic, Sobel/magnitude computed for four pixels per lane from dword LDS reads.
-__global__ void __launch_bounds__(256)
-k_canny_nms_v(const uint8_t *img, u64 *cand, u64 *strong, int h, int w, int low, int high,
-              const int *active) {
-    int g = blockIdx.z;
-    if (active && !active[g]) return;
-    const int PH = CANNY_TH + 4, PWB = CANNY_TW + 2 * CANNY_HALO, MH = CANNY_TH + 2;
-    __shared__ __attribute__((aligned(16))) uint8_t px[PH * PWB]; // rows y0-2 .. y0+TH+1, cols x0-16 .. x0+79
-    __shared__ __attribute__((aligned(16))) int mg[MH * CANNY_MW];
-    __shared__ __attribute__((aligned(16))) int dxy[MH * CANNY_MW];
-    __shared__ int rowflag[PH];
-    int x0 = blockIdx.x * CANNY_TW, y0 = blockIdx.y * CANNY_TH;
-    const uint8_t *s = img + (size_t)g * h * w;
-    if (threadIdx.x < PH) rowflag[threadIdx.x] = 0;
-    __syncthreads();
-    // one 16-byte piece per thread (36 rows x 6 pieces = 216), BORDER_REPLICATE by clamping
-    uint4 v = make_uint4(0, 0, 0, 0);
-    int ty = threadIdx.x / 6, wx = threadIdx.x - ty * 6;
-    bool mine = threadIdx.x < PH * 6;
-    if (mine) {
-        int gy = min(max(y0 - 2 + ty, 0), h - 1), gx = x0 - CANNY_HALO + 16 * wx;
-        if (gx >= 0 && gx < w) v = *(const uint4 *)(s + (size_t)gy * w + gx);
-        else {
-            uint32_t e = s[(size_t)gy * w + (gx < 0 ? 0 : w - 1)];
-            e |= e << 8; e |= e << 16;
-            v = make_uint4(e, e, e, e);
-        }
-    }
-    uint32_t nzv = v.x | v.y | v.z | v.w;
-    int wq = LFD_WQ(w);
-    // an all-zero tile (sky) has zero gradient everywhere: no candidate when low >= 0
-    if (!__syncthreads_or(nzv != 0) && low >= 0) {
-        if (threadIdx.x < CANNY_TH && y0 + threadIdx.x < h) {
-            size_t o = (size_t)g * h * wq + (size_t)(y0 + threadIdx.x) * wq + blockIdx.x;
-            cand[o] = 0ull;
-            strong[o] = 0ull;
-        }
-        return;
-    }
-    if (mine) {
-        ((uint4 *)px)[threadIdx.x] = v;
-        if (nzv) rowflag[ty] = 1;
-    }
-    __syncthreads();
+// Canny stages on a staged tile: px = 36 rows x 96 bytes (rows y0-2.., cols x0-16..), rowflag = row
+// holds a non-zero byte.  Sobel + L1 magnitude four pixels per lane, then NMS -> bit rows.
+__device__ __forceinline__ void canny_tile_stages(const uint8_t *px, const int *rowflag, int *mg, int *dxy, u64 *cand,
+                                                  u64 *strong, int g, int h, int w, int x0, int y0, int low, int high) {
+    const int PWB = CANNY_TW + 2 * CANNY_HALO, MH = CANNY_TH + 2;
+    const int wq = LFD_WQ(w);
     // Sobel + L1 magnitude, 4 pixels per lane: staged bytes 12..83 of rows 1..MH (tile cols -4..67)
     const uint32_t *pw = (const uint32_t *)px;
     for (int it = threadIdx.x; it < MH * (CANNY_MW / 4); it += 256) {
@@ -579,6 +540,189 @@ k_canny_nms_v(const uint8_t *img, u64 *cand, u64 *strong, int h, int w, int low,
             strong[o] = bs;
         }
     }
+}
+
+// Frames whose width is a multiple of 16: 16-byte tile loads, all-zero-tile exit before any LDS
+// traffic, Sobel/magnitude computed for four pixels per lane from dword LDS reads.
+__global__ void __launch_bounds__(256)
+k_canny_nms_v(const uint8_t *img, u64 *cand, u64 *strong, int h, int w, int low, int high,
+              const int *active) {
+    int g = blockIdx.z;
+    if (active && !active[g]) return;
+    const int PH = CANNY_TH + 4, PWB = CANNY_TW + 2 * CANNY_HALO, MH = CANNY_TH + 2;
+    __shared__ __attribute__((aligned(16))) uint8_t px[PH * PWB]; // rows y0-2 .. y0+TH+1, cols x0-16 .. x0+79
+    __shared__ __attribute__((aligned(16))) int mg[MH * CANNY_MW];
+    __shared__ __attribute__((aligned(16))) int dxy[MH * CANNY_MW];
+    __shared__ int rowflag[PH];
+    int x0 = blockIdx.x * CANNY_TW, y0 = blockIdx.y * CANNY_TH;
+    const uint8_t *s = img + (size_t)g * h * w;
+    if (threadIdx.x < PH) rowflag[threadIdx.x] = 0;
+    __syncthreads();
+    // one 16-byte piece per thread (36 rows x 6 pieces = 216), BORDER_REPLICATE by clamping
+    uint4 v = make_uint4(0, 0, 0, 0);
+    int ty = threadIdx.x / 6, wx = threadIdx.x - ty * 6;
+    bool mine = threadIdx.x < PH * 6;
+    if (mine) {
+        int gy = min(max(y0 - 2 + ty, 0), h - 1), gx = x0 - CANNY_HALO + 16 * wx;
+        if (gx >= 0 && gx < w) v = *(const uint4 *)(s + (size_t)gy * w + gx);
+        else {
+            uint32_t e = s[(size_t)gy * w + (gx < 0 ? 0 : w - 1)];
+            e |= e << 8; e |= e << 16;
+            v = make_uint4(e, e, e, e);
+        }
+    }
+    uint32_t nzv = v.x | v.y | v.z | v.w;
+    int wq = LFD_WQ(w);
+    // an all-zero tile (sky) has zero gradient everywhere: no candidate when low >= 0
+    if (!__syncthreads_or(nzv != 0) && low >= 0) {
+        if (threadIdx.x < CANNY_TH && y0 + threadIdx.x < h) {
+            size_t o = (size_t)g * h * wq + (size_t)(y0 + threadIdx.x) * wq + blockIdx.x;
+            cand[o] = 0ull;
+            strong[o] = 0ull;
+        }
+        return;
+    }
+    if (mine) {
+        ((uint4 *)px)[threadIdx.x] = v;
+        if (nzv) rowflag[ty] = 1;
+    }
+    __syncthreads();
+    canny_tile_stages(px, rowflag, mg, dxy, cand, strong, g, h, w, x0, y0, low, high);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused dilation + Canny NMS (batch path): the dilated, equalised tile with a 2-pixel ring is
+// built in LDS and handed straight to the Sobel / NMS stages, so `equ` is never re-read (and
+// not even written unless stage images are requested).  Same arithmetic as k_morph_rect_v<0>
+// followed by k_canny_nms_v, bit for bit: the ring positions outside the image take the
+// replicated border value of the dilated image (Canny's BORDER_REPLICATE), positions inside
+// are ordinary dilation outputs computed from a correspondingly larger input halo.
+// Requires w % 16 == 0 and kw/2 + 2 <= 16, kw - 1 - kw/2 + 2 <= 16.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_dilate_canny_v(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *strong, const uint8_t *lut, int h, int w,
+                 int kh, int kw, int low, int high, const int *active) {
+    int g = blockIdx.z;
+    if (active && !active[g]) return;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smf[];
+    const int PH = CANNY_TH + 4, PWB = CANNY_TW + 2 * CANNY_HALO, MH = CANNY_TH + 2;
+    const int IH = PH + kh - 1;          // input rows feeding dilated rows -2 .. TH+1
+    const int NWD = CANNY_MW / 4;        // 18 dwords per dilated row: tile columns -4 .. 67
+    __shared__ __attribute__((aligned(16))) uint8_t px[PH * PWB];
+    __shared__ uint8_t slut[256];
+    __shared__ int rowflag[CANNY_TH + 4 + LFDMI_MAX_MORPH_K]; // input rows
+    __shared__ int pxflag[PH];                                 // dilated rows
+    uint8_t *tin = smf;                                        // IH x PWB
+    uint32_t *tmpE = (uint32_t *)(smf + IH * PWB), *tmpO = tmpE + IH * NWD;
+    int x0 = blockIdx.x * CANNY_TW, y0 = blockIdx.y * CANNY_TH;
+    int ay = kh / 2, ax = kw / 2;
+    size_t N = (size_t)h * w;
+    const uint8_t *s = src + (size_t)g * N;
+    if (lut) slut[threadIdx.x] = lut[g * 256 + threadIdx.x];
+    if (threadIdx.x < IH) rowflag[threadIdx.x] = 0;
+    if (threadIdx.x < PH) pxflag[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t any = 0;
+    for (int idx = threadIdx.x; idx < IH * 6; idx += 256) {
+        int iy = idx / 6, wx = idx - iy * 6;
+        int gy = y0 - 2 - ay + iy, gx = x0 - CANNY_HALO + 16 * wx;
+        uint4 v = make_uint4(0, 0, 0, 0); // out-of-image samples are ignored by a dilation
+        if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = *(const uint4 *)(s + (size_t)gy * w + gx);
+        uint32_t nzv = v.x | v.y | v.z | v.w;
+        if (nzv) rowflag[iy] = 1;
+        any |= nzv;
+        ((uint4 *)tin)[idx] = v;
+    }
+    int wq = LFD_WQ(w);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int nz = __syncthreads_or(any != 0);
+    uint8_t *d = equ ? equ + (size_t)g * N : nullptr;
+    if (!nz) {
+        // empty neighbourhood: the dilated tile and its ring are lut[0] everywhere: no gradient
+        uint32_t z = lut ? slut[0] : 0u;
+        z |= z << 8; z |= z << 16;
+        if (d && threadIdx.x < CANNY_TH * 4) {
+            int row = threadIdx.x >> 2, c16 = threadIdx.x & 3;
+            int gy = y0 + row, gx = x0 + 16 * c16;
+            if (gy < h && gx < w) *(uint4 *)(d + (size_t)gy * w + gx) = make_uint4(z, z, z, z);
+        }
+        if (threadIdx.x < CANNY_TH && y0 + threadIdx.x < h) {
+            size_t o = (size_t)g * h * wq + (size_t)(y0 + threadIdx.x) * wq + blockIdx.x;
+            equb[o] = z ? valid_mask(blockIdx.x, w) : 0ull;
+            cand[o] = 0ull;
+            strong[o] = 0ull;
+        }
+        if (low >= 0) return;
+        // low < 0 makes zero-gradient pixels candidates: fall through to the general path
+    }
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const uint32_t *tinw = (const uint32_t *)tin;
+    for (int it = threadIdx.x; it < IH * NWD; it += 256) {
+        int ry = it / NWD, j = it - ry * NWD;
+        uint32_t aE = 0, aO = 0;
+        if (rowflag[ry]) {
+            int o = CANNY_MOFF - ax + 4 * j; // byte offset of the window's first column
+            const uint32_t *rw = tinw + ry * (PWB / 4);
+            int qi = o >> 2;
+            uint32_t lo = rw[qi], hi = rw[qi + 1];
+            for (int dx = 0; dx < kw; dx++, o++) {
+                if ((o >> 2) != qi) { qi = o >> 2; lo = hi; hi = rw[qi + 1]; }
+                uint32_t sft = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o & 3));
+                us2 e = __builtin_bit_cast(us2, sft & 0x00FF00FFu), od = __builtin_bit_cast(us2, (sft >> 8) & 0x00FF00FFu);
+                aE = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aE), e));
+                aO = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aO), od));
+            }
+        }
+        tmpE[it] = aE;
+        tmpO[it] = aO;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < PH * NWD; it += 256) {
+        int dr = it / NWD, j = it - dr * NWD;
+        uint32_t aE = 0, aO = 0;
+        bool live = false;
+        for (int dy = 0; dy < kh; dy++) live = live || rowflag[dr + dy];
+        if (live)
+            for (int dy = 0; dy < kh; dy++) {
+                aE = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aE), __builtin_bit_cast(us2, tmpE[(dr + dy) * NWD + j])));
+                aO = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aO), __builtin_bit_cast(us2, tmpO[(dr + dy) * NWD + j])));
+            }
+        uint32_t word = aE | (aO << 8);
+        if (lut)
+            word = (uint32_t)slut[word & 0xff] | ((uint32_t)slut[(word >> 8) & 0xff] << 8) |
+                   ((uint32_t)slut[(word >> 16) & 0xff] << 16) | ((uint32_t)slut[word >> 24] << 24);
+        ((uint32_t *)px)[dr * (PWB / 4) + 3 + j] = word;
+        if (word) pxflag[dr] = 1;
+    }
+    __syncthreads();
+    // ring positions outside the image: replicate the dilated image's border (tiles on the frame only)
+    if (y0 < 2 || y0 + CANNY_TH + 2 > h || x0 < 4 || x0 + CANNY_TW + 4 > w) {
+        for (int it = threadIdx.x; it < PH * CANNY_MW; it += 256) {
+            int dr = it / CANNY_MW, c = CANNY_MOFF + it - dr * CANNY_MW;
+            int gy = y0 - 2 + dr, gx = x0 - CANNY_HALO + c;
+            if (gy < 0 || gy >= h || gx < 0 || gx >= w) {
+                int cy = min(max(gy, 0), h - 1), cx = min(max(gx, 0), w - 1);
+                uint8_t v = px[(cy - (y0 - 2)) * PWB + (cx - (x0 - CANNY_HALO))];
+                px[dr * PWB + c] = v;
+                if (v) pxflag[dr] = 1;
+            }
+        }
+        __syncthreads();
+    }
+    // the tile proper: equ (optional) and its != 0 bit row
+    if (d && threadIdx.x < CANNY_TH * 4) {
+        int row = threadIdx.x >> 2, c16 = threadIdx.x & 3;
+        int gy = y0 + row, gx = x0 + 16 * c16;
+        if (gy < h && gx < w) *(uint4 *)(d + (size_t)gy * w + gx) = *(const uint4 *)(px + (row + 2) * PWB + CANNY_HALO + 16 * c16);
+    }
+    for (int oy = wv; oy < CANNY_TH; oy += 4) {
+        int gy = y0 + oy, gx = x0 + lane;
+        u64 bal = __ballot(gy < h && gx < w && px[(oy + 2) * PWB + CANNY_HALO + lane] != 0);
+        if (lane == 0 && gy < h) equb[(size_t)g * h * wq + (size_t)gy * wq + blockIdx.x] = bal;
+    }
+    __syncthreads(); // tin / tmp are dead: reuse the dynamic LDS for the Canny stages
+    int *mg = (int *)smf, *dxy = mg + MH * CANNY_MW;
+    canny_tile_stages(px, pxflag, mg, dxy, cand, strong, g, h, w, x0, y0, low, high);
 }
 
 // generic widths

@@ -28,13 +28,13 @@ enum {
     KID_REMOVESTARS = 0, KID_PREP_HIST, KID_LUT, KID_ERODE, KID_DILATE, KID_CANNY_NMS, KID_RUNS_INIT_FG,
     KID_RUNS_MERGE8, KID_RUNS_FLATTEN_FG, KID_EDGE, KID_RUNS_INIT_BG, KID_RUNS_MERGE4, KID_RUNS_FLATTEN_BG,
     KID_KEYS, KID_EXTREMES, KID_RECTS, KID_FILL, KID_PIXLIST, KID_VOTE, KID_PEAKS, KID_TOPK, KID_SORT,
-    KID_FINALIZE, KID_MISC, TG_COUNT
+    KID_FINALIZE, KID_DILATE_CANNY, KID_MISC, TG_COUNT
 };
 static const char *const KID_NAMES[TG_COUNT] = {
     "k_removestars", "k_prep_hist", "k_lut", "k_morph(erode)", "k_morph(dilate)", "k_canny_nms", "k_runs_init(fg)",
     "k_runs_merge8", "k_runs_flatten(fg)", "k_edge_from_cand", "k_runs_init(bg)", "k_runs_merge4_bg",
     "k_runs_flatten(bg)", "k_keys", "k_extremes", "k_rects", "k_fill_quads", "k_pixlist", "k_hough_vote",
-    "k_hough_peaks", "k_hough_topk", "k_hough_sort", "k_finalize", "misc"};
+    "k_hough_peaks", "k_hough_topk", "k_hough_sort", "k_finalize", "k_dilate_canny", "misc"};
 
 struct TimedSpan { hipEvent_t a, b; int group, pass, det; };
 
@@ -81,6 +81,8 @@ struct lfdmi_ctx {
     float t_ms[TG_COUNT] = {0};
     int t_n[TG_COUNT] = {0};
     long long t_units[TG_COUNT] = {0}; // frames (images) the timed launches actually worked on
+    bool want_stage_images = false;    // lfdmi_detect_batch writes the equ stage image only on request
+    bool keep_equ = true;              // write the equalised+dilated stage image (off in lfdmi_detect_batch)
     int cur_pass = 0;                  // 0 = bright / stand-alone operator, 1 = dim pass of detect_batch
     int *pass_flags = nullptr;         // per slot: bit0 bright detection, bit1 dim pass ran, bit2 dim detection
     std::vector<void *> allocs;
@@ -223,6 +225,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_rects_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_dilate_canny_v, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     return 0;
@@ -377,10 +380,11 @@ static int run_morph(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, u64 *bits
 
 // Canny = NMS bit rows + hysteresis by run labelling; leaves edge bits in ctx->edgeb and the
 // 8-connected labels of the surviving components in ctx->Lf
-static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, double low_d, double high_d, const int *active) {
+static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, double low_d, double high_d, const int *active,
+                     bool nms_done = false) {
     if (low_d > high_d) { double t = low_d; low_d = high_d; high_d = t; }
     int low = (int)floor(low_d), high = (int)floor(high_d);
-    {
+    if (!nms_done) {
         Span sp(ctx, KID_CANNY_NMS);
         dim3 grid((w + CANNY_TW - 1) / CANNY_TW, (h + CANNY_TH - 1) / CANNY_TH, nc);
         if ((w % 16) == 0) k_canny_nms_v<<<grid, 256, 0, ctx->stream>>>(img, ctx->candb, ctx->strongb, h, w, low, high, active);
@@ -407,6 +411,28 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
       k_edge_from_cand<<<lg, 256, 0, ctx->stream>>>(ctx->candb, ctx->scanf_, ctx->Lf, ctx->FLf, ctx->edgeb, h, w, rc, ctx->wl_fg,
                                                     ctx->counters, C_NFGW, active);
       KCHK("k_edge_from_cand"); }
+    return 0;
+}
+
+// dilate (all-ones kernel) + Canny NMS in one tile kernel when the shapes allow; returns false otherwise
+static bool can_fuse_dilate_canny(const uint8_t *kernel, int kh, int kw, int w) {
+    if (!kernel || kh <= 0 || kw <= 0 || kh > LFDMI_MAX_MORPH_K || kw > LFDMI_MAX_MORPH_K || (w % 16) != 0) return false;
+    if (!all_ones(kernel, kh, kw)) return false;
+    int ax = kw / 2;
+    return ax + 2 <= CANNY_HALO - 4 + 4 && (kw - 1 - ax) + 2 <= CANNY_HALO - 4 + 4 && ax + 4 <= CANNY_HALO && (kw - 1 - ax) + 4 <= CANNY_HALO;
+}
+
+static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, int w, const uint8_t *lut, int kh, int kw,
+                            const int *active) {
+    int IH = CANNY_TH + 4 + kh - 1;
+    size_t a = (size_t)IH * (CANNY_TW + 2 * CANNY_HALO) + (size_t)IH * (CANNY_MW / 4) * 8;
+    size_t b = (size_t)2 * (CANNY_TH + 2) * CANNY_MW * 4;
+    size_t lds = a > b ? a : b;
+    dim3 grid((w + CANNY_TW - 1) / CANNY_TW, (h + CANNY_TH - 1) / CANNY_TH, nc);
+    Span sp(ctx, KID_DILATE_CANNY);
+    k_dilate_canny_v<<<grid, 256, lds, ctx->stream>>>(src, ctx->keep_equ ? ctx->equ : nullptr, ctx->equb, ctx->candb, ctx->strongb,
+                                                       lut, h, w, kh, kw, 0, 255, active);
+    KCHK("k_dilate_canny_v");
     return 0;
 }
 
@@ -561,13 +587,18 @@ static int run_pass(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, i
                     const lfdmi_params *p, const int *active, int *need_dim) {
     RET(zero_counters(ctx, nc));
     RET(run_prep(ctx, src, dtype, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, active));
+    const uint8_t *dil_src = ctx->gray;
     if (dim) {
         RET(run_morph(ctx, ctx->gray, ctx->tmp, nullptr, nullptr, p->erodeKernel, p->erode_kh, p->erode_kw, 1, nc, h, w, active));
-        RET(run_morph(ctx, ctx->tmp, ctx->equ, ctx->equb, ctx->lut, p->dilateKernel, p->dilate_kh, p->dilate_kw, 0, nc, h, w, active));
-    } else {
-        RET(run_morph(ctx, ctx->gray, ctx->equ, ctx->equb, ctx->lut, p->dilateKernel, p->dilate_kh, p->dilate_kw, 0, nc, h, w, active));
+        dil_src = ctx->tmp;
     }
-    RET(run_canny(ctx, ctx->equ, nc, h, w, 0, 255, active));
+    if (can_fuse_dilate_canny(p->dilateKernel, p->dilate_kh, p->dilate_kw, w)) {
+        RET(run_dilate_canny(ctx, dil_src, nc, h, w, ctx->lut, p->dilate_kh, p->dilate_kw, active));
+        RET(run_canny(ctx, ctx->equ, nc, h, w, 0, 255, active, true));
+    } else {
+        RET(run_morph(ctx, dil_src, ctx->equ, ctx->equb, ctx->lut, p->dilateKernel, p->dilate_kh, p->dilate_kw, 0, nc, h, w, active));
+        RET(run_canny(ctx, ctx->equ, nc, h, w, 0, 255, active));
+    }
     RET(run_rects(ctx, nc, h, w, p->contoursMode, p->contoursMethod, p->minAreaRectMinLen, p->lwTresh, active));
     RET(run_hough(ctx, nc, h, w, p->houghMethod, LFD_PI / 180, 1, 2, p->nlinesInSet, 1, active));
     TailParams tp;
@@ -905,6 +936,8 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
     size_t N = (size_t)h * w;
     std::vector<lfdmi_result> host((size_t)ctx->G);
     std::vector<int> flags((size_t)ctx->G);
+    struct KeepEqu { lfdmi_ctx *c; bool old; KeepEqu(lfdmi_ctx *c_, bool v) : c(c_), old(c_->keep_equ) { c->keep_equ = v; } ~KeepEqu() { c->keep_equ = old; } }
+        keep_guard(ctx, ctx->want_stage_images);
     for (int c0 = 0; c0 < n; c0 += ctx->G) {
         int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
         const void *d;
