@@ -21,6 +21,7 @@ enum {
     C_NBGW = 11,     // bit-row words where a background run can start or join (work list of the hole kernels)
     C_NRUNF = 12,    // candidate runs in the frame (compact run ids 0 .. n-1)
     C_NRUNB = 13,    // background runs of the edge image
+    C_NMED = 14,     // keys of medium height (one wave each, small LDS footprint)
     C_COUNT = 16
 };
 

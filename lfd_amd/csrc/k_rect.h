@@ -12,7 +12,8 @@
 #include "common.h"
 
 #define KEY_HOLE_BIT (1 << 30)
-#define BIG_KEY_ROWS 48 // keys with more rows than this get a whole wave (k_rects_big)
+#define SMALL_KEY_ROWS 16 // keys up to this many rows: one thread each (k_rects)
+#define BIG_KEY_ROWS 64   // up to this many rows: one wave each with a 64-row LDS footprint; taller: one wave, full-height LDS
 
 // Run tables of one frame slot (compact ids, see k_ccl.h)
 struct RunTabs {
@@ -24,7 +25,7 @@ struct RunTabs {
 };
 
 __global__ void __launch_bounds__(256)
-k_keys(RunTabs t, int4 *keys, int *bigkeys, int2 *rowext, int *counters, int h, int w, int key_cap, int slot_cap,
+k_keys(RunTabs t, int4 *keys, int *bigkeys, int *medkeys, int2 *rowext, int *counters, int h, int w, int key_cap, int slot_cap,
        const int *wlist_fg, const int *wlist_bg, const int *active) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
@@ -73,6 +74,7 @@ k_keys(RunTabs t, int4 *keys, int *bigkeys, int2 *rowext, int *counters, int h, 
                 else { t.SBb[ro + id] = base; t.PAb[ro + id] = parent; }
                 kg[ki] = make_int4(id, extent | (val ? 0 : KEY_HOLE_BIT), ymin, base);
                 if (extent > BIG_KEY_ROWS) bigkeys[(size_t)g * key_cap + atomicAdd(&cnt[C_NBIG], 1)] = ki;
+                else if (extent > SMALL_KEY_ROWS) medkeys[(size_t)g * key_cap + atomicAdd(&cnt[C_NMED], 1)] = ki;
                 for (int r = 0; r < extent; r++) re[base + r] = make_int2(0x7fffffff, -1);
             }
         }
@@ -327,22 +329,27 @@ k_rects(const int4 *keys, const int2 *rowext, int2 *hullbuf, int *quads, int *co
     int nkeys = min(cnt[C_NKEYS], key_cap);
     const int4 *kg = keys + (size_t)g * key_cap;
     const int2 *re = rowext + (size_t)g * slot_cap;
-    int2 *hb = hullbuf + (size_t)g * slot_cap * 2;
+    // per thread in LDS: the key's row extremes (fetched with independent loads first) and the
+    // two chain stacks -- the hull walk is a chain of dependent accesses, which in global memory
+    // made this kernel pure latency
+    __shared__ int2 stk[64 * 3 * SMALL_KEY_ROWS];
+    int2 *ext = stk + (size_t)threadIdx.x * 3 * SMALL_KEY_ROWS, *c1 = ext + SMALL_KEY_ROWS, *c2 = c1 + SMALL_KEY_ROWS;
+    (void)hullbuf;
     for (int ki = blockIdx.x * blockDim.x + threadIdx.x; ki < nkeys; ki += gridDim.x * blockDim.x) {
         int4 key = kg[ki];
         int extent = key.y & ~KEY_HOLE_BIT, ymin = key.z, base = key.w;
-        if (extent > BIG_KEY_ROWS) continue; // k_rects_big
-        int2 *c1 = hb + 2 * (size_t)base, *c2 = c1 + extent;
+        if (extent > SMALL_KEY_ROWS) continue; // k_rects_big
+        for (int r = 0; r < extent; r++) ext[r] = re[base + r];
         int n1 = 0, n2 = 0;
         for (int r = 0; r < extent; r++) {
-            int2 e = re[base + r];
+            int2 e = ext[r];
             if (e.x > e.y) continue;
             int2 p = make_int2(e.x, ymin + r);
             while (n1 >= 2 && cross_i(c1[n1 - 2], c1[n1 - 1], p) >= 0) n1--;
             c1[n1++] = p;
         }
         for (int r = extent - 1; r >= 0; r--) {
-            int2 e = re[base + r];
+            int2 e = ext[r];
             if (e.x > e.y) continue;
             int2 p = make_int2(e.y, ymin + r);
             while (n2 >= 2 && cross_i(c2[n2 - 2], c2[n2 - 1], p) >= 0) n2--;
@@ -414,13 +421,13 @@ __device__ __forceinline__ int2 *filter_chain(int2 *A, int2 *B, int *n_io) {
 }
 
 __global__ void __launch_bounds__(64)
-k_rects_big(const int4 *keys, const int *bigkeys, const int2 *rowext, int *quads, int *counters, int h, int w,
+k_rects_big(const int4 *keys, const int *bigkeys, int cidx, const int2 *rowext, int *quads, int *counters, int h, int w,
             int key_cap, int slot_cap, int cap, double minLen, double lwTresh, const int *active) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     extern __shared__ int2 lds_pts[]; // 4 x cap
     int *cnt = counters + g * C_COUNT;
-    int nbig = cnt[C_NBIG];
+    int nbig = cnt[cidx];
     const int4 *kg = keys + (size_t)g * key_cap;
     const int2 *re = rowext + (size_t)g * slot_cap;
     int lane = lfd_lane();

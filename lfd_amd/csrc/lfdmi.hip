@@ -55,7 +55,7 @@ struct lfdmi_ctx {
     int *scanf_ = nullptr, *scanb_ = nullptr;
     int run_cap = 0;
     int4 *keys = nullptr;
-    int *bigkeys = nullptr;
+    int *bigkeys = nullptr, *medkeys = nullptr;
     int *wl_fg = nullptr, *wl_bg = nullptr; // work lists of active bit-row words
     int2 *rowext = nullptr, *hullbuf = nullptr;
     int *quads = nullptr;
@@ -202,6 +202,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     RET(dmalloc(ctx, &ctx->scanb_, G * BW));
     RET(dmalloc(ctx, &ctx->keys, G * ctx->key_cap));
     RET(dmalloc(ctx, &ctx->bigkeys, G * ctx->key_cap));
+    RET(dmalloc(ctx, &ctx->medkeys, G * ctx->key_cap));
     RET(dmalloc(ctx, &ctx->wl_fg, G * BW));
     RET(dmalloc(ctx, &ctx->wl_bg, G * BW));
     RET(dmalloc(ctx, &ctx->rowext, G * ctx->slot_cap));
@@ -472,20 +473,24 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     rt.Lb = ctx->Lb; rt.YMb = ctx->YMb; rt.FLb = ctx->FLb; rt.SBb = ctx->SBb; rt.PAb = ctx->PAb; rt.ROWb = ctx->ROWb;
     rt.run_cap = rc;
     { Span sp(ctx, KID_KEYS);
-    k_keys<<<lg, 256, 0, ctx->stream>>>(rt, ctx->keys, ctx->bigkeys, ctx->rowext, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap,
+    k_keys<<<lg, 256, 0, ctx->stream>>>(rt, ctx->keys, ctx->bigkeys, ctx->medkeys, ctx->rowext, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap,
                                          ctx->wl_fg, ctx->wl_bg, active);
     KCHK("k_keys"); }
     { Span sp(ctx, KID_EXTREMES);
     k_extremes<<<lg, 256, 0, ctx->stream>>>(rt, ctx->rowext, h, w, ctx->slot_cap, ctx->wl_fg, ctx->counters, active);
     KCHK("k_extremes"); }
     { Span sp(ctx, KID_RECTS);
-    k_rects<<<dim3(256, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, ctx->hullbuf, ctx->quads, ctx->counters, h, w,
+    k_rects<<<dim3(32, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, ctx->hullbuf, ctx->quads, ctx->counters, h, w,
                                                     ctx->key_cap, ctx->slot_cap, minLen, lwTresh, active);
     KCHK("k_rects");
     {
         int cap = h + 2; // rows a key can span (a hole border adds one row above and below)
-        k_rects_big<<<dim3(48, nc), 64, (size_t)cap * 4 * sizeof(int2), ctx->stream>>>(
-            ctx->keys, ctx->bigkeys, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, cap,
+        k_rects_big<<<dim3(32, nc), 64, (size_t)BIG_KEY_ROWS * 4 * sizeof(int2), ctx->stream>>>(
+            ctx->keys, ctx->medkeys, C_NMED, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, BIG_KEY_ROWS,
+            minLen, lwTresh, active);
+        KCHK("k_rects_med");
+        k_rects_big<<<dim3(8, nc), 64, (size_t)cap * 4 * sizeof(int2), ctx->stream>>>(
+            ctx->keys, ctx->bigkeys, C_NBIG, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, cap,
             minLen, lwTresh, active);
         KCHK("k_rects_big");
     } }
