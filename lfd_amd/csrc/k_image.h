@@ -725,6 +725,349 @@ k_dilate_canny_v(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
     canny_tile_stages(px, pxflag, mg, dxy, cand, strong, g, h, w, x0, y0, low, high);
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused dilation + Canny NMS, one WAVE per 64 x 16 tile, driven by activity masks.
+//
+// The pass input is sparse (well under 1 % non-zero bytes, yet a third of the tiles hold
+// some), so sweeping every tile position wastes the vector units, and a four-wave workgroup
+// that meets at a barrier after every stage mostly waits.  Here a workgroup IS one wave with
+// its own LDS tile: no cross-wave barrier, many independent waves per CU to hide latency.
+// Per tile the wave keeps one 32-bit mask per 4-pixel word column (bit r = "row r of this
+// column can differ from the background"), pushes the masks through the stages with shifts
+// and ORs (input pieces -> horizontal max -> vertical max -> Sobel -> NMS) and evaluates only
+// live (row, column) items, two columns per step (lanes 0-31 / 32-63 = rows of each).
+// Items a later stage reads but that were not evaluated hold the background value by
+// construction: px is pre-filled with lut[0], the magnitude plane with 0.
+// Same arithmetic as k_morph_rect_v<0> followed by k_canny_nms_v, bit for bit.
+// Requires w % 16 == 0, kw/2 + 4 <= 16, kw - 1 - kw/2 + 4 <= 16, kh <= 13, low >= 0.
+// The grid is 1-D and XCD-aware: frame = 8 * (j / tiles_per_frame) + (block & 7) keeps every
+// tile of a frame (and its halo re-reads) behind one L2; a wave walks a strip of S tiles
+// downwards and prefetches the next tile's input while it works on the current one.
+// ------------------------------------------------------------------------------------------
+#define DCW_TH 16
+#define DCW_PH (DCW_TH + 4)  // dilated rows -2 .. TH+1
+#define DCW_MH (DCW_TH + 2)  // magnitude rows -1 .. TH
+#define DCW_TS 112           // tin / px row stride in bytes: 96 used, 16-byte aligned, rows spread over the banks
+#define DCW_NWD 18           // word columns per row: tile columns -4 .. 67
+#define DCW_MAXKH 13         // DCW_PH + kh - 1 <= 32 rows: one 32-bit mask per column
+
+template <class F>
+__device__ __forceinline__ void dcw_for_live(u64 live, uint32_t colmask, int lane, F f) {
+    int r = lane & 31;
+    bool up = lane >= 32;
+    while (live) {
+        int ja = __ffsll((long long)live) - 1;
+        live &= live - 1;
+        uint32_t ma = __builtin_amdgcn_readlane(colmask, ja), mb = 0;
+        int jb = ja;
+        if (live) {
+            jb = __ffsll((long long)live) - 1;
+            live &= live - 1;
+            mb = __builtin_amdgcn_readlane(colmask, jb);
+        }
+        uint32_t m = up ? mb : ma;
+        if ((m >> r) & 1) f(r, up ? jb : ja);
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *strong, const uint8_t *lut, int h, int w,
+                 int kh, int kw, int low, int high, const int *active, int nc, int tiles_x, int nstrips, int S) {
+    int L = blockIdx.x, xcd = L & 7, jb_ = L >> 3, per = tiles_x * nstrips;
+    int g = (jb_ / per) * 8 + xcd;
+    if (g >= nc) return;
+    if (active && !active[g]) return;
+    int rem = jb_ - (jb_ / per) * per;
+    int strip = rem / tiles_x, tx = rem - strip * tiles_x;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smw[];
+    const int PH = DCW_PH, MH = DCW_MH, NWD = DCW_NWD, TS = DCW_TS, TSW = DCW_TS / 4;
+    const int IH = PH + kh - 1;
+    const int MGB = MH * CANNY_MW * 2;                 // magnitude plane: ushort (m << 2 | sector)
+    const int tin_bytes = IH * TS > MGB ? IH * TS : MGB;
+    uint8_t *tin = smw;                                // IH x 112; later the magnitude plane
+    uint32_t *tmpE = (uint32_t *)(smw + tin_bytes), *tmpO = tmpE + IH * NWD;
+    uint8_t *px = (uint8_t *)(tmpO + IH * NWD);        // PH x 112
+    unsigned short *mg = (unsigned short *)smw;
+    __shared__ uint8_t slut[256];
+    __shared__ uint32_t Pm[8];                         // input piece column p: rows holding a non-zero byte
+    __shared__ u64 rowc[DCW_TH], rows[DCW_TH];         // NMS output bit rows of the tile
+    const int lane = threadIdx.x;
+    const int x0 = tx * CANNY_TW;
+    const int ay = kh / 2, ax = kw / 2;
+    const size_t N = (size_t)h * w;
+    const uint8_t *s = src + (size_t)g * N;
+    const int wq = LFD_WQ(w);
+    uint8_t *d = equ ? equ + (size_t)g * N : nullptr;
+    const int npieces = IH * 6;                        // <= 192: three 16-byte pieces per lane
+    int iy[3], wx[3], gxp[3];
+    bool colok[3], has[3];
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        int idx = lane + 64 * p;
+        iy[p] = idx / 6;
+        wx[p] = idx - iy[p] * 6;
+        has[p] = idx < npieces;
+        gxp[p] = x0 - CANNY_HALO + 16 * wx[p];
+        colok[p] = has[p] && gxp[p] >= 0 && gxp[p] < w;
+    }
+    const int tiles_y = (h + DCW_TH - 1) / DCW_TH;
+    int ty = strip * S, ty_end = min(ty + S, tiles_y);
+    uint4 v[3];
+    {
+        int gy = ty * DCW_TH - 2 - ay;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            v[p] = make_uint4(0, 0, 0, 0); // out-of-image samples are ignored by a dilation
+            if (colok[p] && gy + iy[p] >= 0 && gy + iy[p] < h) v[p] = *(const uint4 *)(s + (size_t)(gy + iy[p]) * w + gxp[p]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) slut[lane + 64 * p] = lut ? lut[g * 256 + lane + 64 * p] : (uint8_t)(lane + 64 * p);
+    if (lane < 8) Pm[lane] = 0u;
+    __syncthreads();
+    uint32_t zw = slut[0]; // background of the dilated, equalised image
+    zw |= zw << 8; zw |= zw << 16;
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const uint32_t mPH = (1u << PH) - 1, mMH = (1u << MH) - 1, mIH = IH >= 32 ? ~0u : ((1u << IH) - 1);
+    for (; ty < ty_end; ty++) {
+        const int y0 = ty * DCW_TH;
+        uint32_t anyv = 0;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+            if (has[p]) {
+                uint32_t nzv = v[p].x | v[p].y | v[p].z | v[p].w;
+                if (nzv) atomicOr(&Pm[wx[p]], 1u << iy[p]);
+                anyv |= nzv;
+                *(uint4 *)(tin + iy[p] * TS + wx[p] * 16) = v[p];
+            }
+        if (ty + 1 < ty_end) { // next tile's input: in flight while this tile is processed
+            int gy = y0 + DCW_TH - 2 - ay;
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                v[p] = make_uint4(0, 0, 0, 0);
+                if (colok[p] && gy + iy[p] >= 0 && gy + iy[p] < h) v[p] = *(const uint4 *)(s + (size_t)(gy + iy[p]) * w + gxp[p]);
+            }
+        }
+        if (__ballot(anyv != 0) == 0ull) {
+            // empty neighbourhood: the dilated tile and its ring are lut[0] everywhere: no gradient
+            if (d) {
+                int row = lane >> 2, c16 = lane & 3;
+                int gy = y0 + row, gx = x0 + 16 * c16;
+                if (gy < h && gx < w) *(uint4 *)(d + (size_t)gy * w + gx) = make_uint4(zw, zw, zw, zw);
+            }
+            if (lane < DCW_TH && y0 + lane < h) {
+                size_t o = (size_t)g * h * wq + (size_t)(y0 + lane) * wq + tx;
+                equb[o] = zw ? valid_mask(tx, w) : 0ull;
+                cand[o] = 0ull;
+                strong[o] = 0ull;
+            }
+            continue;
+        }
+        __syncthreads();
+        // ---- background fill of px, activity masks
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+            if (lane + 64 * p < PH * (TS / 16)) ((uint4 *)px)[lane + 64 * p] = make_uint4(zw, zw, zw, zw);
+        if (lane < DCW_TH) { rowc[lane] = 0ull; rows[lane] = 0ull; }
+        uint32_t hp = 0, vm = 0, A = 0;
+        if (lane < NWD) {
+            int o = CANNY_MOFF - ax + 4 * lane;           // window bytes o .. o + kw + 2 of the staged row
+            uint32_t h0 = 0;
+            for (int p = o >> 4; p <= (o + kw + 2) >> 4; p++) h0 |= Pm[p];
+            for (int dy = 0; dy < kh; dy++) vm |= h0 >> dy; // dilated row dr reads input rows dr .. dr+kh-1
+            vm &= mPH;
+            for (int dy = 0; dy < kh; dy++) hp |= vm << dy; // rows of the horizontal pass the live outputs read
+            hp &= mIH;
+            A = vm;
+            // rows outside the image replicate the first / last image row
+            if (y0 == 0 && ((A >> 2) & 1)) A |= 3u;
+            int drl = h - 1 - y0 + 2;
+            if (drl < PH - 1 && ((A >> drl) & 1)) A |= (~0u << (drl + 1)) & mPH;
+        }
+        // columns outside the image replicate the first / last image column
+        {
+            uint32_t A1 = (uint32_t)__shfl((int)A, 1);
+            if (x0 == 0 && lane == 0) A |= A1;
+            bool right = x0 + CANNY_TW >= w;
+            int jlast = (w - x0) >> 2; // word column of the last image column (<= 16 when `right`)
+            uint32_t Al = (uint32_t)__shfl((int)A, right ? jlast : 0);
+            if (right && lane > jlast && lane < NWD) A |= Al;
+        }
+        // the Sobel magnitude can be non-zero where a 3x3 word neighbourhood holds a non-background word
+        uint32_t M;
+        {
+            uint32_t Au = (uint32_t)__shfl((int)A, lane > 0 ? lane - 1 : 0), Ad = (uint32_t)__shfl((int)A, lane + 1);
+            uint32_t Ax = A | (lane > 0 ? Au : 0u) | (lane + 1 < NWD ? Ad : 0u);
+            M = (Ax | (Ax >> 1) | (Ax >> 2)) & mMH;      // magnitude row my reads px rows my .. my+2
+            if (lane >= NWD) M = 0;
+        }
+        uint32_t Mn = (lane >= 1 && lane <= 16) ? (M & 0x1FFFEu) : 0u; // NMS items: the tile's own rows and columns
+        uint32_t rowA = (lane >= 1 && lane <= 16) ? A : 0u;
+        for (int off = 16; off > 0; off >>= 1) rowA |= (uint32_t)__shfl_xor((int)rowA, off);
+        const u64 LH = __ballot(hp != 0), LV = __ballot(vm != 0), LM = __ballot(M != 0), LN = __ballot(Mn != 0);
+        __syncthreads();
+        // ---- horizontal max of the live words
+        dcw_for_live(LH, hp, lane, [&](int ry, int jj) {
+            uint32_t aE = 0, aO = 0;
+            int o = CANNY_MOFF - ax + 4 * jj; // byte offset of the window's first column
+            const uint32_t *rw = (const uint32_t *)(tin + ry * TS);
+            int qi = o >> 2;
+            uint32_t lo = rw[qi], hi = rw[qi + 1];
+            for (int dx = 0; dx < kw; dx++, o++) {
+                if ((o >> 2) != qi) { qi = o >> 2; lo = hi; hi = rw[qi + 1]; }
+                uint32_t sft = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o & 3));
+                us2 e = __builtin_bit_cast(us2, sft & 0x00FF00FFu), od = __builtin_bit_cast(us2, (sft >> 8) & 0x00FF00FFu);
+                aE = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aE), e));
+                aO = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aO), od));
+            }
+            tmpE[ry * NWD + jj] = aE;
+            tmpO[ry * NWD + jj] = aO;
+        });
+        __syncthreads();
+        // tin is dead: clear the masks of the next tile and the magnitude plane that aliases tin
+        if (lane < 8) Pm[lane] = 0u;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+            if (lane + 64 * p < MGB / 16) ((uint4 *)mg)[lane + 64 * p] = make_uint4(0, 0, 0, 0);
+        // ---- vertical max + LUT of the live words
+        dcw_for_live(LV, vm, lane, [&](int dr, int jj) {
+            uint32_t aE = 0, aO = 0;
+            for (int dy = 0; dy < kh; dy++) {
+                aE = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aE), __builtin_bit_cast(us2, tmpE[(dr + dy) * NWD + jj])));
+                aO = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aO), __builtin_bit_cast(us2, tmpO[(dr + dy) * NWD + jj])));
+            }
+            uint32_t word = aE | (aO << 8);
+            word = (uint32_t)slut[word & 0xff] | ((uint32_t)slut[(word >> 8) & 0xff] << 8) |
+                   ((uint32_t)slut[(word >> 16) & 0xff] << 16) | ((uint32_t)slut[word >> 24] << 24);
+            ((uint32_t *)px)[dr * TSW + 3 + jj] = word;
+        });
+        __syncthreads();
+        // ---- ring positions outside the image replicate the dilated image's border: columns, then rows
+        {
+            bool left = x0 == 0, right = x0 + CANNY_TW >= w;
+            if (left || right) {
+                if (lane < PH) {
+                    uint32_t *pr = (uint32_t *)(px + lane * TS);
+                    if (left) pr[3] = 0x01010101u * px[lane * TS + CANNY_HALO];
+                    if (right) {
+                        int cl = CANNY_HALO + (w - x0) - 1; // staged byte of the last image column
+                        uint32_t e = 0x01010101u * px[lane * TS + cl];
+                        for (int wd = (cl + 1) >> 2; wd <= 20; wd++) pr[wd] = e;
+                    }
+                }
+                __syncthreads();
+            }
+            int drl = h - 1 - y0 + 2; // dilated row of the last image row
+            bool top = y0 == 0, bot = drl < PH - 1;
+            if (top || bot) {
+                uint32_t *pw32 = (uint32_t *)px;
+                if (top && lane < 2 * NWD) {
+                    int r = lane / NWD, jj = lane - r * NWD;
+                    pw32[r * TSW + 3 + jj] = pw32[2 * TSW + 3 + jj];
+                }
+                if (bot)
+                    for (int idx = lane; idx < (PH - 1 - drl) * NWD; idx += 64) {
+                        int r = idx / NWD, jj = idx - r * NWD;
+                        pw32[(drl + 1 + r) * TSW + 3 + jj] = pw32[drl * TSW + 3 + jj];
+                    }
+                __syncthreads();
+            }
+        }
+        // ---- the tile proper: equ (optional) and its != 0 bit row
+        if (d) {
+            int row = lane >> 2, c16 = lane & 3;
+            int gy = y0 + row, gx = x0 + 16 * c16;
+            if (gy < h && gx < w) *(uint4 *)(d + (size_t)gy * w + gx) = *(const uint4 *)(px + (row + 2) * TS + CANNY_HALO + 16 * c16);
+        }
+        {
+            u64 mine = 0ull;
+            uint32_t live = zw ? 0xFFFFu : ((rowA >> 2) & 0xFFFFu); // rows that can hold a non-zero pixel
+            live = __builtin_amdgcn_readfirstlane(live);
+            while (live) {
+                int oy = __ffs((int)live) - 1;
+                live &= live - 1;
+                u64 bal = __ballot(x0 + lane < w && px[(oy + 2) * TS + CANNY_HALO + lane] != 0);
+                if (lane == oy) mine = bal;
+            }
+            if (lane < DCW_TH && y0 + lane < h) equb[(size_t)g * h * wq + (size_t)(y0 + lane) * wq + tx] = mine;
+        }
+        // ---- Sobel + L1 magnitude + NMS sector of the live words -> (m << 2 | sector) as ushort
+        dcw_for_live(LM, M, lane, [&](int my, int k) {
+            int gy = y0 - 1 + my;
+            uint32_t o01 = 0, o23 = 0;
+            if (gy >= 0 && gy < h) {
+                int b[3][6]; // bytes -1..4 around the word, for the three rows
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const uint32_t *rw = (const uint32_t *)(px + (my + r) * TS) + 3 + k;
+                    uint32_t wm = rw[-1], wc = rw[0], wp = rw[1];
+                    b[r][0] = wm >> 24; b[r][1] = wc & 0xff; b[r][2] = (wc >> 8) & 0xff;
+                    b[r][3] = (wc >> 16) & 0xff; b[r][4] = wc >> 24; b[r][5] = wp & 0xff;
+                }
+                int cs[6], rd[6]; // column sums r0 + 2 r1 + r2 and row differences r2 - r0
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    cs[c] = b[0][c] + 2 * b[1][c] + b[2][c];
+                    rd[c] = b[2][c] - b[0][c];
+                }
+                uint32_t pk[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    int gx = x0 - 4 + 4 * k + q;
+                    int dx = cs[q + 2] - cs[q];
+                    int dy = rd[q] + 2 * rd[q + 1] + rd[q + 2];
+                    int adx = abs(dx), ady = abs(dy) << 15;
+                    int tg22x = adx * 13573;
+                    uint32_t sec = ady < tg22x ? 0u : (ady > tg22x + (adx << 16) ? 1u : (((dx ^ dy) < 0) ? 3u : 2u));
+                    uint32_t m = (uint32_t)(abs(dx) + abs(dy));
+                    pk[q] = (gx >= 0 && gx < w) ? ((m << 2) | sec) : 0u;
+                }
+                o01 = pk[0] | (pk[1] << 16);
+                o23 = pk[2] | (pk[3] << 16);
+            }
+            *(uint2 *)(mg + my * CANNY_MW + 4 * k) = make_uint2(o01, o23);
+        });
+        __syncthreads();
+        // ---- non-maximum suppression of the live words of the tile
+        dcw_for_live(LN, Mn, lane, [&](int my, int k) {
+            // ushorts 4k-2 .. 4k+5 of the three rows (pixel q of the word sits at index q + 2)
+            uint32_t u[3][4];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const uint32_t *rp = (const uint32_t *)(mg + (my - 1 + r) * CANNY_MW + 4 * k - 2);
+                u[r][0] = rp[0]; u[r][1] = rp[1]; u[r][2] = rp[2]; u[r][3] = rp[3];
+            }
+            auto val = [&](int r, int i) -> int { uint32_t x = u[r][i >> 1]; return (int)((i & 1) ? (x >> 16) : (x & 0xffffu)); };
+            uint32_t cb = 0, sb = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int vv = val(1, q + 2), m = vv >> 2, sec = vv & 3;
+                if (m > low) {
+                    int a, bb;
+                    bool strict_b;
+                    if (sec == 0) { a = val(1, q + 1) >> 2; bb = val(1, q + 3) >> 2; strict_b = false; }
+                    else if (sec == 1) { a = val(0, q + 2) >> 2; bb = val(2, q + 2) >> 2; strict_b = false; }
+                    else if (sec == 2) { a = val(0, q + 1) >> 2; bb = val(2, q + 3) >> 2; strict_b = true; }
+                    else { a = val(0, q + 3) >> 2; bb = val(2, q + 1) >> 2; strict_b = true; }
+                    bool keep = (m > a) && (strict_b ? (m > bb) : (m >= bb));
+                    if (keep) {
+                        cb |= 1u << q;
+                        if (m > high) sb |= 1u << q;
+                    }
+                }
+            }
+            if (cb) atomicOr((unsigned long long *)&rowc[my - 1], (u64)cb << (4 * (k - 1)));
+            if (sb) atomicOr((unsigned long long *)&rows[my - 1], (u64)sb << (4 * (k - 1)));
+        });
+        __syncthreads();
+        if (lane < DCW_TH && y0 + lane < h) {
+            size_t o = (size_t)g * h * wq + (size_t)(y0 + lane) * wq + tx;
+            cand[o] = rowc[lane];
+            strong[o] = rows[lane];
+        }
+    }
+}
+
 // generic widths
 
 __global__ void __launch_bounds__(256)

@@ -82,6 +82,7 @@ struct lfdmi_ctx {
     int t_n[TG_COUNT] = {0};
     long long t_units[TG_COUNT] = {0}; // frames (images) the timed launches actually worked on
     bool want_stage_images = false;    // lfdmi_detect_batch writes the equ stage image only on request
+    int dc_strip = 8;                  // tiles per wave strip in k_dilate_canny_w
     bool keep_equ = true;              // write the equalised+dilated stage image (off in lfdmi_detect_batch)
     int cur_pass = 0;                  // 0 = bright / stand-alone operator, 1 = dim pass of detect_batch
     int *pass_flags = nullptr;         // per slot: bit0 bright detection, bit1 dim pass ran, bit2 dim detection
@@ -171,6 +172,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     lfdmi_ctx *ctx = new lfdmi_ctx();
     *out = ctx;
     ctx->device = device; ctx->H = max_h; ctx->W = max_w; ctx->G = max_inflight;
+    if (const char *e = getenv("LFDMI_DC_STRIP")) { int v = atoi(e); if (v >= 1 && v <= 256) ctx->dc_strip = v; } // tuning knob
     ctx->N = (size_t)max_h * max_w;
     ctx->wq = LFD_WQ(max_w);
     size_t N = ctx->N, G = (size_t)max_inflight, BW = (size_t)max_h * ctx->wq;
@@ -425,6 +427,18 @@ static bool can_fuse_dilate_canny(const uint8_t *kernel, int kh, int kw, int w) 
 
 static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, int w, const uint8_t *lut, int kh, int kw,
                             const int *active) {
+    if (kh <= DCW_MAXKH) { // one wave per 64 x 16 tile, mask-driven (the sparse pass images)
+        int IH = DCW_PH + kh - 1, MGB = DCW_MH * CANNY_MW * 2;
+        size_t lds = (size_t)(IH * DCW_TS > MGB ? IH * DCW_TS : MGB) + (size_t)IH * DCW_NWD * 8 + (size_t)DCW_PH * DCW_TS;
+        int tiles_x = (w + CANNY_TW - 1) / CANNY_TW, tiles_y = (h + DCW_TH - 1) / DCW_TH;
+        int S = ctx->dc_strip, nstrips = (tiles_y + S - 1) / S;
+        unsigned grid = 8u * ((nc + 7) / 8) * tiles_x * nstrips; // frame = 8 * (j / tiles) + (block & 7): one XCD per frame
+        Span sp(ctx, KID_DILATE_CANNY);
+        k_dilate_canny_w<<<grid, 64, lds, ctx->stream>>>(src, ctx->keep_equ ? ctx->equ : nullptr, ctx->equb, ctx->candb,
+                                                          ctx->strongb, lut, h, w, kh, kw, 0, 255, active, nc, tiles_x, nstrips, S);
+        KCHK("k_dilate_canny_w");
+        return 0;
+    }
     int IH = CANNY_TH + 4 + kh - 1;
     size_t a = (size_t)IH * (CANNY_TW + 2 * CANNY_HALO) + (size_t)IH * (CANNY_MW / 4) * 8;
     size_t b = (size_t)2 * (CANNY_TH + 2) * CANNY_MW * 4;
