@@ -43,6 +43,8 @@ STAGE_BYTES_PER_PX = {
     "k_finalize": 0.0, "misc": 0.0,
     # fused dilate (2N) + Canny NMS (the Canny stage's 2N) tile kernel
     "k_dilate_canny": 4.0,
+    # per-frame LDS connectivity kernels (k_frame.h): same stages as the run kernels they replace
+    "k_frame_fg": 2.0, "k_frame_bg": 2.0, "k_frame_keys": 2.0,
 }
 
 

@@ -29,7 +29,7 @@ SYMBOLS = (
     "lfdmi_max_inflight", "lfdmi_prep_u8", "lfdmi_equalize_hist", "lfdmi_dilate", "lfdmi_erode",
     "lfdmi_canny", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
     "lfdmi_hough_dims", "lfdmi_remove_stars", "lfdmi_process_bright", "lfdmi_process_dim",
-    "lfdmi_detect_batch", "lfdmi_get_stage", "lfdmi_enable_timing", "lfdmi_get_timing",
+    "lfdmi_detect_batch", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_get_timing",
     "lfdmi_timing_slots", "lfdmi_timing_name",
 )
 
@@ -397,6 +397,13 @@ class Context:
                                                C.byref(pb), C.byref(pd), _ptr(res),
                                                DEVICE if _is_dev(frames) else HOST))
         return res
+
+    def get_counters(self, slot0=0, n=None):
+        """Work counters ([n, 16] int32) the last pass left for in-flight slots slot0 .. slot0+n-1."""
+        n = self.max_inflight - slot0 if n is None else int(n)
+        out = np.zeros((n, 16), np.int32)
+        self._chk(self._lib.lfdmi_get_counters(self._h, int(slot0), n, _ptr(out)))
+        return out
 
     def get_stage(self, slot, which, h, w):
         out = np.empty((h, w), np.uint8)

@@ -1,0 +1,247 @@
+// k_frame.h -- per-frame connectivity with the run tables in LDS.
+//
+// The run kernels of k_ccl.h spread one frame's few thousand active words over 48 workgroups
+// and chase union-find links through HBM: every step of a `find` is a ~2 us round trip and the
+// whole chain (init -> merge -> flatten -> edges) is five launches of mostly waiting waves.  A
+// sky frame has only a few thousand runs, so here ONE workgroup owns a frame and keeps the
+// label table in LDS (a `find` step costs an LDS access), walking the same work list through
+// the phases with workgroup barriers in between.  Results are identical: the union-find links
+// always point to the smaller id, so every component's root is its raster-first run either way.
+// A frame with more runs than the LDS table holds is left to the multi-workgroup kernels of
+// k_ccl.h: each k_frame_* kernel writes a per-frame `fallback` flag those are launched with as
+// their `active` mask (they exit at once when the flag is clear).
+//
+// Every phase walks the work list through frame_pipeline(): the global loads of an item (its
+// words, their scan entries) do not depend on any table, so the loads of the NEXT item and the
+// list entry after that are issued before the current item is processed -- the ~2 us HBM round
+// trips overlap with the LDS work instead of adding up.
+#pragma once
+#include "k_ccl.h"
+
+#define FRAME_THREADS 1024
+#define FRAME_RUNCAP 32768 // runs per frame the LDS label table holds (128 KB); busier frames take the k_ccl.h kernels
+
+__device__ __forceinline__ int lds_find(const int *L, int x) {
+    int p;
+    while ((p = L[x]) != x) x = p;
+    return x;
+}
+
+// find with path halving: a non-root entry may be re-pointed to any ancestor at any time (links
+// only ever go to smaller ids, and a linked run never becomes a root again)
+__device__ __forceinline__ int lds_find_halve(int *L, int x) {
+    int p;
+    while ((p = L[x]) != x) {
+        int gp = L[p];
+        if (gp != p) L[x] = gp;
+        x = gp;
+    }
+    return x;
+}
+
+__device__ __forceinline__ void lds_union(int *L, int a, int b) {
+    for (;;) {
+        a = lds_find_halve(L, a);
+        b = lds_find_halve(L, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        int old = atomicMin(&L[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+template <class Item, class LoadF, class ProcF>
+__device__ __forceinline__ void frame_pipeline(const int *wl, int nwork, LoadF load, ProcF proc) {
+    int it = threadIdx.x;
+    int i1 = it < nwork ? wl[it] : -1;
+    int i2 = it + FRAME_THREADS < nwork ? wl[it + FRAME_THREADS] : -1;
+    Item cur;
+    if (i1 >= 0) cur = load(i1);
+    while (i1 >= 0) {
+        int i3 = it + 2 * FRAME_THREADS < nwork ? wl[it + 2 * FRAME_THREADS] : -1;
+        Item nxt;
+        if (i2 >= 0) nxt = load(i2);
+        proc(cur);
+        cur = nxt;
+        i1 = i2;
+        i2 = i3;
+        it += FRAME_THREADS;
+    }
+}
+
+// bits 0 .. b
+__device__ __forceinline__ u64 upto_bit(int b) { return (b == 63) ? ~0ull : ((2ull << b) - 1ull); }
+
+struct FgMergeItem { int idx, id0, idu; u64 c, cp, u, up, un; };
+struct FgWordItem { int idx, id0; u64 c, cp, m; };
+
+// Hysteresis of one frame: 8-connected components of the candidate runs, strong flags, edge
+// bit rows; Lf / YMf / ROWf written for the contour kernels.  Replaces k_runs_init(fg),
+// k_runs_merge8, k_runs_flatten(fg) and k_edge_from_cand.
+__global__ void __launch_bounds__(FRAME_THREADS)
+k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_fg, const int *counters, int *Lf, int *YMf,
+           int *ROWf, u64 *edge, int h, int w, int run_cap, int lds_cap, const int *active, int *fallback) {
+    const int g = blockIdx.x;
+    if (active && !active[g]) {
+        if (threadIdx.x == 0) fallback[g] = 0;
+        return;
+    }
+    const int wq = LFD_WQ(w);
+    const size_t fo = (size_t)g * h * wq, ro = (size_t)g * run_cap;
+    const int nwork = counters[g * C_COUNT + C_NFGW], nrun = counters[g * C_COUNT + C_NRUNF];
+    const bool fits = nrun <= lds_cap; // lds_cap <= FRAME_RUNCAP (k_scan_runs flags nrun > run_cap as an overflow)
+    if (threadIdx.x == 0) fallback[g] = fits ? 0 : 1;
+    if (!fits) return;
+    extern __shared__ int sm_frame[];
+    int *L = sm_frame;
+    unsigned *FL = (unsigned *)(sm_frame + FRAME_RUNCAP); // root holds a strong pixel
+    unsigned *HB = FL + FRAME_RUNCAP / 32;               // run touches a run of the next row
+    int *YMg = YMf + ro, *ROWg = ROWf + ro;
+    const u64 *fb = cand + fo, *mb = strong + fo;
+    const int *sf = scanf + fo, *wl = wl_fg + fo;
+    for (int i = threadIdx.x; i < (nrun + 31) / 32; i += FRAME_THREADS) { FL[i] = 0u; HB[i] = 0u; }
+    for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) L[i] = i; // every run its own root
+    __syncthreads();
+    // ---- row of every run; 8-connectivity between rows y and y-1
+    frame_pipeline<FgMergeItem>(
+        wl, nwork,
+        [&](int idx) {
+            FgMergeItem t;
+            int y = idx / wq, q = idx - y * wq;
+            t.idx = idx;
+            t.c = fb[idx];
+            t.cp = q > 0 ? fb[idx - 1] : 0ull;
+            t.id0 = sf[idx];
+            t.u = 0; t.up = 0; t.un = 0; t.idu = 0;
+            if (y > 0) {
+                t.u = fb[idx - wq];
+                t.up = q > 0 ? fb[idx - wq - 1] : 0ull;
+                t.un = q + 1 < wq ? fb[idx - wq + 1] : 0ull;
+                t.idu = sf[idx - wq];
+            }
+            return t;
+        },
+        [&](const FgMergeItem &t) {
+            int y = t.idx / wq, q = t.idx - y * wq;
+            u64 vmask = valid_mask(q, w);
+            u64 c = t.c & vmask;
+            u64 s = c & ~((c << 1) | (t.cp >> 63)); // run starts of this word
+            for (int k = 0, n = __popcll(s); k < n; k++) {
+                ROWg[t.id0 + k] = y;
+                YMg[t.id0 + k] = y;
+            }
+            if (y == 0 || !c) return;
+            u64 u = t.u & vmask;
+            u64 su = u & ~((u << 1) | (t.up >> 63)); // run starts of the word above
+            u64 uL = (u << 1) | (t.up >> 63);         // bit x set <=> up[x-1]
+            u64 uR = (u >> 1) | (t.un << 63);         // bit x set <=> up[x+1]
+            u64 v0 = c & u;
+            v0 &= ~(v0 << 1); // first column of every vertical-contact stretch
+            u64 vm = c & uL & ~u, vp = c & uR & ~u; // diagonal contacts not implied by a vertical one
+            // run holding bit b of this word / of the word above (the bit is set)
+            auto own = [&](int b) { return t.id0 + __popcll(s & upto_bit(b)) - 1; };
+            auto above = [&](int b) { return t.idu + __popcll(su & upto_bit(b)) - 1; };
+            // every touching (upper run, lower run) pair shows up in exactly these contacts, so the
+            // upper run of a contact is never in its component's last row
+            auto join = [&](int lo, int hi) {
+                atomicOr(&HB[hi >> 5], 1u << (hi & 31));
+                lds_union(L, lo, hi);
+            };
+            while (v0) {
+                int b = __ffsll((long long)v0) - 1;
+                v0 &= v0 - 1;
+                join(own(b), above(b));
+            }
+            while (vm) {
+                int b = __ffsll((long long)vm) - 1;
+                vm &= vm - 1;
+                // bit b-1 of the word above; for b == 0 the last pixel of the previous word: the run
+                // started last before this word
+                join(own(b), b ? above(b - 1) : t.idu - 1);
+            }
+            while (vp) {
+                int b = __ffsll((long long)vp) - 1;
+                vp &= vp - 1;
+                // bit b+1 of the word above; for b == 63 the first pixel of the next word, which starts a
+                // run there (bit 63 above is clear): the first run after those starting in this word
+                join(own(b), b < 63 ? above(b + 1) : t.idu + __popcll(su));
+            }
+        });
+    __syncthreads();
+    // ---- flatten; last row and strong flag per root
+    frame_pipeline<FgWordItem>(
+        wl, nwork,
+        [&](int idx) {
+            FgWordItem t;
+            int y = idx / wq, q = idx - y * wq;
+            t.idx = idx;
+            t.c = fb[idx];
+            t.cp = q > 0 ? fb[idx - 1] : 0ull;
+            t.m = mb[idx];
+            t.id0 = sf[idx];
+            return t;
+        },
+        [&](const FgWordItem &t) {
+            int y = t.idx / wq, q = t.idx - y * wq;
+            u64 c = t.c & valid_mask(q, w);
+            u64 s = c & ~((c << 1) | (t.cp >> 63));
+            int id = t.id0;
+            for (; s; id++) {
+                int b = __ffsll((long long)s) - 1;
+                s &= s - 1;
+                int root = lds_find(L, id);
+                if (root != id) {
+                    L[id] = root;
+                    // last row of the component: only runs with nothing below them can hold it (a big
+                    // component would otherwise serialise thousands of atomics on one address)
+                    if (!((HB[id >> 5] >> (id & 31)) & 1u)) atomicMax(&YMg[root], y);
+                }
+                // strong pixels of the run: inside this word, and in the following words if it runs on
+                u64 inv = ~(c >> b);
+                int len = inv ? (__ffsll((long long)inv) - 1) : (64 - b);
+                u64 seg = (len >= 64 ? ~0ull : ((1ull << len) - 1)) << b;
+                bool flag = (t.m & seg) != 0;
+                if (!flag && b + len == 64 && q + 1 < wq) {
+                    const u64 *row = fb + (size_t)y * wq, *mrow = mb + (size_t)y * wq;
+                    int xs = (q << 6) + b, xe = run_end(row, xs, 1, w);
+                    for (int k = q + 1; k <= (xe >> 6) && !flag; k++) {
+                        int hi = (k == (xe >> 6)) ? (xe & 63) : 63;
+                        flag = (mrow[k] & (~0ull >> (63 - hi))) != 0;
+                    }
+                }
+                if (flag) atomicOr(&FL[root >> 5], 1u << (root & 31));
+            }
+        });
+    __syncthreads();
+    // ---- edge = candidate runs whose component holds a strong pixel
+    frame_pipeline<FgWordItem>(
+        wl, nwork,
+        [&](int idx) {
+            FgWordItem t;
+            int y = idx / wq, q = idx - y * wq;
+            t.idx = idx;
+            t.c = fb[idx];
+            t.cp = q > 0 ? fb[idx - 1] : 0ull;
+            t.m = 0;
+            t.id0 = sf[idx];
+            return t;
+        },
+        [&](const FgWordItem &t) {
+            int y = t.idx / wq, q = t.idx - y * wq;
+            u64 c = t.c & valid_mask(q, w);
+            u64 s = c & ~((c << 1) | (t.cp >> 63));
+            u64 rem = c, res = 0;
+            while (rem) {
+                int b = __ffsll((long long)rem) - 1;
+                u64 inv = ~(c >> b);
+                int len = inv ? (__ffsll((long long)inv) - 1) : (64 - b);
+                u64 seg = (len >= 64 ? ~0ull : ((1ull << len) - 1)) << b;
+                int root = L[t.id0 + __popcll(s & upto_bit(b)) - 1]; // a stretch continuing from the previous word: id0 - 1
+                if ((FL[root >> 5] >> (root & 31)) & 1u) res |= seg;
+                rem &= ~seg;
+            }
+            edge[fo + t.idx] = res;
+        });
+    for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) Lf[ro + i] = L[i];
+}

@@ -770,7 +770,7 @@ __device__ __forceinline__ void dcw_for_live(u64 live, uint32_t colmask, int lan
     }
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
 k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *strong, const uint8_t *lut, int h, int w,
                  int kh, int kw, int low, int high, const int *active, int nc, int tiles_x, int nstrips, int S) {
     int L = blockIdx.x, xcd = L & 7, jb_ = L >> 3, per = tiles_x * nstrips;
@@ -785,8 +785,8 @@ k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
     const int MGB = MH * CANNY_MW * 2;                 // magnitude plane: ushort (m << 2 | sector)
     const int tin_bytes = IH * TS > MGB ? IH * TS : MGB;
     uint8_t *tin = smw;                                // IH x 112; later the magnitude plane
-    uint32_t *tmpE = (uint32_t *)(smw + tin_bytes), *tmpO = tmpE + IH * NWD;
-    uint8_t *px = (uint8_t *)(tmpO + IH * NWD);        // PH x 112
+    uint32_t *tmp = (uint32_t *)(smw + tin_bytes);      // IH x 18 words of horizontal maxima
+    uint8_t *px = (uint8_t *)(tmp + IH * NWD);         // PH x 112
     unsigned short *mg = (unsigned short *)smw;
     __shared__ uint8_t slut[256];
     __shared__ uint32_t Pm[8];                         // input piece column p: rows holding a non-zero byte
@@ -920,8 +920,7 @@ k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
                 aE = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aE), e));
                 aO = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aO), od));
             }
-            tmpE[ry * NWD + jj] = aE;
-            tmpO[ry * NWD + jj] = aO;
+            tmp[ry * NWD + jj] = aE | (aO << 8);
         });
         __syncthreads();
         // tin is dead: clear the masks of the next tile and the magnitude plane that aliases tin
@@ -933,8 +932,9 @@ k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
         dcw_for_live(LV, vm, lane, [&](int dr, int jj) {
             uint32_t aE = 0, aO = 0;
             for (int dy = 0; dy < kh; dy++) {
-                aE = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aE), __builtin_bit_cast(us2, tmpE[(dr + dy) * NWD + jj])));
-                aO = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aO), __builtin_bit_cast(us2, tmpO[(dr + dy) * NWD + jj])));
+                uint32_t t = tmp[(dr + dy) * NWD + jj];
+                aE = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aE), __builtin_bit_cast(us2, t & 0x00FF00FFu)));
+                aO = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aO), __builtin_bit_cast(us2, (t >> 8) & 0x00FF00FFu)));
             }
             uint32_t word = aE | (aO << 8);
             word = (uint32_t)slut[word & 0xff] | ((uint32_t)slut[(word >> 8) & 0xff] << 8) |

@@ -16,6 +16,7 @@
 #include "../../include/lfdmi.h"
 #include "common.h"
 #include "k_ccl.h"
+#include "k_frame.h"
 #include "k_hough.h"
 #include "k_image.h"
 #include "k_rect.h"
@@ -28,13 +29,14 @@ enum {
     KID_REMOVESTARS = 0, KID_PREP_HIST, KID_LUT, KID_ERODE, KID_DILATE, KID_CANNY_NMS, KID_RUNS_INIT_FG,
     KID_RUNS_MERGE8, KID_RUNS_FLATTEN_FG, KID_EDGE, KID_RUNS_INIT_BG, KID_RUNS_MERGE4, KID_RUNS_FLATTEN_BG,
     KID_KEYS, KID_EXTREMES, KID_RECTS, KID_FILL, KID_PIXLIST, KID_VOTE, KID_PEAKS, KID_TOPK, KID_SORT,
-    KID_FINALIZE, KID_DILATE_CANNY, KID_MISC, TG_COUNT
+    KID_FINALIZE, KID_DILATE_CANNY, KID_FRAME_FG, KID_FRAME_BG, KID_FRAME_KEYS, KID_MISC, TG_COUNT
 };
 static const char *const KID_NAMES[TG_COUNT] = {
     "k_removestars", "k_prep_hist", "k_lut", "k_morph(erode)", "k_morph(dilate)", "k_canny_nms", "k_runs_init(fg)",
     "k_runs_merge8", "k_runs_flatten(fg)", "k_edge_from_cand", "k_runs_init(bg)", "k_runs_merge4_bg",
     "k_runs_flatten(bg)", "k_keys", "k_extremes", "k_rects", "k_fill_quads", "k_pixlist", "k_hough_vote",
-    "k_hough_peaks", "k_hough_topk", "k_hough_sort", "k_finalize", "k_dilate_canny", "misc"};
+    "k_hough_peaks", "k_hough_topk", "k_hough_sort", "k_finalize", "k_dilate_canny", "k_frame_fg", "k_frame_bg",
+    "k_frame_keys", "misc"};
 
 struct TimedSpan { hipEvent_t a, b; int group, pass, det; };
 
@@ -64,6 +66,7 @@ struct lfdmi_ctx {
     u64 *peaks = nullptr;
     float *lines = nullptr, *tab = nullptr;
     int *counters = nullptr, *need_dim = nullptr;
+    int *fb_fg = nullptr, *fb_bg = nullptr; // per slot: frame left to the multi-workgroup run kernels (k_frame.h)
     lfdmi_result *res_dev = nullptr;
     void *stage = nullptr;
     size_t stage_bytes = 0;
@@ -82,6 +85,8 @@ struct lfdmi_ctx {
     int t_n[TG_COUNT] = {0};
     long long t_units[TG_COUNT] = {0}; // frames (images) the timed launches actually worked on
     bool want_stage_images = false;    // lfdmi_detect_batch writes the equ stage image only on request
+    bool frame_ccl = true;             // per-frame LDS connectivity kernels (k_frame.h)
+    int frame_runcap = FRAME_RUNCAP;   // runs per frame they take (LFDMI_FRAME_RUNCAP lowers it: tests of the fallback path)
     int dc_strip = 8;                  // tiles per wave strip in k_dilate_canny_w
     bool keep_equ = true;              // write the equalised+dilated stage image (off in lfdmi_detect_batch)
     int cur_pass = 0;                  // 0 = bright / stand-alone operator, 1 = dim pass of detect_batch
@@ -172,6 +177,8 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     lfdmi_ctx *ctx = new lfdmi_ctx();
     *out = ctx;
     ctx->device = device; ctx->H = max_h; ctx->W = max_w; ctx->G = max_inflight;
+    if (const char *e = getenv("LFDMI_FRAME_CCL")) ctx->frame_ccl = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_FRAME_RUNCAP")) { int v = atoi(e); if (v >= 0 && v < FRAME_RUNCAP) ctx->frame_runcap = v; }
     if (const char *e = getenv("LFDMI_DC_STRIP")) { int v = atoi(e); if (v >= 1 && v <= 256) ctx->dc_strip = v; } // tuning knob
     ctx->N = (size_t)max_h * max_w;
     ctx->wq = LFD_WQ(max_w);
@@ -200,6 +207,8 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     for (int **p : {&ctx->Lf, &ctx->YMf, &ctx->FLf, &ctx->Lb, &ctx->YMb, &ctx->FLb, &ctx->SBf, &ctx->SBb, &ctx->PAb,
                     &ctx->ROWf, &ctx->ROWb})
         RET(dmalloc(ctx, p, G * ctx->run_cap));
+    RET(dmalloc(ctx, &ctx->fb_fg, G));
+    RET(dmalloc(ctx, &ctx->fb_bg, G));
     RET(dmalloc(ctx, &ctx->scanf_, G * BW));
     RET(dmalloc(ctx, &ctx->scanb_, G * BW));
     RET(dmalloc(ctx, &ctx->keys, G * ctx->key_cap));
@@ -229,6 +238,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_rects_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_dilate_canny_v, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_frame_fg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     return 0;
@@ -400,6 +410,16 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
       k_scan_runs<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->candb, 1, ctx->scanf_, ctx->counters, C_NRUNF, h, w, rc, ctx->wl_fg,
                                                         ctx->wl_bg, ctx->edgeb, active);
       KCHK("k_scan_runs(fg)");
+    }
+    if (ctx->frame_ccl) { // frames that fit the LDS tables; the rest (fallback flag) take the kernels below
+        Span sp(ctx, KID_FRAME_FG);
+        size_t lds = (size_t)(FRAME_RUNCAP + 2 * (FRAME_RUNCAP / 32)) * sizeof(int);
+        k_frame_fg<<<nc, FRAME_THREADS, lds, ctx->stream>>>(ctx->candb, ctx->strongb, ctx->scanf_, ctx->wl_fg, ctx->counters, ctx->Lf,
+                                                            ctx->YMf, ctx->ROWf, ctx->edgeb, h, w, rc, ctx->frame_runcap, active, ctx->fb_fg);
+        KCHK("k_frame_fg");
+        active = ctx->fb_fg;
+    }
+    { Span sp(ctx, KID_RUNS_INIT_FG);
       k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->candb, 1, ctx->scanf_, ctx->Lf, ctx->YMf, ctx->FLf, ctx->ROWf, h, w, rc,
                                                ctx->wl_fg, ctx->counters, C_NFGW, active);
       KCHK("k_runs_init"); }
@@ -429,7 +449,7 @@ static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, i
                             const int *active) {
     if (kh <= DCW_MAXKH) { // one wave per 64 x 16 tile, mask-driven (the sparse pass images)
         int IH = DCW_PH + kh - 1, MGB = DCW_MH * CANNY_MW * 2;
-        size_t lds = (size_t)(IH * DCW_TS > MGB ? IH * DCW_TS : MGB) + (size_t)IH * DCW_NWD * 8 + (size_t)DCW_PH * DCW_TS;
+        size_t lds = (size_t)(IH * DCW_TS > MGB ? IH * DCW_TS : MGB) + (size_t)IH * DCW_NWD * 4 + (size_t)DCW_PH * DCW_TS;
         int tiles_x = (w + CANNY_TW - 1) / CANNY_TW, tiles_y = (h + DCW_TH - 1) / DCW_TH;
         int S = ctx->dc_strip, nstrips = (tiles_y + S - 1) / S;
         unsigned grid = 8u * ((nc + 7) / 8) * tiles_x * nstrips; // frame = 8 * (j / tiles) + (block & 7): one XCD per frame
@@ -985,6 +1005,15 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
             results[c0 + i] = host[i];
         }
     }
+    return 0;
+}
+
+extern "C" int lfdmi_get_counters(lfdmi_ctx *ctx, int slot0, int n, int32_t *dst) {
+    if (!ctx || !dst || slot0 < 0 || n < 0 || slot0 + n > ctx->G) return LFDMI_ERR_ARG;
+    static_assert(C_COUNT == LFDMI_COUNTERS, "counter layout");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(dst, ctx->counters + (size_t)slot0 * C_COUNT, (size_t)n * C_COUNT * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

@@ -184,3 +184,33 @@ def test_full_batch_properties_at_baseline_size(gpu_ctx):
     res_p = gpu_ctx.detect_batch(dp, pb, pd)
     assert res_p.tobytes() == res[perm].tobytes()
     assert (res["status"] == 0).all() and set(np.unique(res["found"])) == {0, 1, 2}
+
+
+@pytest.mark.parametrize("runcap", [0, 6000])
+def test_frame_kernels_fallback_path(oracle, monkeypatch, runcap):
+    """The per-frame LDS connectivity kernels hand frames with more runs than their table holds to
+    the multi-workgroup run kernels (k_frame.h).  LFDMI_FRAME_RUNCAP lowers the table size: 0 sends
+    every frame down the general path, 6000 splits a synthetic batch between the two.  Records
+    and stage images must not depend on the path taken."""
+    from lfd_amd import _native, synth
+    pb, pd, prs = params()
+    rs_g, rs_o = rs_pair(oracle, prs)
+    frames, cats = zip(*[synth.make_frame(k)[:2] for k in range(6)])
+    batch = np.stack(frames)
+    cat = synth.pack_catalogs(list(cats))
+    ref_ctx = _native.Context(0, 1489, 2048, 6)
+    ref = ref_ctx.detect_batch(batch.copy(), pb, pd, cat, rs_g)
+    ref_edges = [ref_ctx.get_stage(i, _native.STAGE_CANNY, 1489, 2048) for i in range(6)]
+    ref_ctx.close()
+    monkeypatch.setenv("LFDMI_FRAME_RUNCAP", str(runcap))
+    ctx = _native.Context(0, 1489, 2048, 6)
+    res = ctx.detect_batch(batch.copy(), pb, pd, cat, rs_g)
+    assert res.tobytes() == ref.tobytes()
+    for i in range(6):
+        assert np.array_equal(ctx.get_stage(i, _native.STAGE_CANNY, 1489, 2048), ref_edges[i])
+    runs = ctx.get_counters(0, 6)[:, 12]
+    if runcap:
+        assert (runs > runcap).any(), runs                              # the general path was taken
+    want = oracle.detect_frame(frames[0].copy(), pb, pd, cats[0], rs_o)
+    assert same(res[0], want)
+    ctx.close()
