@@ -245,3 +245,148 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
         });
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) Lf[ro + i] = L[i];
 }
+
+struct BgMergeItem { int idx, id0, idu, first, firstu; u64 c, cp, u, up, r0, u0; };
+struct BgWordItem { int idx, id0, lastid; u64 c, cp, rl; };
+
+// Background of one frame's edge image: 4-connected components of the 0-runs, "touches the
+// frame" flag per root (FLb: 1 = outside, 0 = hole), last row of every hole (YMb), row of every
+// run (ROWb), flattened labels (Lb).  Replaces k_runs_init(bg), k_runs_merge4_bg,
+// k_runs_flatten(bg) and k_bg_extent; same tables, same values.
+__global__ void __launch_bounds__(FRAME_THREADS)
+k_frame_bg(const u64 *edge, const int *scanb, const int *wl_bg, const int *counters, int *Lb, int *YMb, int *FLb, int *ROWb, int h,
+           int w, int run_cap, int lds_cap, const int *active, int *fallback) {
+    const int g = blockIdx.x;
+    if (active && !active[g]) {
+        if (threadIdx.x == 0) fallback[g] = 0;
+        return;
+    }
+    const int wq = LFD_WQ(w);
+    const size_t fo = (size_t)g * h * wq, ro = (size_t)g * run_cap;
+    const int nwork = counters[g * C_COUNT + C_NBGW], nrun = counters[g * C_COUNT + C_NRUNB];
+    const bool fits = nrun <= lds_cap;
+    if (threadIdx.x == 0) fallback[g] = fits ? 0 : 1;
+    if (!fits) return;
+    extern __shared__ int sm_frame[];
+    int *L = sm_frame;
+    unsigned *FL = (unsigned *)(sm_frame + FRAME_RUNCAP); // root touches the frame (outside)
+    unsigned *HB = FL + FRAME_RUNCAP / 32;               // run touches a 0-run of the next row
+    int *YMg = YMb + ro, *ROWg = ROWb + ro;
+    const u64 *fb = edge + fo;
+    const int *sb = scanb + fo, *wl = wl_bg + fo;
+    for (int i = threadIdx.x; i < (nrun + 31) / 32; i += FRAME_THREADS) { FL[i] = 0u; HB[i] = 0u; }
+    for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) L[i] = i;
+    __syncthreads();
+    // ---- row of every run; 4-connectivity between rows y and y-1
+    frame_pipeline<BgMergeItem>(
+        wl, nwork,
+        [&](int idx) {
+            BgMergeItem t;
+            int y = idx / wq, q = idx - y * wq;
+            t.idx = idx;
+            t.c = fb[idx];
+            t.cp = q > 0 ? fb[idx - 1] : ~0ull;
+            t.id0 = sb[idx];
+            t.u = 0; t.up = 0; t.idu = 0; t.r0 = 0; t.u0 = 0; t.first = 0; t.firstu = 0;
+            if (y > 0) {
+                t.u = fb[idx - wq];
+                t.up = q > 0 ? fb[idx - wq - 1] : ~0ull;
+                t.idu = sb[idx - wq];
+                t.r0 = fb[idx - q];
+                t.u0 = fb[idx - q - wq];
+                t.first = sb[idx - q];
+                t.firstu = sb[idx - q - wq];
+            }
+            return t;
+        },
+        [&](const BgMergeItem &t) {
+            int y = t.idx / wq, q = t.idx - y * wq;
+            u64 vmask = valid_mask(q, w);
+            u64 z = ~t.c & vmask;                              // 0-pixels of this word
+            u64 s = z & ~((z << 1) | ((~t.cp) >> 63));         // 0-run starts (cp = all ones left of column 0)
+            for (int k = 0, n = __popcll(s); k < n; k++) {
+                ROWg[t.id0 + k] = y;
+                YMg[t.id0 + k] = y;
+            }
+            if (y == 0) return;
+            u64 zu = ~t.u & vmask;
+            u64 su = zu & ~((zu << 1) | ((~t.up) >> 63));
+            u64 v = z & zu;
+            // first column of every stretch; a stretch continuing from the previous word (both rows 0
+            // at the last column of that word) was already joined there
+            u64 cont = q > 0 ? ((~t.cp & ~t.up) >> 63) : 0ull;
+            u64 st = v & ~((v << 1) | cont);
+            while (st) {
+                int b = __ffsll((long long)st) - 1;
+                st &= st - 1;
+                int ia = t.id0 + __popcll(s & upto_bit(b)) - 1, ib = t.idu + __popcll(su & upto_bit(b)) - 1;
+                atomicOr(&HB[ib >> 5], 1u << (ib & 31));
+                // two runs that both start at column 0 touch the frame: each is flagged "outside" on its
+                // own, joining them would only build a 1 489-link chain down the left image border
+                bool a0 = (ia == t.first) && !(t.r0 & 1ull), b0 = (ib == t.firstu) && !(t.u0 & 1ull);
+                if (a0 && b0) continue;
+                lds_union(L, ia, ib);
+            }
+        });
+    __syncthreads();
+    // ---- flatten; outside flag per root
+    frame_pipeline<BgWordItem>(
+        wl, nwork,
+        [&](int idx) {
+            BgWordItem t;
+            int y = idx / wq, q = idx - y * wq;
+            t.idx = idx;
+            t.c = fb[idx];
+            t.cp = q > 0 ? fb[idx - 1] : ~0ull;
+            t.id0 = sb[idx];
+            t.rl = fb[idx - q + wq - 1];
+            t.lastid = (y + 1 < h) ? sb[idx - q + wq] - 1 : nrun - 1;
+            return t;
+        },
+        [&](const BgWordItem &t) {
+            int y = t.idx / wq, q = t.idx - y * wq;
+            u64 z = ~t.c & valid_mask(q, w);
+            u64 s = z & ~((z << 1) | ((~t.cp) >> 63));
+            bool last0 = !((t.rl >> ((w - 1) & 63)) & 1ull); // the row's last pixel is background
+            int id = t.id0;
+            for (; s; id++) {
+                int b = __ffsll((long long)s) - 1;
+                s &= s - 1;
+                int root = lds_find(L, id);
+                if (root != id) L[id] = root;
+                // touches the frame: first / last row, starts at column 0, or is the row's last run and
+                // that reaches the last column
+                bool flag = (y == 0) || (y == h - 1) || ((q << 6) + b == 0) || (id == t.lastid && last0);
+                if (flag && !((FL[root >> 5] >> (root & 31)) & 1u)) atomicOr(&FL[root >> 5], 1u << (root & 31));
+            }
+        });
+    __syncthreads();
+    // ---- last row of every hole
+    frame_pipeline<BgWordItem>(
+        wl, nwork,
+        [&](int idx) {
+            BgWordItem t;
+            int q = idx % wq;
+            t.idx = idx;
+            t.c = fb[idx];
+            t.cp = q > 0 ? fb[idx - 1] : ~0ull;
+            t.id0 = sb[idx];
+            t.rl = 0; t.lastid = 0;
+            return t;
+        },
+        [&](const BgWordItem &t) {
+            int y = t.idx / wq, q = t.idx - y * wq;
+            u64 z = ~t.c & valid_mask(q, w);
+            u64 s = z & ~((z << 1) | ((~t.cp) >> 63));
+            int n = __popcll(s);
+            for (int k = 0; k < n; k++) {
+                int id = t.id0 + k, root = L[id];
+                if (root != id && !((FL[root >> 5] >> (root & 31)) & 1u) && !((HB[id >> 5] >> (id & 31)) & 1u)) atomicMax(&YMg[root], y);
+            }
+        });
+    for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
+        int root = L[i];
+        Lb[ro + i] = root;
+        FLb[ro + i] = (root == i) ? (int)((FL[i >> 5] >> (i & 31)) & 1u) : 0;
+    }
+}

@@ -239,6 +239,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     HIPCHK(hipFuncSetAttribute((const void *)k_rects_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_dilate_canny_v, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_frame_fg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_frame_bg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     return 0;
@@ -487,19 +488,29 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     { Span sp(ctx, KID_RUNS_INIT_BG);
       k_scan_runs<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->scanb_, ctx->counters, C_NRUNB, h, w, rc, nullptr, nullptr,
                                                         ctx->boxb, active);
-      KCHK("k_scan_runs(bg)");
+      KCHK("k_scan_runs(bg)"); }
+    const int *gen = active; // frames for the general run kernels
+    if (ctx->frame_ccl) {
+        Span sp(ctx, KID_FRAME_BG);
+        size_t lds = (size_t)(FRAME_RUNCAP + 2 * (FRAME_RUNCAP / 32)) * sizeof(int);
+        k_frame_bg<<<nc, FRAME_THREADS, lds, ctx->stream>>>(ctx->edgeb, ctx->scanb_, ctx->wl_bg, ctx->counters, ctx->Lb, ctx->YMb,
+                                                            ctx->FLb, ctx->ROWb, h, w, rc, ctx->frame_runcap, active, ctx->fb_bg);
+        KCHK("k_frame_bg");
+        gen = ctx->fb_bg;
+    }
+    { Span sp(ctx, KID_RUNS_INIT_BG);
       k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->scanb_, ctx->Lb, ctx->YMb, ctx->FLb, ctx->ROWb, h, w, rc,
-                                               ctx->wl_bg, ctx->counters, C_NBGW, active);
+                                               ctx->wl_bg, ctx->counters, C_NBGW, gen);
       KCHK("k_runs_init(bg)"); }
     { Span sp(ctx, KID_RUNS_MERGE4);
-      k_runs_merge4_bg<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->scanb_, ctx->Lb, h, w, rc, ctx->wl_bg, ctx->counters, C_NBGW, active);
+      k_runs_merge4_bg<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->scanb_, ctx->Lb, h, w, rc, ctx->wl_bg, ctx->counters, C_NBGW, gen);
       KCHK("k_runs_merge4_bg"); }
     { Span sp(ctx, KID_RUNS_FLATTEN_BG);
       k_runs_flatten<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, nullptr, ctx->scanb_, ctx->Lb, ctx->YMb, ctx->FLb, h, w, rc,
-                                                  ctx->wl_bg, ctx->counters, C_NBGW, active);
+                                                  ctx->wl_bg, ctx->counters, C_NBGW, gen);
       KCHK("k_runs_flatten(bg)");
       k_bg_extent<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->scanb_, ctx->Lb, ctx->YMb, ctx->FLb, h, w, rc, ctx->wl_bg,
-                                               ctx->counters, C_NBGW, active);
+                                               ctx->counters, C_NBGW, gen);
       KCHK("k_bg_extent"); }
     RunTabs rt;
     rt.cand = ctx->candb; rt.edge = ctx->edgeb; rt.scanf = ctx->scanf_; rt.scanb = ctx->scanb_;
