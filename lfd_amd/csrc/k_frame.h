@@ -17,6 +17,7 @@
 // trips overlap with the LDS work instead of adding up.
 #pragma once
 #include "k_ccl.h"
+#include "k_rect.h"
 
 #define FRAME_THREADS 1024
 #define FRAME_RUNCAP 32768 // runs per frame the LDS label table holds (128 KB); busier frames take the k_ccl.h kernels
@@ -77,11 +78,11 @@ struct FgMergeItem { int idx, id0, idu; u64 c, cp, u, up, un; };
 struct FgWordItem { int idx, id0; u64 c, cp, m; };
 
 // Hysteresis of one frame: 8-connected components of the candidate runs, strong flags, edge
-// bit rows; Lf / YMf / ROWf written for the contour kernels.  Replaces k_runs_init(fg),
+// bit rows; Lf / YMf / FLf / ROWf written for the contour kernels.  Replaces k_runs_init(fg),
 // k_runs_merge8, k_runs_flatten(fg) and k_edge_from_cand.
 __global__ void __launch_bounds__(FRAME_THREADS)
 k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_fg, const int *counters, int *Lf, int *YMf,
-           int *ROWf, u64 *edge, int h, int w, int run_cap, int lds_cap, const int *active, int *fallback) {
+           int *FLf, int *ROWf, u64 *edge, int h, int w, int run_cap, int lds_cap, const int *active, int *fallback) {
     const int g = blockIdx.x;
     if (active && !active[g]) {
         if (threadIdx.x == 0) fallback[g] = 0;
@@ -188,7 +189,6 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
             u64 s = c & ~((c << 1) | (t.cp >> 63));
             int id = t.id0;
             for (; s; id++) {
-                int b = __ffsll((long long)s) - 1;
                 s &= s - 1;
                 int root = lds_find(L, id);
                 if (root != id) {
@@ -197,20 +197,20 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
                     // component would otherwise serialise thousands of atomics on one address)
                     if (!((HB[id >> 5] >> (id & 31)) & 1u)) atomicMax(&YMg[root], y);
                 }
-                // strong pixels of the run: inside this word, and in the following words if it runs on
+            }
+            // strong pixels, stretch by stretch INSIDE this word (a run that started in an earlier word is
+            // id0 - 1; its pieces in later words flag the same root, so nobody walks across words)
+            u64 rem = c & t.m ? c : 0ull;
+            s = c & ~((c << 1) | (t.cp >> 63));
+            while (rem) {
+                int b = __ffsll((long long)rem) - 1;
                 u64 inv = ~(c >> b);
                 int len = inv ? (__ffsll((long long)inv) - 1) : (64 - b);
                 u64 seg = (len >= 64 ? ~0ull : ((1ull << len) - 1)) << b;
-                bool flag = (t.m & seg) != 0;
-                if (!flag && b + len == 64 && q + 1 < wq) {
-                    const u64 *row = fb + (size_t)y * wq, *mrow = mb + (size_t)y * wq;
-                    int xs = (q << 6) + b, xe = run_end(row, xs, 1, w);
-                    for (int k = q + 1; k <= (xe >> 6) && !flag; k++) {
-                        int hi = (k == (xe >> 6)) ? (xe & 63) : 63;
-                        flag = (mrow[k] & (~0ull >> (63 - hi))) != 0;
-                    }
-                }
-                if (flag) atomicOr(&FL[root >> 5], 1u << (root & 31));
+                rem &= ~seg;
+                if (!(t.m & seg)) continue;
+                int root = lds_find(L, t.id0 + __popcll(s & upto_bit(b)) - 1);
+                atomicOr(&FL[root >> 5], 1u << (root & 31));
             }
         });
     __syncthreads();
@@ -243,19 +243,40 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
             }
             edge[fo + t.idx] = res;
         });
-    for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) Lf[ro + i] = L[i];
+    for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
+        int root = L[i];
+        Lf[ro + i] = root;
+        FLf[ro + i] = (root == i) ? (int)((FL[i >> 5] >> (i & 31)) & 1u) : 0; // root of an edge component
+    }
 }
 
 struct BgMergeItem { int idx, id0, idu, first, firstu; u64 c, cp, u, up, r0, u0; };
 struct BgWordItem { int idx, id0, lastid; u64 c, cp, rl; };
 
-// Background of one frame's edge image: 4-connected components of the 0-runs, "touches the
-// frame" flag per root (FLb: 1 = outside, 0 = hole), last row of every hole (YMb), row of every
-// run (ROWb), flattened labels (Lb).  Replaces k_runs_init(bg), k_runs_merge4_bg,
-// k_runs_flatten(bg) and k_bg_extent; same tables, same values.
+struct KeyFgItem { int idx, id0; u64 e, ep, c, cp; };
+struct KeyBgItem { int idx, id0, idcu; u64 e, ep, cu, cup; };
+struct ExtItem { int idx, id0, sbc, sbu, sbd; u64 e, ep, en, c, cp, u, up, d, dp; };
+
+// Contour topology of one frame's edge image.
+//  (1) background: 4-connected components of the 0-runs, "touches the frame" flag per root
+//      (FLb: 1 = outside, 0 = hole), last row of every hole (YMb), row of every run (ROWb),
+//      flattened labels (Lb) -- what k_runs_init(bg), k_runs_merge4_bg, k_runs_flatten(bg) and
+//      k_bg_extent compute;
+//  (2) contour keys with their row-extent slots -- k_keys;
+//  (3) per-row extremes of every key -- k_extremes;
+// with the background labels and flags read from LDS in (2) and (3) and the key / slot counters
+// kept in LDS.  Same tables, same values (the order of the keys is as arbitrary as before).
 __global__ void __launch_bounds__(FRAME_THREADS)
-k_frame_bg(const u64 *edge, const int *scanb, const int *wl_bg, const int *counters, int *Lb, int *YMb, int *FLb, int *ROWb, int h,
-           int w, int run_cap, int lds_cap, const int *active, int *fallback) {
+k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, int4 *keys, int *bigkeys, int *medkeys, int2 *rowext,
+                 int h, int w, int key_cap, int slot_cap, int lds_cap, const int *active, int *fallback, long long *prof) {
+    // developer profile (prof != nullptr): wall-clock ticks (10 ns) at the end of every phase, per frame
+    const long long t0 = prof ? wall_clock64() : 0;
+    int pk = 0;
+#define FRAME_PROF() do { if (prof && threadIdx.x == 0) prof[blockIdx.x * 8 + (pk++)] = wall_clock64() - t0; } while (0)
+    const u64 *edge = t.edge;
+    const int *scanb = t.scanb;
+    int *Lb = t.Lb, *YMb = t.YMb, *FLb = t.FLb, *ROWb = t.ROWb;
+    const int run_cap = t.run_cap;
     const int g = blockIdx.x;
     if (active && !active[g]) {
         if (threadIdx.x == 0) fallback[g] = 0;
@@ -264,17 +285,22 @@ k_frame_bg(const u64 *edge, const int *scanb, const int *wl_bg, const int *count
     const int wq = LFD_WQ(w);
     const size_t fo = (size_t)g * h * wq, ro = (size_t)g * run_cap;
     const int nwork = counters[g * C_COUNT + C_NBGW], nrun = counters[g * C_COUNT + C_NRUNB];
-    const bool fits = nrun <= lds_cap;
+    const int nwf = counters[g * C_COUNT + C_NFGW], nrunf = counters[g * C_COUNT + C_NRUNF];
+    const bool fits = nrun <= lds_cap && nrunf <= lds_cap; // (then k_frame_fg took the frame too: FLf is set)
     if (threadIdx.x == 0) fallback[g] = fits ? 0 : 1;
     if (!fits) return;
     extern __shared__ int sm_frame[];
     int *L = sm_frame;
     unsigned *FL = (unsigned *)(sm_frame + FRAME_RUNCAP); // root touches the frame (outside)
     unsigned *HB = FL + FRAME_RUNCAP / 32;               // run touches a 0-run of the next row
+    unsigned *HL = HB + FRAME_RUNCAP / 32;               // run belongs to a hole
+    unsigned *HR = HL + FRAME_RUNCAP / 32;               // run is the root of a hole
     int *YMg = YMb + ro, *ROWg = ROWb + ro;
     const u64 *fb = edge + fo;
     const int *sb = scanb + fo, *wl = wl_bg + fo;
-    for (int i = threadIdx.x; i < (nrun + 31) / 32; i += FRAME_THREADS) { FL[i] = 0u; HB[i] = 0u; }
+    __shared__ int c_slots, c_keys, c_big, c_med, c_ovf;
+    if (threadIdx.x == 0) { c_slots = 0; c_keys = 0; c_big = 0; c_med = 0; c_ovf = 0; }
+    for (int i = threadIdx.x; i < (nrun + 31) / 32; i += FRAME_THREADS) { FL[i] = 0u; HB[i] = 0u; HL[i] = 0u; HR[i] = 0u; }
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) L[i] = i;
     __syncthreads();
     // ---- row of every run; 4-connectivity between rows y and y-1
@@ -329,6 +355,7 @@ k_frame_bg(const u64 *edge, const int *scanb, const int *wl_bg, const int *count
             }
         });
     __syncthreads();
+    FRAME_PROF(); // 0: background merge
     // ---- flatten; outside flag per root
     frame_pipeline<BgWordItem>(
         wl, nwork,
@@ -361,7 +388,8 @@ k_frame_bg(const u64 *edge, const int *scanb, const int *wl_bg, const int *count
             }
         });
     __syncthreads();
-    // ---- last row of every hole
+    FRAME_PROF(); // 1: flatten
+    // ---- last row of every hole; which runs belong to a hole, which are a hole's root
     frame_pipeline<BgWordItem>(
         wl, nwork,
         [&](int idx) {
@@ -381,12 +409,196 @@ k_frame_bg(const u64 *edge, const int *scanb, const int *wl_bg, const int *count
             int n = __popcll(s);
             for (int k = 0; k < n; k++) {
                 int id = t.id0 + k, root = L[id];
-                if (root != id && !((FL[root >> 5] >> (root & 31)) & 1u) && !((HB[id >> 5] >> (id & 31)) & 1u)) atomicMax(&YMg[root], y);
+                if ((FL[root >> 5] >> (root & 31)) & 1u) continue; // outside
+                atomicOr(&HL[id >> 5], 1u << (id & 31));
+                if (root == id) atomicOr(&HR[id >> 5], 1u << (id & 31));
+                else if (!((HB[id >> 5] >> (id & 31)) & 1u)) atomicMax(&YMg[root], y);
             }
         });
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
         int root = L[i];
         Lb[ro + i] = root;
         FLb[ro + i] = (root == i) ? (int)((FL[i >> 5] >> (i & 31)) & 1u) : 0;
+    }
+    // ---- contour keys of the edge components (outer borders): one per root run of an edge component
+    const u64 *cb = t.cand + fo;
+    const int *sf = t.scanf + fo, *wlf = wl_fg + fo;
+    const int *Lfg = t.Lf + ro, *YMfg = t.YMf + ro, *ROWfg = t.ROWf + ro, *FLfg = t.FLf + ro;
+    int *SBfg = t.SBf + ro, *SBbg = t.SBb + ro, *PAbg = t.PAb + ro;
+    int4 *kg = keys + (size_t)g * key_cap;
+    int2 *re = rowext + (size_t)g * slot_cap;
+    auto new_key = [&](int id, int ymin, int extent, bool hole) -> int { // slot base, or -1
+        int base = atomicAdd(&c_slots, extent);
+        int ki = atomicAdd(&c_keys, 1);
+        if (base + extent > slot_cap || ki >= key_cap) {
+            c_ovf = 1;
+            return -1;
+        }
+        kg[ki] = make_int4(id, extent | (hole ? KEY_HOLE_BIT : 0), ymin, base);
+        if (extent > BIG_KEY_ROWS) bigkeys[(size_t)g * key_cap + atomicAdd(&c_big, 1)] = ki;
+        else if (extent > SMALL_KEY_ROWS) medkeys[(size_t)g * key_cap + atomicAdd(&c_med, 1)] = ki;
+        for (int r = 0; r < extent; r++) re[base + r] = make_int2(0x7fffffff, -1);
+        return base;
+    };
+    for (int i = threadIdx.x; i < nrunf; i += FRAME_THREADS) {
+        if (Lfg[i] != i || !FLfg[i]) continue;
+        int y0 = ROWfg[i];
+        SBfg[i] = new_key(i, y0, YMfg[i] - y0 + 1, false);
+    }
+    __syncthreads(); // hole extents (memory-side atomics), SBf and the hole bits are complete; L is dead
+    FRAME_PROF(); // 2: hole extents, write-out, outer keys
+    // ---- RS[i]: row-extent slot of candidate run i in its component's key (the L table's LDS is reused)
+    int *RS = L;
+    for (int i0 = threadIdx.x; i0 < nrunf; i0 += 4 * FRAME_THREADS) {
+        int A[4], r[4], sbA[4], rA[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int i = i0 + k * FRAME_THREADS;
+            A[k] = i < nrunf ? Lfg[i] : 0;
+            r[k] = i < nrunf ? ROWfg[i] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int i = i0 + k * FRAME_THREADS;
+            sbA[k] = i < nrunf ? SBfg[A[k]] : -1;
+            rA[k] = i < nrunf ? ROWfg[A[k]] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int i = i0 + k * FRAME_THREADS;
+            if (i < nrunf) RS[i] = sbA[k] >= 0 ? sbA[k] + r[k] - rA[k] : -1; // (only edge runs are ever looked up)
+        }
+    }
+    // ---- hole keys: border rows run from the row above a hole's first pixel to the row below its last;
+    // its surrounding component is that of the (edge) pixel right above the first pixel
+    frame_pipeline<KeyBgItem>(
+        wl, nwork,
+        [&](int idx) {
+            KeyBgItem k;
+            int y = idx / wq, q = idx - y * wq;
+            k.idx = idx;
+            k.e = fb[idx];
+            k.ep = q > 0 ? fb[idx - 1] : ~0ull;
+            k.id0 = sb[idx];
+            k.cu = 0; k.cup = 0; k.idcu = 0;
+            if (y > 0) {
+                k.cu = cb[idx - wq];
+                k.cup = q > 0 ? cb[idx - wq - 1] : 0ull;
+                k.idcu = sf[idx - wq];
+            }
+            return k;
+        },
+        [&](const KeyBgItem &k) {
+            int y = k.idx / wq, q = k.idx - y * wq;
+            u64 vmask = valid_mask(q, w);
+            u64 z = ~k.e & vmask;
+            u64 s = z & ~((z << 1) | ((~k.ep) >> 63));
+            int id = k.id0;
+            for (; s; id++) {
+                int b = __ffsll((long long)s) - 1;
+                s &= s - 1;
+                if (id >= run_cap || !((HR[id >> 5] >> (id & 31)) & 1u)) continue;
+                int ymax = __hip_atomic_load(&YMg[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u64 cu = k.cu & vmask;
+                u64 scu = cu & ~((cu << 1) | (k.cup >> 63));
+                int parent = Lfg[k.idcu + __popcll(scu & upto_bit(b)) - 1];
+                int base = new_key(id, y - 1, ymax - y + 3, true);
+                SBbg[id] = base;
+                if (base >= 0) PAbg[id] = parent;
+            }
+        });
+    __syncthreads(); // RS, SBb / PAb of this frame are written
+    FRAME_PROF(); // 3: slot table, hole keys
+    // ---- per-row extremes: every edge run widens its component's outer-border key, and the
+    // hole-border key of every hole it is 4-adjacent to (if its component surrounds that hole)
+    const int *ROWbg = ROWb + ro, *Lbg = Lb + ro;
+    auto hole_update = [&](int bid, int fid, int y, int xa, int xb) {
+        if (!((HL[bid >> 5] >> (bid & 31)) & 1u)) return; // a run of the outside
+        int B = Lbg[bid], A = Lfg[fid];
+        if (PAbg[B] == A && SBbg[B] >= 0) slot_update(re, SBbg[B] + (y - (ROWbg[B] - 1)), xa, xb);
+    };
+    frame_pipeline<ExtItem>(
+        wlf, nwf,
+        [&](int idx) {
+            ExtItem k;
+            int y = idx / wq, q = idx - y * wq;
+            k.idx = idx;
+            k.e = fb[idx];
+            k.ep = q > 0 ? fb[idx - 1] : ~0ull; // "edge" left of column 0: no background run continues from there
+            k.en = q + 1 < wq ? fb[idx + 1] : 0ull;
+            k.c = cb[idx];
+            k.cp = q > 0 ? cb[idx - 1] : 0ull;
+            k.id0 = sf[idx];
+            k.sbc = sb[idx];
+            k.u = ~0ull; k.up = ~0ull; k.sbu = 0; k.d = ~0ull; k.dp = ~0ull; k.sbd = 0;
+            if (y > 0) {
+                k.u = fb[idx - wq];
+                if (q > 0) k.up = fb[idx - wq - 1];
+                k.sbu = sb[idx - wq];
+            }
+            if (y + 1 < h) {
+                k.d = fb[idx + wq];
+                if (q > 0) k.dp = fb[idx + wq - 1];
+                k.sbd = sb[idx + wq];
+            }
+            return k;
+        },
+        [&](const ExtItem &k) {
+            int y = k.idx / wq, q = k.idx - y * wq;
+            u64 vmask = valid_mask(q, w);
+            u64 e = k.e & vmask, c = k.c & vmask;
+            u64 epe = q > 0 ? k.ep : 0ull; // edge bits of the previous word (none left of column 0)
+            u64 se = e & ~((e << 1) | (epe >> 63)), sc = c & ~((c << 1) | (k.cp >> 63));
+            u64 z = ~e & vmask;
+            u64 s0 = z & ~((z << 1) | ((~k.ep) >> 63)); // 0-run starts of this word
+            // Every maximal stretch of edge pixels INSIDE this word is handled here, whether or not its
+            // run started in an earlier word or goes on in the next one: the slot updates are min / max,
+            // so the pieces of a run add up to the run, and no lane ever walks across words.
+            u64 rem = e;
+            while (rem) {
+                int b = __ffsll((long long)rem) - 1;
+                u64 inv = ~(e >> b);
+                int len = inv ? (__ffsll((long long)inv) - 1) : (64 - b);
+                u64 seg = (len >= 64 ? ~0ull : ((1ull << len) - 1)) << b;
+                rem &= ~seg;
+                int xs = (q << 6) + b, xe = xs + len - 1;
+                int fid = k.id0 + __popcll(sc & upto_bit(b)) - 1; // a stretch continuing from the previous word: id0 - 1
+                if (fid < 0 || fid >= nrunf) continue;
+                int slot = RS[fid];
+                if (slot >= 0) slot_update(re, slot, xs, xe);
+                // same-row neighbours: the 0-pixel before the run and the one after it
+                bool starts = (se >> b) & 1ull;
+                bool ends = (b + len < 64) || q + 1 >= wq || !(k.en & 1ull);
+                if (starts && xs > 0) hole_update(b ? k.sbc + __popcll(s0 & upto_bit(b - 1)) - 1 : k.sbc - 1, fid, y, xs, xs);
+                if (ends && xe < w - 1)
+                    hole_update((b + len < 64) ? k.sbc + __popcll(s0 & upto_bit(b + len)) - 1 : k.sbc + __popcll(s0), fid, y, xe, xe);
+                // rows above and below: 0-runs overlapping [xs, xe]
+                for (int dy = -1; dy <= 1; dy += 2) {
+                    int yy = y + dy;
+                    if (yy < 0 || yy >= h) continue;
+                    u64 ow = dy < 0 ? k.u : k.d, owp = dy < 0 ? k.up : k.dp;
+                    int sbo = dy < 0 ? k.sbu : k.sbd;
+                    u64 zz = ~ow & vmask;
+                    u64 s0o = zz & ~((zz << 1) | ((~owp) >> 63));
+                    u64 ov = zz & seg;
+                    while (ov) {
+                        int bx = __ffsll((long long)ov) - 1;
+                        u64 inv2 = ~(ov >> bx);
+                        int l2 = inv2 ? (__ffsll((long long)inv2) - 1) : (64 - bx);
+                        hole_update(sbo + __popcll(s0o & upto_bit(bx)) - 1, fid, y, (q << 6) + bx, (q << 6) + bx + l2 - 1);
+                        ov &= ~((l2 >= 64 ? ~0ull : ((1ull << l2) - 1)) << bx);
+                    }
+                }
+            }
+        });
+    __syncthreads();
+    FRAME_PROF(); // 4: extremes
+    if (threadIdx.x == 0) {
+        int *cnt = counters + g * C_COUNT;
+        cnt[C_NSLOTS] = c_slots;
+        cnt[C_NKEYS] = c_keys < key_cap ? c_keys : key_cap;
+        cnt[C_NBIG] = c_big;
+        cnt[C_NMED] = c_med;
+        if (c_ovf) cnt[C_OVERFLOW] = 1;
     }
 }

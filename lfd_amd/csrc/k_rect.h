@@ -20,6 +20,7 @@ struct RunTabs {
     const u64 *cand, *edge;          // bit rows (edge runs are candidate runs: fg ids come from cand)
     const int *scanf, *scanb;        // per-word exclusive run counts
     int *Lf, *YMf, *SBf, *ROWf;      // edge-run labels, last row / slot base per root, row per run
+    const int *FLf;                  // root of an edge component (candidate component holding a strong pixel)
     int *Lb, *YMb, *FLb, *SBb, *PAb, *ROWb; // background runs: label, last row, outside flag, slot base, parent, row
     int run_cap;
 };

@@ -16,10 +16,10 @@
 #include "../../include/lfdmi.h"
 #include "common.h"
 #include "k_ccl.h"
-#include "k_frame.h"
 #include "k_hough.h"
 #include "k_image.h"
 #include "k_rect.h"
+#include "k_frame.h"
 
 #define LFD_PI 3.1415926535897932384626433832795
 #define MAX_ANGLES 4096 // rows of the cos/sin table (theta >= pi/4096)
@@ -66,6 +66,7 @@ struct lfdmi_ctx {
     u64 *peaks = nullptr;
     float *lines = nullptr, *tab = nullptr;
     int *counters = nullptr, *need_dim = nullptr;
+    long long *prof = nullptr;         // LFDMI_FRAME_PROFILE=1: per-frame phase clocks of k_frame_contours (developer tool)
     int *fb_fg = nullptr, *fb_bg = nullptr; // per slot: frame left to the multi-workgroup run kernels (k_frame.h)
     lfdmi_result *res_dev = nullptr;
     void *stage = nullptr;
@@ -207,6 +208,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     for (int **p : {&ctx->Lf, &ctx->YMf, &ctx->FLf, &ctx->Lb, &ctx->YMb, &ctx->FLb, &ctx->SBf, &ctx->SBb, &ctx->PAb,
                     &ctx->ROWf, &ctx->ROWb})
         RET(dmalloc(ctx, p, G * ctx->run_cap));
+    if (getenv("LFDMI_FRAME_PROFILE")) RET(dmalloc(ctx, &ctx->prof, G * 8));
     RET(dmalloc(ctx, &ctx->fb_fg, G));
     RET(dmalloc(ctx, &ctx->fb_bg, G));
     RET(dmalloc(ctx, &ctx->scanf_, G * BW));
@@ -239,7 +241,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     HIPCHK(hipFuncSetAttribute((const void *)k_rects_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_dilate_canny_v, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_frame_fg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    HIPCHK(hipFuncSetAttribute((const void *)k_frame_bg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_frame_contours, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     return 0;
@@ -416,7 +418,7 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
         Span sp(ctx, KID_FRAME_FG);
         size_t lds = (size_t)(FRAME_RUNCAP + 2 * (FRAME_RUNCAP / 32)) * sizeof(int);
         k_frame_fg<<<nc, FRAME_THREADS, lds, ctx->stream>>>(ctx->candb, ctx->strongb, ctx->scanf_, ctx->wl_fg, ctx->counters, ctx->Lf,
-                                                            ctx->YMf, ctx->ROWf, ctx->edgeb, h, w, rc, ctx->frame_runcap, active, ctx->fb_fg);
+                                                            ctx->YMf, ctx->FLf, ctx->ROWf, ctx->edgeb, h, w, rc, ctx->frame_runcap, active, ctx->fb_fg);
         KCHK("k_frame_fg");
         active = ctx->fb_fg;
     }
@@ -489,13 +491,19 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
       k_scan_runs<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->scanb_, ctx->counters, C_NRUNB, h, w, rc, nullptr, nullptr,
                                                         ctx->boxb, active);
       KCHK("k_scan_runs(bg)"); }
+    RunTabs rt;
+    rt.cand = ctx->candb; rt.edge = ctx->edgeb; rt.scanf = ctx->scanf_; rt.scanb = ctx->scanb_;
+    rt.Lf = ctx->Lf; rt.YMf = ctx->YMf; rt.SBf = ctx->SBf; rt.ROWf = ctx->ROWf; rt.FLf = ctx->FLf;
+    rt.Lb = ctx->Lb; rt.YMb = ctx->YMb; rt.FLb = ctx->FLb; rt.SBb = ctx->SBb; rt.PAb = ctx->PAb; rt.ROWb = ctx->ROWb;
+    rt.run_cap = rc;
     const int *gen = active; // frames for the general run kernels
     if (ctx->frame_ccl) {
         Span sp(ctx, KID_FRAME_BG);
-        size_t lds = (size_t)(FRAME_RUNCAP + 2 * (FRAME_RUNCAP / 32)) * sizeof(int);
-        k_frame_bg<<<nc, FRAME_THREADS, lds, ctx->stream>>>(ctx->edgeb, ctx->scanb_, ctx->wl_bg, ctx->counters, ctx->Lb, ctx->YMb,
-                                                            ctx->FLb, ctx->ROWb, h, w, rc, ctx->frame_runcap, active, ctx->fb_bg);
-        KCHK("k_frame_bg");
+        size_t lds = (size_t)(FRAME_RUNCAP + 4 * (FRAME_RUNCAP / 32)) * sizeof(int);
+        k_frame_contours<<<nc, FRAME_THREADS, lds, ctx->stream>>>(rt, ctx->wl_fg, ctx->wl_bg, ctx->counters, ctx->keys, ctx->bigkeys,
+                                                                  ctx->medkeys, ctx->rowext, h, w, ctx->key_cap, ctx->slot_cap,
+                                                                  ctx->frame_runcap, active, ctx->fb_bg, ctx->prof);
+        KCHK("k_frame_contours");
         gen = ctx->fb_bg;
     }
     { Span sp(ctx, KID_RUNS_INIT_BG);
@@ -512,17 +520,12 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
       k_bg_extent<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, ctx->scanb_, ctx->Lb, ctx->YMb, ctx->FLb, h, w, rc, ctx->wl_bg,
                                                ctx->counters, C_NBGW, gen);
       KCHK("k_bg_extent"); }
-    RunTabs rt;
-    rt.cand = ctx->candb; rt.edge = ctx->edgeb; rt.scanf = ctx->scanf_; rt.scanb = ctx->scanb_;
-    rt.Lf = ctx->Lf; rt.YMf = ctx->YMf; rt.SBf = ctx->SBf; rt.ROWf = ctx->ROWf;
-    rt.Lb = ctx->Lb; rt.YMb = ctx->YMb; rt.FLb = ctx->FLb; rt.SBb = ctx->SBb; rt.PAb = ctx->PAb; rt.ROWb = ctx->ROWb;
-    rt.run_cap = rc;
     { Span sp(ctx, KID_KEYS);
     k_keys<<<lg, 256, 0, ctx->stream>>>(rt, ctx->keys, ctx->bigkeys, ctx->medkeys, ctx->rowext, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap,
-                                         ctx->wl_fg, ctx->wl_bg, active);
+                                         ctx->wl_fg, ctx->wl_bg, gen);
     KCHK("k_keys"); }
     { Span sp(ctx, KID_EXTREMES);
-    k_extremes<<<lg, 256, 0, ctx->stream>>>(rt, ctx->rowext, h, w, ctx->slot_cap, ctx->wl_fg, ctx->counters, active);
+    k_extremes<<<lg, 256, 0, ctx->stream>>>(rt, ctx->rowext, h, w, ctx->slot_cap, ctx->wl_fg, ctx->counters, gen);
     KCHK("k_extremes"); }
     { Span sp(ctx, KID_RECTS);
     k_rects<<<dim3(32, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, ctx->hullbuf, ctx->quads, ctx->counters, h, w,
@@ -1024,6 +1027,14 @@ extern "C" int lfdmi_get_counters(lfdmi_ctx *ctx, int slot0, int n, int32_t *dst
     static_assert(C_COUNT == LFDMI_COUNTERS, "counter layout");
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(dst, ctx->counters + (size_t)slot0 * C_COUNT, (size_t)n * C_COUNT * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// developer tool, not part of include/lfdmi.h: phase clocks of the last k_frame_contours launch
+extern "C" int lfdmi_debug_frame_profile(lfdmi_ctx *ctx, int n, long long *dst) {
+    if (!ctx || !ctx->prof || n < 0 || n > ctx->G) return LFDMI_ERR_ARG;
+    HIPCHK(hipMemcpyAsync(dst, ctx->prof, (size_t)n * 8 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
