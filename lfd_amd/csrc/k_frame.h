@@ -20,6 +20,7 @@
 #include "k_rect.h"
 
 #define FRAME_THREADS 1024
+#define FRAME_HOLECAP 1024 // hash slots for the holes of a frame (more holes: looked up in the global tables)
 #define FRAME_RUNCAP 32768 // runs per frame the LDS label table holds (128 KB); busier frames take the k_ccl.h kernels
 
 __device__ __forceinline__ int lds_find(const int *L, int x) {
@@ -268,7 +269,7 @@ struct ExtItem { int idx, id0, sbc, sbu, sbd; u64 e, ep, en, c, cp, u, up, d, dp
 // kept in LDS.  Same tables, same values (the order of the keys is as arbitrary as before).
 __global__ void __launch_bounds__(FRAME_THREADS)
 k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, int4 *keys, int *bigkeys, int *medkeys, int2 *rowext,
-                 int h, int w, int key_cap, int slot_cap, int lds_cap, const int *active, int *fallback, long long *prof) {
+                 int2 *rsa, int h, int w, int key_cap, int slot_cap, int lds_cap, const int *active, int *fallback, long long *prof) {
     // developer profile (prof != nullptr): wall-clock ticks (10 ns) at the end of every phase, per frame
     const long long t0 = prof ? wall_clock64() : 0;
     int pk = 0;
@@ -298,8 +299,12 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
     int *YMg = YMb + ro, *ROWg = ROWb + ro;
     const u64 *fb = edge + fo;
     const int *sb = scanb + fo, *wl = wl_bg + fo;
-    __shared__ int c_slots, c_keys, c_big, c_med, c_ovf;
-    if (threadIdx.x == 0) { c_slots = 0; c_keys = 0; c_big = 0; c_med = 0; c_ovf = 0; }
+    __shared__ int c_slots, c_keys, c_big, c_med, c_ovf, c_hovf;
+    // holes of the frame, keyed by their root run: (slot of border row 0 minus that row, surrounding component)
+    __shared__ int hkey[FRAME_HOLECAP];
+    __shared__ int2 hval[FRAME_HOLECAP];
+    if (threadIdx.x == 0) { c_slots = 0; c_keys = 0; c_big = 0; c_med = 0; c_ovf = 0; c_hovf = 0; }
+    for (int i = threadIdx.x; i < FRAME_HOLECAP; i += FRAME_THREADS) hkey[i] = -1;
     for (int i = threadIdx.x; i < (nrun + 31) / 32; i += FRAME_THREADS) { FL[i] = 0u; HB[i] = 0u; HL[i] = 0u; HR[i] = 0u; }
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) L[i] = i;
     __syncthreads();
@@ -445,10 +450,11 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
         int y0 = ROWfg[i];
         SBfg[i] = new_key(i, y0, YMfg[i] - y0 + 1, false);
     }
-    __syncthreads(); // hole extents (memory-side atomics), SBf and the hole bits are complete; L is dead
+    __syncthreads(); // hole extents (memory-side atomics), SBf and the hole bits are complete
     FRAME_PROF(); // 2: hole extents, write-out, outer keys
-    // ---- RS[i]: row-extent slot of candidate run i in its component's key (the L table's LDS is reused)
-    int *RS = L;
+    // ---- rsa[i] = (row-extent slot of candidate run i in its component's key, that component): one load
+    // per edge stretch later instead of a chain through Lf / SBf / ROWf
+    int2 *RSA = rsa + (size_t)g * FRAME_RUNCAP;
     for (int i0 = threadIdx.x; i0 < nrunf; i0 += 4 * FRAME_THREADS) {
         int A[4], r[4], sbA[4], rA[4];
 #pragma unroll
@@ -466,7 +472,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             int i = i0 + k * FRAME_THREADS;
-            if (i < nrunf) RS[i] = sbA[k] >= 0 ? sbA[k] + r[k] - rA[k] : -1; // (only edge runs are ever looked up)
+            if (i < nrunf) RSA[i] = make_int2(sbA[k] >= 0 ? sbA[k] + r[k] - rA[k] : -1, A[k]); // (only edge runs are ever looked up)
         }
     }
     // ---- hole keys: border rows run from the row above a hole's first pixel to the row below its last;
@@ -505,17 +511,54 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
                 int base = new_key(id, y - 1, ymax - y + 3, true);
                 SBbg[id] = base;
                 if (base >= 0) PAbg[id] = parent;
+                // border row yy of this hole lives in slot base + (yy - (y - 1))
+                unsigned hs = ((unsigned)id * 2654435761u) >> 22; // 10 bits
+                bool put = false;
+                for (int probe = 0; probe < 16 && !put; probe++, hs = (hs + 1) & (FRAME_HOLECAP - 1))
+                    if (atomicCAS(&hkey[hs], -1, id) == -1) {
+                        hval[hs] = make_int2(base >= 0 ? base - (y - 1) : INT_MIN, parent);
+                        put = true;
+                    }
+                if (!put) c_hovf = 1;
             }
         });
-    __syncthreads(); // RS, SBb / PAb of this frame are written
+    __syncthreads(); // rsa, the hole table, SBb / PAb of this frame are written
     FRAME_PROF(); // 3: slot table, hole keys
     // ---- per-row extremes: every edge run widens its component's outer-border key, and the
     // hole-border key of every hole it is 4-adjacent to (if its component surrounds that hole)
-    const int *ROWbg = ROWb + ro, *Lbg = Lb + ro;
-    auto hole_update = [&](int bid, int fid, int y, int xa, int xb) {
+    const int *ROWbg = ROWb + ro;
+    const bool hovf = c_hovf != 0;
+    // Slot updates are min / max, so consecutive updates of one slot are merged in registers and sent as
+    // one atomic pair: a word's stretches mostly widen the same outer-border row and the same hole
+    // (the inside of their own ring); the memory-side atomics are what this phase is short of.
+    struct SlotAcc { int slot, lo, hi; };
+    auto acc_flush = [&](SlotAcc &a) {
+        if (a.slot >= 0) slot_update(re, a.slot, a.lo, a.hi);
+        a.slot = -1;
+    };
+    auto acc_add = [&](SlotAcc &a, int slot, int xa, int xb) {
+        if (slot == a.slot) {
+            a.lo = min(a.lo, xa);
+            a.hi = max(a.hi, xb);
+            return;
+        }
+        acc_flush(a);
+        a.slot = slot; a.lo = xa; a.hi = xb;
+    };
+    auto hole_update = [&](SlotAcc &acc, int bid, int A, int y, int xa, int xb) {
         if (!((HL[bid >> 5] >> (bid & 31)) & 1u)) return; // a run of the outside
-        int B = Lbg[bid], A = Lfg[fid];
-        if (PAbg[B] == A && SBbg[B] >= 0) slot_update(re, SBbg[B] + (y - (ROWbg[B] - 1)), xa, xb);
+        int B = L[bid];
+        unsigned hs = ((unsigned)B * 2654435761u) >> 22;
+        for (int probe = 0; probe < 16; probe++, hs = (hs + 1) & (FRAME_HOLECAP - 1)) {
+            int kk = hkey[hs];
+            if (kk == B) {
+                int2 v = hval[hs];
+                if (v.y == A && v.x != INT_MIN) acc_add(acc, v.x + y, xa, xb);
+                return;
+            }
+            if (kk == -1) break;
+        }
+        if (hovf && PAbg[B] == A && SBbg[B] >= 0) acc_add(acc, SBbg[B] + (y - (ROWbg[B] - 1)), xa, xb); // table was full
     };
     frame_pipeline<ExtItem>(
         wlf, nwf,
@@ -554,6 +597,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
             // Every maximal stretch of edge pixels INSIDE this word is handled here, whether or not its
             // run started in an earlier word or goes on in the next one: the slot updates are min / max,
             // so the pieces of a run add up to the run, and no lane ever walks across words.
+            SlotAcc outer = {-1, 0, 0}, hole = {-1, 0, 0};
             u64 rem = e;
             while (rem) {
                 int b = __ffsll((long long)rem) - 1;
@@ -564,14 +608,15 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
                 int xs = (q << 6) + b, xe = xs + len - 1;
                 int fid = k.id0 + __popcll(sc & upto_bit(b)) - 1; // a stretch continuing from the previous word: id0 - 1
                 if (fid < 0 || fid >= nrunf) continue;
-                int slot = RS[fid];
-                if (slot >= 0) slot_update(re, slot, xs, xe);
+                int2 ra = RSA[fid];
+                const int slot = ra.x, A = ra.y;
+                if (slot >= 0) acc_add(outer, slot, xs, xe);
                 // same-row neighbours: the 0-pixel before the run and the one after it
                 bool starts = (se >> b) & 1ull;
                 bool ends = (b + len < 64) || q + 1 >= wq || !(k.en & 1ull);
-                if (starts && xs > 0) hole_update(b ? k.sbc + __popcll(s0 & upto_bit(b - 1)) - 1 : k.sbc - 1, fid, y, xs, xs);
+                if (starts && xs > 0) hole_update(hole, b ? k.sbc + __popcll(s0 & upto_bit(b - 1)) - 1 : k.sbc - 1, A, y, xs, xs);
                 if (ends && xe < w - 1)
-                    hole_update((b + len < 64) ? k.sbc + __popcll(s0 & upto_bit(b + len)) - 1 : k.sbc + __popcll(s0), fid, y, xe, xe);
+                    hole_update(hole, (b + len < 64) ? k.sbc + __popcll(s0 & upto_bit(b + len)) - 1 : k.sbc + __popcll(s0), A, y, xe, xe);
                 // rows above and below: 0-runs overlapping [xs, xe]
                 for (int dy = -1; dy <= 1; dy += 2) {
                     int yy = y + dy;
@@ -585,11 +630,13 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
                         int bx = __ffsll((long long)ov) - 1;
                         u64 inv2 = ~(ov >> bx);
                         int l2 = inv2 ? (__ffsll((long long)inv2) - 1) : (64 - bx);
-                        hole_update(sbo + __popcll(s0o & upto_bit(bx)) - 1, fid, y, (q << 6) + bx, (q << 6) + bx + l2 - 1);
+                        hole_update(hole, sbo + __popcll(s0o & upto_bit(bx)) - 1, A, y, (q << 6) + bx, (q << 6) + bx + l2 - 1);
                         ov &= ~((l2 >= 64 ? ~0ull : ((1ull << l2) - 1)) << bx);
                     }
                 }
             }
+            acc_flush(outer);
+            acc_flush(hole);
         });
     __syncthreads();
     FRAME_PROF(); // 4: extremes

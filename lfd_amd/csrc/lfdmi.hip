@@ -66,6 +66,7 @@ struct lfdmi_ctx {
     u64 *peaks = nullptr;
     float *lines = nullptr, *tab = nullptr;
     int *counters = nullptr, *need_dim = nullptr;
+    int2 *rsa = nullptr;               // k_frame_contours: (row slot, component) per candidate run, FRAME_RUNCAP per slot
     long long *prof = nullptr;         // LFDMI_FRAME_PROFILE=1: per-frame phase clocks of k_frame_contours (developer tool)
     int *fb_fg = nullptr, *fb_bg = nullptr; // per slot: frame left to the multi-workgroup run kernels (k_frame.h)
     lfdmi_result *res_dev = nullptr;
@@ -209,6 +210,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
                     &ctx->ROWf, &ctx->ROWb})
         RET(dmalloc(ctx, p, G * ctx->run_cap));
     if (getenv("LFDMI_FRAME_PROFILE")) RET(dmalloc(ctx, &ctx->prof, G * 8));
+    RET(dmalloc(ctx, &ctx->rsa, G * FRAME_RUNCAP));
     RET(dmalloc(ctx, &ctx->fb_fg, G));
     RET(dmalloc(ctx, &ctx->fb_bg, G));
     RET(dmalloc(ctx, &ctx->scanf_, G * BW));
@@ -241,7 +243,8 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     HIPCHK(hipFuncSetAttribute((const void *)k_rects_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_dilate_canny_v, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_frame_fg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    HIPCHK(hipFuncSetAttribute((const void *)k_frame_contours, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_frame_contours, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (FRAME_RUNCAP + 4 * (FRAME_RUNCAP / 32)) * (int)sizeof(int)));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     return 0;
@@ -501,7 +504,7 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
         Span sp(ctx, KID_FRAME_BG);
         size_t lds = (size_t)(FRAME_RUNCAP + 4 * (FRAME_RUNCAP / 32)) * sizeof(int);
         k_frame_contours<<<nc, FRAME_THREADS, lds, ctx->stream>>>(rt, ctx->wl_fg, ctx->wl_bg, ctx->counters, ctx->keys, ctx->bigkeys,
-                                                                  ctx->medkeys, ctx->rowext, h, w, ctx->key_cap, ctx->slot_cap,
+                                                                  ctx->medkeys, ctx->rowext, ctx->rsa, h, w, ctx->key_cap, ctx->slot_cap,
                                                                   ctx->frame_runcap, active, ctx->fb_bg, ctx->prof);
         KCHK("k_frame_contours");
         gen = ctx->fb_bg;
