@@ -254,6 +254,12 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
 struct BgMergeItem { int idx, id0, idu, first, firstu; u64 c, cp, u, up, r0, u0; };
 struct BgWordItem { int idx, id0, lastid; u64 c, cp, rl; };
 
+// position of the k-th (0-based) set bit of s
+__device__ __forceinline__ int hole_bit(u64 s, int k) {
+    for (; k > 0; k--) s &= s - 1;
+    return __ffsll((long long)s) - 1;
+}
+
 struct KeyFgItem { int idx, id0; u64 e, ep, c, cp; };
 struct KeyBgItem { int idx, id0, idcu; u64 e, ep, cu, cup; };
 struct ExtItem { int idx, id0, sbc, sbu, sbd; u64 e, ep, en, c, cp, u, up, d, dp; };
@@ -297,6 +303,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
     unsigned *HL = HB + FRAME_RUNCAP / 32;               // run belongs to a hole
     unsigned *HR = HL + FRAME_RUNCAP / 32;               // run is the root of a hole
     int *YMg = YMb + ro, *ROWg = ROWb + ro;
+    int *XSg = t.PAb + ro; // scratch until the hole keys are made: PAb[root] = first column of the hole
     const u64 *fb = edge + fo;
     const int *sb = scanb + fo, *wl = wl_bg + fo;
     __shared__ int c_slots, c_keys, c_big, c_med, c_ovf, c_hovf;
@@ -416,15 +423,19 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
                 int id = t.id0 + k, root = L[id];
                 if ((FL[root >> 5] >> (root & 31)) & 1u) continue; // outside
                 atomicOr(&HL[id >> 5], 1u << (id & 31));
-                if (root == id) atomicOr(&HR[id >> 5], 1u << (id & 31));
-                else if (!((HB[id >> 5] >> (id & 31)) & 1u)) atomicMax(&YMg[root], y);
+                if (root == id) {
+                    atomicOr(&HR[id >> 5], 1u << (id & 31));
+                    XSg[id] = (q << 6) + hole_bit(s, k); // column of the hole's raster-first pixel
+                } else if (!((HB[id >> 5] >> (id & 31)) & 1u)) atomicMax(&YMg[root], y);
             }
         });
+    if (prof) { __syncthreads(); FRAME_PROF(); } // 2: hole extents
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
         int root = L[i];
         Lb[ro + i] = root;
         FLb[ro + i] = (root == i) ? (int)((FL[i >> 5] >> (i & 31)) & 1u) : 0;
     }
+    if (prof) { __syncthreads(); FRAME_PROF(); } // 3: write-out
     // ---- contour keys of the edge components (outer borders): one per root run of an edge component
     const u64 *cb = t.cand + fo;
     const int *sf = t.scanf + fo, *wlf = wl_fg + fo;
@@ -442,16 +453,28 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
         kg[ki] = make_int4(id, extent | (hole ? KEY_HOLE_BIT : 0), ymin, base);
         if (extent > BIG_KEY_ROWS) bigkeys[(size_t)g * key_cap + atomicAdd(&c_big, 1)] = ki;
         else if (extent > SMALL_KEY_ROWS) medkeys[(size_t)g * key_cap + atomicAdd(&c_med, 1)] = ki;
-        for (int r = 0; r < extent; r++) re[base + r] = make_int2(0x7fffffff, -1);
-        return base;
+        return base; // the slots themselves are initialised by the whole workgroup, see below
     };
-    for (int i = threadIdx.x; i < nrunf; i += FRAME_THREADS) {
-        if (Lfg[i] != i || !FLfg[i]) continue;
-        int y0 = ROWfg[i];
-        SBfg[i] = new_key(i, y0, YMfg[i] - y0 + 1, false);
+    for (int i0 = threadIdx.x; i0 < nrunf; i0 += 4 * FRAME_THREADS) { // four independent loads in flight per lane
+        int lf[4], fl[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int i = i0 + k * FRAME_THREADS;
+            lf[k] = i < nrunf ? Lfg[i] : -1;
+            fl[k] = i < nrunf ? FLfg[i] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int i = i0 + k * FRAME_THREADS;
+            if (lf[k] != i || !fl[k]) continue;
+            int y0 = ROWfg[i];
+            SBfg[i] = new_key(i, y0, YMfg[i] - y0 + 1, false);
+        }
     }
     __syncthreads(); // hole extents (memory-side atomics), SBf and the hole bits are complete
-    FRAME_PROF(); // 2: hole extents, write-out, outer keys
+    const int n_outer_slots = min(c_slots, slot_cap);
+    for (int i = threadIdx.x; i < n_outer_slots; i += FRAME_THREADS) re[i] = make_int2(0x7fffffff, -1);
+    FRAME_PROF(); // 4: outer keys
     // ---- rsa[i] = (row-extent slot of candidate run i in its component's key, that component): one load
     // per edge stretch later instead of a chain through Lf / SBf / ROWf
     int2 *RSA = rsa + (size_t)g * FRAME_RUNCAP;
@@ -475,55 +498,36 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
             if (i < nrunf) RSA[i] = make_int2(sbA[k] >= 0 ? sbA[k] + r[k] - rA[k] : -1, A[k]); // (only edge runs are ever looked up)
         }
     }
+    if (prof) { __syncthreads(); FRAME_PROF(); } // 5: slot table
     // ---- hole keys: border rows run from the row above a hole's first pixel to the row below its last;
-    // its surrounding component is that of the (edge) pixel right above the first pixel
-    frame_pipeline<KeyBgItem>(
-        wl, nwork,
-        [&](int idx) {
-            KeyBgItem k;
-            int y = idx / wq, q = idx - y * wq;
-            k.idx = idx;
-            k.e = fb[idx];
-            k.ep = q > 0 ? fb[idx - 1] : ~0ull;
-            k.id0 = sb[idx];
-            k.cu = 0; k.cup = 0; k.idcu = 0;
-            if (y > 0) {
-                k.cu = cb[idx - wq];
-                k.cup = q > 0 ? cb[idx - wq - 1] : 0ull;
-                k.idcu = sf[idx - wq];
-            }
-            return k;
-        },
-        [&](const KeyBgItem &k) {
-            int y = k.idx / wq, q = k.idx - y * wq;
-            u64 vmask = valid_mask(q, w);
-            u64 z = ~k.e & vmask;
-            u64 s = z & ~((z << 1) | ((~k.ep) >> 63));
-            int id = k.id0;
-            for (; s; id++) {
-                int b = __ffsll((long long)s) - 1;
-                s &= s - 1;
-                if (id >= run_cap || !((HR[id >> 5] >> (id & 31)) & 1u)) continue;
-                int ymax = __hip_atomic_load(&YMg[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                u64 cu = k.cu & vmask;
-                u64 scu = cu & ~((cu << 1) | (k.cup >> 63));
-                int parent = Lfg[k.idcu + __popcll(scu & upto_bit(b)) - 1];
-                int base = new_key(id, y - 1, ymax - y + 3, true);
-                SBbg[id] = base;
-                if (base >= 0) PAbg[id] = parent;
-                // border row yy of this hole lives in slot base + (yy - (y - 1))
-                unsigned hs = ((unsigned)id * 2654435761u) >> 22; // 10 bits
-                bool put = false;
-                for (int probe = 0; probe < 16 && !put; probe++, hs = (hs + 1) & (FRAME_HOLECAP - 1))
-                    if (atomicCAS(&hkey[hs], -1, id) == -1) {
-                        hval[hs] = make_int2(base >= 0 ? base - (y - 1) : INT_MIN, parent);
-                        put = true;
-                    }
-                if (!put) c_hovf = 1;
-            }
-        });
+    // its surrounding component is that of the (edge) pixel right above the first pixel.  One lane per
+    // 32 background runs of the root bitset: only actual holes cost memory round trips.
+    for (int wd = threadIdx.x; wd < (nrun + 31) / 32; wd += FRAME_THREADS) {
+        unsigned bits = HR[wd];
+        while (bits) {
+            int id = (wd << 5) + __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            int y = ROWg[id], x = XSg[id];
+            int ymax = __hip_atomic_load(&YMg[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int parent = Lfg[run_id(sf, cb, y - 1, x, 1, wq, w)];
+            int base = new_key(id, y - 1, ymax - y + 3, true);
+            SBbg[id] = base;
+            PAbg[id] = parent; // (overwrites the scratch column)
+            // border row yy of this hole lives in slot base + (yy - (y - 1))
+            unsigned hs = ((unsigned)id * 2654435761u) >> 22; // 10 bits
+            bool put = false;
+            for (int probe = 0; probe < 16 && !put; probe++, hs = (hs + 1) & (FRAME_HOLECAP - 1))
+                if (atomicCAS(&hkey[hs], -1, id) == -1) {
+                    hval[hs] = make_int2(base >= 0 ? base - (y - 1) : INT_MIN, parent);
+                    put = true;
+                }
+            if (!put) c_hovf = 1;
+        }
+    }
     __syncthreads(); // rsa, the hole table, SBb / PAb of this frame are written
-    FRAME_PROF(); // 3: slot table, hole keys
+    for (int i = n_outer_slots + threadIdx.x; i < min(c_slots, slot_cap); i += FRAME_THREADS) re[i] = make_int2(0x7fffffff, -1);
+    __syncthreads(); // every slot is initialised before the first update
+    FRAME_PROF(); // 6: hole keys
     // ---- per-row extremes: every edge run widens its component's outer-border key, and the
     // hole-border key of every hole it is 4-adjacent to (if its component surrounds that hole)
     const int *ROWbg = ROWb + ro;
@@ -639,7 +643,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
             acc_flush(hole);
         });
     __syncthreads();
-    FRAME_PROF(); // 4: extremes
+    FRAME_PROF(); // 7: extremes
     if (threadIdx.x == 0) {
         int *cnt = counters + g * C_COUNT;
         cnt[C_NSLOTS] = c_slots;
