@@ -260,8 +260,6 @@ __device__ __forceinline__ int hole_bit(u64 s, int k) {
     return __ffsll((long long)s) - 1;
 }
 
-struct KeyFgItem { int idx, id0; u64 e, ep, c, cp; };
-struct KeyBgItem { int idx, id0, idcu; u64 e, ep, cu, cup; };
 struct ExtItem { int idx, id0, sbc, sbu, sbd; u64 e, ep, en, c, cp, u, up, d, dp; };
 
 // Contour topology of one frame's edge image.

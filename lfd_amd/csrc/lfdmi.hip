@@ -45,6 +45,8 @@ struct lfdmi_ctx {
     size_t N = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
+    hipStream_t side[2] = {nullptr, nullptr}; // the tall-key rectangle kernels run beside the short-key one
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     std::string err;
     // dense images
     uint8_t *gray = nullptr, *tmp = nullptr, *equ = nullptr, *lut = nullptr, *mask = nullptr;
@@ -187,6 +189,11 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     size_t N = ctx->N, G = (size_t)max_inflight, BW = (size_t)max_h * ctx->wq;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     ctx->key_cap = (int)(N / 2 + 16);
     ctx->slot_cap = (int)(2 * N + 4 * (size_t)max_h + 16);
     int na, nr;
@@ -259,6 +266,11 @@ extern "C" void lfdmi_ctx_destroy(lfdmi_ctx *ctx) {
     if (ctx->cat_dev) hipFree(ctx->cat_dev);
     for (auto e : ctx->ev_pool) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->side[i]) hipStreamDestroy(ctx->side[i]);
+        if (ctx->ev_join[i]) hipEventDestroy(ctx->ev_join[i]);
+    }
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     delete ctx;
 }
 
@@ -531,20 +543,29 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     k_extremes<<<lg, 256, 0, ctx->stream>>>(rt, ctx->rowext, h, w, ctx->slot_cap, ctx->wl_fg, ctx->counters, gen);
     KCHK("k_extremes"); }
     { Span sp(ctx, KID_RECTS);
+    // Three independent kernels by key height (short: a lane per key; medium / tall: a wave per key).
+    // Each is a handful of long serial hulls, so they run side by side: fork two helper streams off
+    // the launch stream, join before the fill.
+    int cap = h + 2; // rows a key can span (a hole border adds one row above and below)
+    HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0));
+    k_rects_big<<<dim3(32, nc), 64, (size_t)BIG_KEY_ROWS * 4 * sizeof(int2), ctx->side[0]>>>(
+        ctx->keys, ctx->medkeys, C_NMED, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, BIG_KEY_ROWS,
+        minLen, lwTresh, active);
+    KCHK("k_rects_med");
+    HIPCHK(hipEventRecord(ctx->ev_join[0], ctx->side[0]));
+    HIPCHK(hipStreamWaitEvent(ctx->side[1], ctx->ev_fork, 0));
+    k_rects_big<<<dim3(8, nc), 64, (size_t)cap * 4 * sizeof(int2), ctx->side[1]>>>(
+        ctx->keys, ctx->bigkeys, C_NBIG, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, cap,
+        minLen, lwTresh, active);
+    KCHK("k_rects_big");
+    HIPCHK(hipEventRecord(ctx->ev_join[1], ctx->side[1]));
     k_rects<<<dim3(32, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, ctx->hullbuf, ctx->quads, ctx->counters, h, w,
                                                     ctx->key_cap, ctx->slot_cap, minLen, lwTresh, active);
     KCHK("k_rects");
-    {
-        int cap = h + 2; // rows a key can span (a hole border adds one row above and below)
-        k_rects_big<<<dim3(32, nc), 64, (size_t)BIG_KEY_ROWS * 4 * sizeof(int2), ctx->stream>>>(
-            ctx->keys, ctx->medkeys, C_NMED, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, BIG_KEY_ROWS,
-            minLen, lwTresh, active);
-        KCHK("k_rects_med");
-        k_rects_big<<<dim3(8, nc), 64, (size_t)cap * 4 * sizeof(int2), ctx->stream>>>(
-            ctx->keys, ctx->bigkeys, C_NBIG, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, cap,
-            minLen, lwTresh, active);
-        KCHK("k_rects_big");
-    } }
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[1], 0));
+    }
     Span sp(ctx, KID_FILL);
     k_fill_quads<<<dim3(FILL_BLOCKS, nc), 256, 0, ctx->stream>>>(ctx->quads, ctx->counters, ctx->boxb, h, w, ctx->key_cap, active);
     KCHK("k_fill_quads");
