@@ -171,7 +171,7 @@ def main():
             if (c["frames_per_gpu"], c["inflight"], c["lanes"], c["shape"]) == (n, args.inflight, args.lanes, [h, w]):
                 key = {"k_morph(dilate)": "k_morph_rect_v<0>", "k_morph(erode)": "k_morph_rect_v<1>",
                        "k_canny_nms": "k_canny_nms_v", "k_hough_vote": "k_hough_vote<6>",
-                       "k_dilate_canny": "k_dilate_canny_v"}.get(name, name.split("(")[0])
+                       "k_dilate_canny": "k_dilate_canny_w", "k_frame_bg": "k_frame_contours"}.get(name, name.split("(")[0])
                 traffic = tj["kernels"][key]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None
