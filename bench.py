@@ -152,6 +152,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    cnt = det.get_counters()[:n]  # last pass of every slot: Hough cost is 180 votes per non-zero pixel
+    nnz_equ, nnz_box = cnt[:, 3][cnt[:, 8] > 0], cnt[:, 4][cnt[:, 8] > 0]
     found_b = int((res["found"] == 1).sum())
     found_d = int((res["found"] == 2).sum())
     errors = int((res["status"] != 0).sum())
@@ -187,9 +189,12 @@ def main():
                        "frames_per_gpu": n, "inflight": args.inflight, "lanes": args.lanes, "shape": [h, w],
                        "removestars": not args.no_removestars, "parallelism": "frame-parallel x%d" % world,
                        "found_bright": found_b, "found_dim": found_d, "frame_errors": errors,
+                       "hough_nnz_equ_median": int(np.median(nnz_equ)) if len(nnz_equ) else 0,
+                       "hough_nnz_box_median": int(np.median(nnz_box)) if len(nnz_box) else 0,
                        "gen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "frac_of_measured_copy_6290": round(achieved / 6290.0, 5),
                          "avg_launch_ms": round(ms / max(1, launches), 4),
                          "frames_per_launch": round(units / max(1, launches), 2),
                          "algorithmic_bytes_per_frame": bytes_per_frame},

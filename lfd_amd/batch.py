@@ -87,6 +87,10 @@ class BatchDetector:
                 out[k] = (a[0] + ms, a[1] + n, a[2] + u)
         return out
 
+    def get_counters(self):
+        """Work counters ([slots, 16] int32, see lfdmi_get_counters) the last pass left, all lanes."""
+        return np.concatenate([c.get_counters() for c in self.ctxs])
+
     @staticmethod
     def _slice_cat(cat, a, b):
         if cat is None:
