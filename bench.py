@@ -45,6 +45,8 @@ STAGE_BYTES_PER_PX = {
     "k_dilate_canny": 4.0,
     # per-frame LDS connectivity kernels (k_frame.h): same stages as the run kernels they replace
     "k_frame_fg": 2.0, "k_frame_bg": 2.0, "k_frame_keys": 2.0,
+    # dim pass: prep (5N) + erode (2N) in one band kernel
+    "k_prep_erode": 7.0,
 }
 
 

@@ -149,6 +149,120 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
     if (s) atomicAdd(&hist[g * 256 + b], s);
 }
 
+// ------------------------------------------------------------------------------------------
+// prep + histogram + erosion in one pass (the dim pass's front end: processfield.py:453-464).
+// A workgroup owns a band of BR image rows over the full width: the float rows of the band and
+// of the (kh-1) halo rows are converted once into an LDS band (16-byte 0xFF pads left and right,
+// 0xFF rows outside the image: an erosion ignores what lies outside), the histogram is taken
+// from the band's own rows (equalizeHist sees the un-eroded image; its monotone LUT is applied
+// after the morphology), then the separable minimum runs on the LDS band four pixels per lane
+// (even / odd bytes as packed u16, v_pk_min_u16) and the eroded rows are stored 16 B per lane.
+// The 8-bit image is never written or re-read: 4N(1 + (kh-1)/BR) + 1N bytes instead of 5N + 2N.
+// float32 input, all-ones kernel, w % 16 == 0, kw/2 <= 16 and kw - 1 - kw/2 <= 16.
+// ------------------------------------------------------------------------------------------
+#define PE_THREADS 1024
+__global__ void __launch_bounds__(PE_THREADS)
+k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float af, uint8_t *dst, int *hist, int kh, int kw,
+             int BR, const int *active) {
+    int g = blockIdx.y;
+    if (active && !active[g]) return;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smb[];
+    __shared__ int sh[PE_THREADS / 64][256];
+    const int R = BR + kh - 1, S = w + 32, SW = S >> 2, W4 = w >> 2;
+    uint32_t *band = (uint32_t *)smb;            // R x S bytes
+    uint32_t *vbuf = band + R * SW;              // BR x S bytes: vertical minimum
+    for (int k = threadIdx.x; k < (PE_THREADS / 64) * 256; k += PE_THREADS) ((int *)sh)[k] = 0;
+    const int y0 = blockIdx.x * BR, ay = kh / 2, ax = kw / 2;
+    const size_t N = (size_t)h * w;
+    const float *s = src + (size_t)g * N;
+    const int wv = threadIdx.x >> 6;
+    // pads of every staged row
+    for (int it = threadIdx.x; it < R * 8; it += PE_THREADS) {
+        int r = it >> 3, k = it & 7;
+        band[r * SW + (k < 4 ? k : W4 + k)] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    int zeros = 0;
+    for (int it0 = threadIdx.x; it0 < R * W4; it0 += 4 * PE_THREADS) { // four row pieces in flight per lane
+        float4 v[4];
+        int gyv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int it = it0 + u * PE_THREADS;
+            int r = it / W4, x4 = it - r * W4;
+            int gy = y0 - ay + r;
+            gyv[u] = (it < R * W4 && gy >= 0 && gy < h) ? gy : -1;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gyv[u] >= 0) v[u] = ((const float4 *)(s + (size_t)(flip ? (h - 1 - gy) : gy) * w))[x4];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int it = it0 + u * PE_THREADS;
+            if (it >= R * W4) continue;
+            int r = it / W4, x4 = it - r * W4;
+            uint32_t word = 0xFFFFFFFFu;
+            if (gyv[u] >= 0) {
+                unsigned a = prep_f32(v[u].x, mode, mf, af), b = prep_f32(v[u].y, mode, mf, af), c = prep_f32(v[u].z, mode, mf, af),
+                         e = prep_f32(v[u].w, mode, mf, af);
+                word = a | (b << 8) | (c << 16) | (e << 24);
+                if (gyv[u] >= y0 && gyv[u] < y0 + BR) { // the band's own rows: every image row is counted once
+                    if (a) atomicAdd(&sh[wv][a], 1); else zeros++;
+                    if (b) atomicAdd(&sh[wv][b], 1); else zeros++;
+                    if (c) atomicAdd(&sh[wv][c], 1); else zeros++;
+                    if (e) atomicAdd(&sh[wv][e], 1); else zeros++;
+                }
+            }
+            band[r * SW + 4 + x4] = word;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) zeros += __shfl_down(zeros, off);
+    if (lfd_lane() == 0 && zeros) atomicAdd(&sh[wv][0], zeros);
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        int b = threadIdx.x, t = 0;
+        for (int k = 0; k < PE_THREADS / 64; k++) t += sh[k][b];
+        if (t) atomicAdd(&hist[g * 256 + b], t);
+    }
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    // vertical minimum, pads included (they stay 0xFF)
+    for (int it = threadIdx.x; it < BR * SW; it += PE_THREADS) {
+        int o = it / SW, j = it - o * SW;
+        us2 mE = __builtin_bit_cast(us2, 0x00FF00FFu), mO = mE;
+        for (int dy = 0; dy < kh; dy++) {
+            uint32_t t = band[(o + dy) * SW + j];
+            mE = __builtin_elementwise_min(mE, __builtin_bit_cast(us2, t & 0x00FF00FFu));
+            mO = __builtin_elementwise_min(mO, __builtin_bit_cast(us2, (t >> 8) & 0x00FF00FFu));
+        }
+        vbuf[it] = __builtin_bit_cast(uint32_t, mE) | (__builtin_bit_cast(uint32_t, mO) << 8);
+    }
+    __syncthreads();
+    // horizontal minimum and store: 16 output bytes per lane
+    uint8_t *d = dst + (size_t)g * N;
+    const int W16 = w >> 4;
+    for (int it = threadIdx.x; it < BR * W16; it += PE_THREADS) {
+        int o = it / W16, x16 = it - o * W16;
+        int gy = y0 + o;
+        if (gy >= h) continue;
+        const uint32_t *rw = vbuf + o * SW;
+        uint32_t outw[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int ob = 16 + 16 * x16 + 4 * q - ax; // byte offset of the window's first column in the padded row
+            int qi = ob >> 2;
+            uint32_t lo = rw[qi], hi = rw[qi + 1];
+            us2 mE = __builtin_bit_cast(us2, 0x00FF00FFu), mO = mE;
+            for (int dx = 0; dx < kw; dx++, ob++) {
+                if ((ob >> 2) != qi) { qi = ob >> 2; lo = hi; hi = rw[qi + 1]; }
+                uint32_t sft = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(ob & 3));
+                mE = __builtin_elementwise_min(mE, __builtin_bit_cast(us2, sft & 0x00FF00FFu));
+                mO = __builtin_elementwise_min(mO, __builtin_bit_cast(us2, (sft >> 8) & 0x00FF00FFu));
+            }
+            outw[q] = __builtin_bit_cast(uint32_t, mE) | (__builtin_bit_cast(uint32_t, mO) << 8);
+        }
+        *(uint4 *)(d + (size_t)gy * w + 16 * x16) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+    }
+}
+
 // histogram only (for lfdmi_equalize_hist on an existing u8 image)
 __global__ void __launch_bounds__(256)
 k_hist_u8(const uint8_t *src, size_t N, int *hist) {

@@ -29,14 +29,14 @@ enum {
     KID_REMOVESTARS = 0, KID_PREP_HIST, KID_LUT, KID_ERODE, KID_DILATE, KID_CANNY_NMS, KID_RUNS_INIT_FG,
     KID_RUNS_MERGE8, KID_RUNS_FLATTEN_FG, KID_EDGE, KID_RUNS_INIT_BG, KID_RUNS_MERGE4, KID_RUNS_FLATTEN_BG,
     KID_KEYS, KID_EXTREMES, KID_RECTS, KID_FILL, KID_PIXLIST, KID_VOTE, KID_PEAKS, KID_TOPK, KID_SORT,
-    KID_FINALIZE, KID_DILATE_CANNY, KID_FRAME_FG, KID_FRAME_BG, KID_FRAME_KEYS, KID_MISC, TG_COUNT
+    KID_FINALIZE, KID_DILATE_CANNY, KID_FRAME_FG, KID_FRAME_BG, KID_FRAME_KEYS, KID_PREP_ERODE, KID_MISC, TG_COUNT
 };
 static const char *const KID_NAMES[TG_COUNT] = {
     "k_removestars", "k_prep_hist", "k_lut", "k_morph(erode)", "k_morph(dilate)", "k_canny_nms", "k_runs_init(fg)",
     "k_runs_merge8", "k_runs_flatten(fg)", "k_edge_from_cand", "k_runs_init(bg)", "k_runs_merge4_bg",
     "k_runs_flatten(bg)", "k_keys", "k_extremes", "k_rects", "k_fill_quads", "k_pixlist", "k_hough_vote",
     "k_hough_peaks", "k_hough_topk", "k_hough_sort", "k_finalize", "k_dilate_canny", "k_frame_fg", "k_frame_bg",
-    "k_frame_keys", "misc"};
+    "k_frame_keys", "k_prep_erode", "misc"};
 
 struct TimedSpan { hipEvent_t a, b; int group, pass, det; };
 
@@ -89,6 +89,8 @@ struct lfdmi_ctx {
     int t_n[TG_COUNT] = {0};
     long long t_units[TG_COUNT] = {0}; // frames (images) the timed launches actually worked on
     bool want_stage_images = false;    // lfdmi_detect_batch writes the equ stage image only on request
+    int pe_rows = 12;                  // rows per band of k_prep_erode
+    bool fuse_prep_erode = true;       // dim pass: prep + histogram + erosion in one kernel (LFDMI_FUSE_PREP_ERODE=0: separate)
     bool frame_ccl = true;             // per-frame LDS connectivity kernels (k_frame.h)
     int frame_runcap = FRAME_RUNCAP;   // runs per frame they take (LFDMI_FRAME_RUNCAP lowers it: tests of the fallback path)
     int dc_strip = 8;                  // tiles per wave strip in k_dilate_canny_w
@@ -182,6 +184,8 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     *out = ctx;
     ctx->device = device; ctx->H = max_h; ctx->W = max_w; ctx->G = max_inflight;
     if (const char *e = getenv("LFDMI_FRAME_CCL")) ctx->frame_ccl = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_FUSE_PREP_ERODE")) ctx->fuse_prep_erode = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_PE_ROWS")) { int v = atoi(e); if (v >= 2 && v <= 64) ctx->pe_rows = v; }
     if (const char *e = getenv("LFDMI_FRAME_RUNCAP")) { int v = atoi(e); if (v >= 0 && v < FRAME_RUNCAP) ctx->frame_runcap = v; }
     if (const char *e = getenv("LFDMI_DC_STRIP")) { int v = atoi(e); if (v >= 1 && v <= 256) ctx->dc_strip = v; } // tuning knob
     ctx->N = (size_t)max_h * max_w;
@@ -250,6 +254,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     HIPCHK(hipFuncSetAttribute((const void *)k_rects_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_dilate_canny_v, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_frame_fg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_frame_contours, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (FRAME_RUNCAP + 4 * (FRAME_RUNCAP / 32)) * (int)sizeof(int)));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -660,14 +665,47 @@ static int check_params(lfdmi_ctx *ctx, const lfdmi_params *p, bool dim) {
 }
 
 // one detection pass on nc images already resident at src (device): fills ctx->res_dev
+// prep + histogram + LUT + erosion without the 8-bit image in between (batch path of the dim pass); false if the
+// shapes do not allow it
+static bool can_fuse_prep_erode(const lfdmi_ctx *ctx, int dtype, int w, const uint8_t *kernel, int kh, int kw) {
+    if (!ctx->fuse_prep_erode || ctx->keep_equ || dtype != LFDMI_F32 || (w % 16) != 0) return false; // (stage images wanted: keep gray)
+    if (!kernel || kh <= 0 || kw <= 0 || kh > LFDMI_MAX_MORPH_K || kw > LFDMI_MAX_MORPH_K || !all_ones(kernel, kh, kw)) return false;
+    return kw / 2 <= 16 && kw - 1 - kw / 2 <= 16;
+}
+
+static int run_prep_erode(lfdmi_ctx *ctx, const void *src, int nc, int h, int w, int flip, int mode, double minFlux, double addFlux,
+                          int kh, int kw, const int *active) {
+    HIPCHK(hipMemsetAsync(ctx->hist, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
+    int BR = ctx->pe_rows;
+    while (BR > 2 && (size_t)(2 * BR + kh - 1) * (w + 32) > 60 * 1024) BR >>= 1; // two 1024-thread workgroups per CU when possible
+    size_t lds = (size_t)(2 * BR + kh - 1) * (w + 32) + 16; // (+ one piece: the sliding window peeks one word ahead)
+    if (lds > 140 * 1024) return fail(ctx, LFDMI_ERR_UNSUPPORTED, "row band does not fit LDS");
+    {
+        Span sp(ctx, KID_PREP_ERODE);
+        k_prep_erode<<<dim3((h + BR - 1) / BR, nc), PE_THREADS, lds, ctx->stream>>>((const float *)src, h, w, flip, mode, (float)minFlux,
+                                                                               (float)addFlux, ctx->tmp, ctx->hist, kh, kw, BR, active);
+        KCHK("k_prep_erode");
+    }
+    Span sp(ctx, KID_LUT);
+    k_lut<<<nc, 256, 0, ctx->stream>>>(ctx->hist, h * w, ctx->lut, active);
+    KCHK("k_lut");
+    return 0;
+}
+
 static int run_pass(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int prep_mode, bool dim,
                     const lfdmi_params *p, const int *active, int *need_dim) {
     RET(zero_counters(ctx, nc));
-    RET(run_prep(ctx, src, dtype, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, active));
     const uint8_t *dil_src = ctx->gray;
-    if (dim) {
-        RET(run_morph(ctx, ctx->gray, ctx->tmp, nullptr, nullptr, p->erodeKernel, p->erode_kh, p->erode_kw, 1, nc, h, w, active));
+    if (dim && can_fuse_prep_erode(ctx, dtype, w, p->erodeKernel, p->erode_kh, p->erode_kw) &&
+        (size_t)(2 * 2 + p->erode_kh - 1) * (w + 32) <= 140 * 1024) {
+        RET(run_prep_erode(ctx, src, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, p->erode_kh, p->erode_kw, active));
         dil_src = ctx->tmp;
+    } else {
+        RET(run_prep(ctx, src, dtype, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, active));
+        if (dim) {
+            RET(run_morph(ctx, ctx->gray, ctx->tmp, nullptr, nullptr, p->erodeKernel, p->erode_kh, p->erode_kw, 1, nc, h, w, active));
+            dil_src = ctx->tmp;
+        }
     }
     if (can_fuse_dilate_canny(p->dilateKernel, p->dilate_kh, p->dilate_kw, w)) {
         RET(run_dilate_canny(ctx, dil_src, nc, h, w, ctx->lut, p->dilate_kh, p->dilate_kw, active));

@@ -214,3 +214,29 @@ def test_frame_kernels_fallback_path(oracle, monkeypatch, runcap):
     want = oracle.detect_frame(frames[0].copy(), pb, pd, cats[0], rs_o)
     assert same(res[0], want)
     ctx.close()
+
+
+def test_fused_prep_erode_matches_separate_kernels(oracle, monkeypatch):
+    """Dim pass front end: the band kernel that converts, histograms and erodes in one pass
+    (k_prep_erode) against the separate prep / erode kernels (LFDMI_FUSE_PREP_ERODE=0): same
+    records, same edge images, for a 3x3 and a 9x9 erosion."""
+    from lfd_amd import _native, synth
+    pb, pd, prs = params()
+    frames = np.stack([synth.make_frame(k, with_catalog=False)[0] for k in (1, 3, 5, 7)])
+    for ek in (3, 9):
+        pdk = dict(pd, erodeKernel=np.ones((ek, ek), np.uint8))
+        out = []
+        for fused in ("1", "0"):
+            monkeypatch.setenv("LFDMI_FUSE_PREP_ERODE", fused)
+            ctx = _native.Context(0, 1489, 2048, 4)
+            res = ctx.detect_batch(frames.copy(), pb, pdk)
+            edges = [ctx.get_stage(i, _native.STAGE_CANNY, 1489, 2048) for i in range(4)]
+            out.append((res.tobytes(), edges))
+            ctx.close()
+        assert out[0][0] == out[1][0]
+        for a, b in zip(out[0][1], out[1][1]):
+            assert np.array_equal(a, b)
+    want = oracle.detect_frame(frames[0].copy(), pb, pd)
+    ctx = _native.Context(0, 1489, 2048, 4)
+    assert same(ctx.detect_batch(frames.copy(), pb, pd)[0], want)
+    ctx.close()
