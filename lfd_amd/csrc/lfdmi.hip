@@ -664,22 +664,29 @@ static int check_params(lfdmi_ctx *ctx, const lfdmi_params *p, bool dim) {
     return 0;
 }
 
-// one detection pass on nc images already resident at src (device): fills ctx->res_dev
+// Rows per band of k_prep_erode for this shape: as many as ctx->pe_rows while two 1024-thread workgroups fit a
+// CU's LDS; 0 when the band would get so short that the halo rows dominate (wide frames with a tall erosion
+// kernel, e.g. 4096 px x 9 rows: the separate kernels are the better choice there).
+static int prep_erode_rows(const lfdmi_ctx *ctx, int w, int kh) {
+    int BR = ctx->pe_rows;
+    while (BR > 2 && (size_t)(2 * BR + kh - 1) * (w + 32) > 60 * 1024) BR >>= 1;
+    if ((size_t)(2 * BR + kh - 1) * (w + 32) + 16 > 140 * 1024) return 0;
+    return BR >= 2 * (kh - 1) ? BR : 0; // at most 50 % extra float reads
+}
+
 // prep + histogram + LUT + erosion without the 8-bit image in between (batch path of the dim pass); false if the
 // shapes do not allow it
 static bool can_fuse_prep_erode(const lfdmi_ctx *ctx, int dtype, int w, const uint8_t *kernel, int kh, int kw) {
     if (!ctx->fuse_prep_erode || ctx->keep_equ || dtype != LFDMI_F32 || (w % 16) != 0) return false; // (stage images wanted: keep gray)
     if (!kernel || kh <= 0 || kw <= 0 || kh > LFDMI_MAX_MORPH_K || kw > LFDMI_MAX_MORPH_K || !all_ones(kernel, kh, kw)) return false;
-    return kw / 2 <= 16 && kw - 1 - kw / 2 <= 16;
+    return kw / 2 <= 16 && kw - 1 - kw / 2 <= 16 && prep_erode_rows(ctx, w, kh) > 0;
 }
 
 static int run_prep_erode(lfdmi_ctx *ctx, const void *src, int nc, int h, int w, int flip, int mode, double minFlux, double addFlux,
                           int kh, int kw, const int *active) {
     HIPCHK(hipMemsetAsync(ctx->hist, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
-    int BR = ctx->pe_rows;
-    while (BR > 2 && (size_t)(2 * BR + kh - 1) * (w + 32) > 60 * 1024) BR >>= 1; // two 1024-thread workgroups per CU when possible
+    int BR = prep_erode_rows(ctx, w, kh);
     size_t lds = (size_t)(2 * BR + kh - 1) * (w + 32) + 16; // (+ one piece: the sliding window peeks one word ahead)
-    if (lds > 140 * 1024) return fail(ctx, LFDMI_ERR_UNSUPPORTED, "row band does not fit LDS");
     {
         Span sp(ctx, KID_PREP_ERODE);
         k_prep_erode<<<dim3((h + BR - 1) / BR, nc), PE_THREADS, lds, ctx->stream>>>((const float *)src, h, w, flip, mode, (float)minFlux,
@@ -692,12 +699,12 @@ static int run_prep_erode(lfdmi_ctx *ctx, const void *src, int nc, int h, int w,
     return 0;
 }
 
+// one detection pass on nc images already resident at src (device): fills ctx->res_dev
 static int run_pass(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int prep_mode, bool dim,
                     const lfdmi_params *p, const int *active, int *need_dim) {
     RET(zero_counters(ctx, nc));
     const uint8_t *dil_src = ctx->gray;
-    if (dim && can_fuse_prep_erode(ctx, dtype, w, p->erodeKernel, p->erode_kh, p->erode_kw) &&
-        (size_t)(2 * 2 + p->erode_kh - 1) * (w + 32) <= 140 * 1024) {
+    if (dim && can_fuse_prep_erode(ctx, dtype, w, p->erodeKernel, p->erode_kh, p->erode_kw)) {
         RET(run_prep_erode(ctx, src, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, p->erode_kh, p->erode_kw, active));
         dil_src = ctx->tmp;
     } else {

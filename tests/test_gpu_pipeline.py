@@ -219,11 +219,12 @@ def test_frame_kernels_fallback_path(oracle, monkeypatch, runcap):
 def test_fused_prep_erode_matches_separate_kernels(oracle, monkeypatch):
     """Dim pass front end: the band kernel that converts, histograms and erodes in one pass
     (k_prep_erode) against the separate prep / erode kernels (LFDMI_FUSE_PREP_ERODE=0): same
-    records, same edge images, for a 3x3 and a 9x9 erosion."""
+    records, same edge images, for a 3x3 and a 5x5 erosion (taller kernels at this width keep the
+    separate kernels: the halo rows of a short band would dominate)."""
     from lfd_amd import _native, synth
     pb, pd, prs = params()
     frames = np.stack([synth.make_frame(k, with_catalog=False)[0] for k in (1, 3, 5, 7)])
-    for ek in (3, 9):
+    for ek in (3, 5):
         pdk = dict(pd, erodeKernel=np.ones((ek, ek), np.uint8))
         out = []
         for fused in ("1", "0"):
