@@ -155,7 +155,7 @@ def main():
         elapsed = float(t.item())
 
     cnt = det.get_counters()[:n]  # last pass of every slot: Hough cost is 180 votes per non-zero pixel
-    nnz_equ, nnz_box = cnt[:, 3][cnt[:, 8] > 0], cnt[:, 4][cnt[:, 8] > 0]
+    nnz_equ, nnz_box = cnt[:, 15][cnt[:, 8] > 0], cnt[:, 16][cnt[:, 8] > 0]
     found_b = int((res["found"] == 1).sum())
     found_d = int((res["found"] == 2).sum())
     errors = int((res["status"] != 0).sum())

@@ -172,10 +172,11 @@ int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w,
 /* copy a stage image (u8, h x w) of in-flight slot `slot` of the LAST call to dst */
 int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, uint8_t *dst, int loc);
 /* diagnostics: the work counters of in-flight slots [slot0, slot0 + n) as left by the LAST pass
- * (LFDMI_COUNTERS int32 values per slot; order: keys, row slots, rectangles, equ pixels, box
- * pixels, equ peaks, box peaks, overflow flag, detection, tall keys, candidate words, background
- * words, candidate runs, background runs, medium keys, reserved) */
-#define LFDMI_COUNTERS 16
+ * (LFDMI_COUNTERS int32 values per slot; order: keys, row slots, rectangles, equ list entries, box
+ * list entries (pixel chunks the Hough kernels vote with), equ peaks, box peaks, overflow flag,
+ * detection, tall keys, candidate words, background words, candidate runs, background runs, medium
+ * keys, non-zero pixels of equ, of box_img, reserved x3) */
+#define LFDMI_COUNTERS 20
 int lfdmi_get_counters(lfdmi_ctx *ctx, int slot0, int n, int32_t *dst);
 /* per-kernel timing for bench.py's roofline entry: when enabled, every kernel launch is
  * bracketed by HIP events on the launch stream; lfdmi_get_timing returns, per timing slot,

@@ -399,9 +399,9 @@ class Context:
         return res
 
     def get_counters(self, slot0=0, n=None):
-        """Work counters ([n, 16] int32) the last pass left for in-flight slots slot0 .. slot0+n-1."""
+        """Work counters ([n, 20] int32, see LFDMI_COUNTERS) the last pass left for in-flight slots slot0 .. slot0+n-1."""
         n = self.max_inflight - slot0 if n is None else int(n)
-        out = np.zeros((n, 16), np.int32)
+        out = np.zeros((n, 20), np.int32)
         self._chk(self._lib.lfdmi_get_counters(self._h, int(slot0), n, _ptr(out)))
         return out
 

@@ -88,7 +88,7 @@ class BatchDetector:
         return out
 
     def get_counters(self):
-        """Work counters ([slots, 16] int32, see lfdmi_get_counters) the last pass left, all lanes."""
+        """Work counters ([slots, 20] int32, see lfdmi_get_counters) the last pass left, all lanes."""
         return np.concatenate([c.get_counters() for c in self.ctxs])
 
     @staticmethod

@@ -10,8 +10,8 @@ enum {
     C_NKEYS = 0,     // contour keys (fg components + holes)
     C_NSLOTS = 1,    // row-extent slots handed out
     C_NQUADS = 2,    // accepted rectangles
-    C_NPIX_EQU = 3,  // non-zero pixels of equ (Hough input list)
-    C_NPIX_BOX = 4,  // non-zero pixels of box_img
+    C_NPIX_EQU = 3,  // entries of equ's Hough input list (pixel chunks, see k_pixlist)
+    C_NPIX_BOX = 4,  // entries of box_img's list
     C_NPEAK_EQU = 5, // local maxima of the equ accumulator
     C_NPEAK_BOX = 6,
     C_OVERFLOW = 7,  // workspace overflow flag
@@ -22,7 +22,9 @@ enum {
     C_NRUNF = 12,    // candidate runs in the frame (compact run ids 0 .. n-1)
     C_NRUNB = 13,    // background runs of the edge image
     C_NMED = 14,     // keys of medium height (one wave each, small LDS footprint)
-    C_COUNT = 16
+    C_NNZ_EQU = 15,  // non-zero pixels of equ (180 Hough votes each)
+    C_NNZ_BOX = 16,  // non-zero pixels of box_img
+    C_COUNT = 20
 };
 
 #define LFD_WQ(w) (((w) + 63) >> 6)

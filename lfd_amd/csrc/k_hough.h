@@ -11,9 +11,18 @@
 #include "common.h"
 #include "../../include/lfdmi.h"
 
-// bit rows -> packed (y << 16 | x) list, order irrelevant (votes commute)
+// bit rows -> list of horizontal pixel CHUNKS, order irrelevant (votes commute):
+//   entry = (len - 1) << 26 | y << 13 | x0,   1 <= len <= 16, the pixels (y, x0 .. x0 + len - 1) all set.
+// The Hough inputs are dilated blobs and filled rectangles: runs of 10-100 pixels, so a frame's list is
+// ~12x shorter than its pixel count, and the vote kernel handles a chunk with two accumulator updates
+// per angle instead of one per pixel (see k_hough_vote).  Image sides up to 8191 (13 bits).
+#define CHUNK_MAX 16 // (4 bits; the host passes min(CHUNK_MAX, floor(rho)) so that a chunk spans less than one bin)
+__device__ __forceinline__ uint32_t chunk_entry(int y, int x0, int len) {
+    return ((uint32_t)(len - 1) << 26) | ((uint32_t)y << 13) | (uint32_t)x0;
+}
+
 __global__ void __launch_bounds__(256)
-k_pixlist(const u64 *bits, uint32_t *list, int *counters, int cidx, int h, int w, size_t list_cap,
+k_pixlist(const u64 *bits, uint32_t *list, int *counters, int cidx, int nnz_idx, int chunk_max, int h, int w, size_t list_cap,
           int *accum_clear, int acc_n, size_t acc_stride, const int *active, int need_detect) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
@@ -31,23 +40,35 @@ k_pixlist(const u64 *bits, uint32_t *list, int *counters, int cidx, int h, int w
         y = idx / wq; q = idx - y * wq;
         c = bits[(size_t)g * h * wq + idx] & valid_mask(q, w);
     }
-    int n = __popcll(c);
+    // chunks of this word: every maximal stretch of set bits, cut every CHUNK_MAX pixels
+    int n = 0;
+    for (u64 r = c; r;) {
+        int b = __ffsll((long long)r) - 1;
+        u64 inv = ~(r >> b);
+        int len = inv ? (__ffsll((long long)inv) - 1) : (64 - b);
+        r &= ~((len >= 64 ? ~0ull : ((1ull << len) - 1)) << b);
+        n += (len + chunk_max - 1) / chunk_max;
+    }
     // wave-aggregated allocation: inclusive scan of n, one atomic per wave
-    int lane = lfd_lane(), incl = n;
+    int lane = lfd_lane(), incl = n, px = __popcll(c);
     for (int off = 1; off < 64; off <<= 1) {
         int t = __shfl_up(incl, off);
         if (lane >= off) incl += t;
     }
+    for (int off = 32; off > 0; off >>= 1) px += __shfl_down(px, off);
     int total = __shfl(incl, 63);
     int base = 0;
     if (lane == 63 && total) base = atomicAdd(&cnt[cidx], total);
+    if (lane == 0 && px) atomicAdd(&cnt[nnz_idx], px);
     base = __shfl(base, 63);
     int o = base + incl - n;
     uint32_t *lg = list + (size_t)g * list_cap;
-    while (c) {
-        int b = __ffsll((long long)c) - 1;
-        c &= c - 1;
-        lg[o++] = ((uint32_t)y << 16) | (uint32_t)((q << 6) + b);
+    for (u64 r = c; r;) {
+        int b = __ffsll((long long)r) - 1;
+        u64 inv = ~(r >> b);
+        int len = inv ? (__ffsll((long long)inv) - 1) : (64 - b);
+        r &= ~((len >= 64 ? ~0ull : ((1ull << len) - 1)) << b);
+        for (int x0 = (q << 6) + b; len > 0; x0 += chunk_max, len -= chunk_max) lg[o++] = chunk_entry(y, x0, min(len, chunk_max));
     }
 }
 
@@ -102,34 +123,56 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     const unsigned cell = act ? (unsigned)(((numrho - 1) / 2) * AW + lane) : (unsigned)(numrho * AW + lane);
     const unsigned lanebase = (cell << 2) - (0x4B400000u << (aw_log2 + 2));
     char *accb = (char *)acc;
-#define LFD_VOTE(K)                                                                                   \
-    {                                                                                                 \
-        float fj_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fxv), (K))); \
-        float v_ = __fadd_rn(__fadd_rn(__fmul_rn(fj_, c), ys), 12582912.0f);                         \
-        atomicAdd((int *)(accb + ((__builtin_bit_cast(unsigned, v_) << (aw_log2 + 2)) + lanebase)), 1); \
-    }
-    // One coalesced load fetches 64 list entries per wave; each lane converts its own x to float
-    // once, then the wave walks the entries with v_readlane (wave-uniform pixel, lane = angle).
-    // Entries arrive row by row, so the chunk is cut at row changes (wave-uniform mask) and the
-    // y*sin term is computed once per row segment: 1 readlane + mul + 2 add + shift-add + LDS add
-    // per pixel.  No per-lane branch anywhere (v_readlane needs every lane's fxv).
+    // A list entry is a chunk of horizontal neighbours (y, x0 .. x0 + len - 1), len <= min(16, rho) (k_pixlist).
+    // Along a chunk the vote value w(x) = fl(fl(x c) + y s) is monotone in x and moves by less than one bin
+    // (|c| = |cos| / rho per pixel), so the chunk's pixels fall into at most two adjacent bins: the first t
+    // into bin(x0), the rest into bin(x0 + len - 1).  Per angle:
+    //   both ends in one bin            -> one LDS add of len;
+    //   otherwise t is estimated from the line equation, t = ceil((r0 +- 1/2 - w0) / c), and CHECKED with the
+    //   exact per-pixel arithmetic at x0 + t - 1 and x0 + t (bin(x0) and bin(x_end) respectively): monotone
+    //   + both checks hold <=> t is exact.  If any lane's check fails (ties, rounding of the estimate) the
+    //   wave walks the chunk pixel by pixel.  Either way every pixel's bin is the one OpenCV computes.
+    // ~40 vector instructions and 2 LDS adds per chunk and wave instead of 6 and 1 per pixel.
+    const float inv_c = 1.0f / c;                 // +-inf for lanes without an angle (c = 0): harmless, see below
+    const float half_s = c < 0.f ? -0.5f : 0.5f;
+    const int sh = aw_log2 + 2;
+#define LFD_BIN(FX, YS) __builtin_bit_cast(unsigned, __fadd_rn(__fadd_rn(__fmul_rn((FX), c), (YS)), 12582912.0f))
     for (int base = begin + wv * 64; base < end; base += nw * 64) {
         int m = min(64, end - base);
         uint32_t pv = (lane < m) ? list[base + lane] : 0u;
-        float fxv = (float)(pv & 0xffffu);
-        int yv = (int)(pv >> 16);
-        int yprev = __shfl_up(yv, 1);
-        u64 starts = __ballot(lane < m && (lane == 0 || yv != yprev));
-        int k = 0;
-        while (k < m) {
-            u64 rest = (k >= 63) ? 0ull : (starts & ~((2ull << k) - 1ull));
-            int kend = rest ? (int)__ffsll((long long)rest) - 1 : m;
-            float ys = __fmul_rn((float)__builtin_amdgcn_readlane(yv, k), s);
-            for (; k + 4 <= kend; k += 4) { LFD_VOTE(k) LFD_VOTE(k + 1) LFD_VOTE(k + 2) LFD_VOTE(k + 3) }
-            for (; k < kend; k++) LFD_VOTE(k)
+        // every lane converts its own entry once; the wave then walks the entries with v_readlane
+        const int lenv = (int)(pv >> 26);                       // len - 1
+        const float fx0v = (float)(pv & 0x1fffu), fyv = (float)((pv >> 13) & 0x1fffu);
+        const float fxev = fx0v + (float)lenv;
+        for (int k = 0; k < m; k++) {
+            const float fx0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx0v), k));
+            const float fxe = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fxev), k));
+            const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyv), k));
+            const int L = __builtin_amdgcn_readlane(lenv, k) + 1;
+            const float ys = __fmul_rn(fy, s);
+            const float w0 = __fadd_rn(__fmul_rn(fx0, c), ys);
+            const float v0 = __fadd_rn(w0, 12582912.0f);
+            const unsigned b0 = __builtin_bit_cast(unsigned, v0), be = LFD_BIN(fxe, ys);
+            if (__ballot(b0 != be) == 0ull) { // the whole chunk votes for one bin at every angle of this wave
+                atomicAdd((int *)(accb + ((b0 << sh) + lanebase)), L);
+                continue;
+            }
+            // boundary estimate (lanes whose ends agree get some t in [1, L-1]: both parts land in the same bin)
+            float tf = __fmul_rn(__fsub_rn(__fadd_rn(__fsub_rn(v0, 12582912.0f), half_s), w0), inv_c);
+            tf = fminf(fmaxf(tf, 1.0f), (float)(L - 1)); // also takes care of inf / NaN (lanes without an angle)
+            const int t = (int)ceilf(tf);
+            const float fxb = __fadd_rn(fx0, (float)t), fxa = __fsub_rn(fxb, 1.0f);
+            const bool ok = (LFD_BIN(fxa, ys) == b0) && (LFD_BIN(fxb, ys) == be);
+            if (__ballot(!ok) == 0ull) {
+                atomicAdd((int *)(accb + ((b0 << sh) + lanebase)), t);
+                atomicAdd((int *)(accb + ((be << sh) + lanebase)), L - t);
+                continue;
+            }
+            for (int j = 0; j < L; j++) // rare: exact walk
+                atomicAdd((int *)(accb + ((LFD_BIN(__fadd_rn(fx0, (float)j), ys) << sh) + lanebase)), 1);
         }
     }
-#undef LFD_VOTE
+#undef LFD_BIN
     __syncthreads();
     int *ag = accum + ((size_t)g * 2 + im) * acc_cap;
     const int ts = numangle + 2; // transposed row length

@@ -179,7 +179,7 @@ extern "C" void lfdmi_hough_dims(int h, int w, double rho_d, double theta_d, int
 }
 
 extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflight, lfdmi_ctx **out) {
-    if (!out || max_h <= 0 || max_w <= 0 || max_inflight <= 0 || max_h > 65535 || max_w > 65535) return LFDMI_ERR_ARG;
+    if (!out || max_h <= 0 || max_w <= 0 || max_inflight <= 0 || max_h > 8191 || max_w > 8191) return LFDMI_ERR_ARG;
     lfdmi_ctx *ctx = new lfdmi_ctx();
     *out = ctx;
     ctx->device = device; ctx->H = max_h; ctx->W = max_w; ctx->G = max_inflight;
@@ -315,7 +315,7 @@ extern "C" const char *lfdmi_timing_name(int i) { return (i >= 0 && i < TG_COUNT
 static int check_shape(lfdmi_ctx *ctx, int n, int h, int w) {
     if (!ctx) return LFDMI_ERR_ARG;
     if (n < 0 || h <= 0 || w <= 0) return fail(ctx, LFDMI_ERR_ARG, "bad shape");
-    if ((size_t)h * w > ctx->N || h > 65535 || w > 65535 || LFD_WQ(w) * (size_t)h > (size_t)ctx->wq * ctx->H ||
+    if ((size_t)h * w > ctx->N || h > 8191 || w > 8191 || LFD_WQ(w) * (size_t)h > (size_t)ctx->wq * ctx->H ||
         (LFD_WQ(w) * (size_t)h + 63) / 64 > SCAN_MAX_SEG)
         return fail(ctx, LFDMI_ERR_CAPACITY, "frame larger than the context was created for");
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, LFDMI_ERR_HIP, "hipSetDevice");
@@ -619,11 +619,13 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         int acc_n = (na + 2) * (nr + 2);
         { Span sp(ctx, KID_PIXLIST, need_detect);
         // per-slot accumulator pairs are 2 * acc_cap apart; the kernel indexes by slot itself
-        k_pixlist<<<wg, 256, 0, ctx->stream>>>(ctx->equb, ctx->pix_equ, ctx->counters, C_NPIX_EQU, h, w, ctx->list_cap,
+        // a chunk must span less than one rho bin: |cos| / rho per pixel
+        int chunk_max = rho >= CHUNK_MAX ? CHUNK_MAX : (rho >= 1 ? (int)rho : 1);
+        k_pixlist<<<wg, 256, 0, ctx->stream>>>(ctx->equb, ctx->pix_equ, ctx->counters, C_NPIX_EQU, C_NNZ_EQU, chunk_max, h, w, ctx->list_cap,
                                                nsplit > 1 ? ctx->accum : nullptr, acc_n, ctx->acc_cap, active, need_detect);
         KCHK("k_pixlist(equ)");
         if (n_img > 1) {
-            k_pixlist<<<wg, 256, 0, ctx->stream>>>(ctx->boxb, ctx->pix_box, ctx->counters, C_NPIX_BOX, h, w, ctx->list_cap,
+            k_pixlist<<<wg, 256, 0, ctx->stream>>>(ctx->boxb, ctx->pix_box, ctx->counters, C_NPIX_BOX, C_NNZ_BOX, chunk_max, h, w, ctx->list_cap,
                                                    nsplit > 1 ? ctx->accum + ctx->acc_cap : nullptr, acc_n, ctx->acc_cap, active, need_detect);
             KCHK("k_pixlist(box)");
         } }

@@ -16,13 +16,13 @@ for k in range(n):
 frames = np.stack(frames)
 ctx = Nv.Context(0, 1489, 2048, n)
 ctx.remove_stars(frames, synth.pack_catalogs(cats), rs)
-names = ["keys", "slots", "quads", "pix_equ", "pix_box", "peak_equ", "peak_box", "ovf", "detect", "big", "fgw", "bgw",
-         "runf", "runb", "med", "-"]
+names = ["keys", "slots", "quads", "chunks_equ", "chunks_box", "peak_equ", "peak_box", "ovf", "detect", "big", "fgw", "bgw",
+         "runf", "runb", "med", "nnz_equ", "nnz_box"]
 for label, fn in (("bright", lambda: ctx.process_bright(frames, pb, flip=True)),
                   ("dim", lambda: ctx.process_dim(frames, pd, flip=True, after_bright=True))):
     fn()
     c = ctx.get_counters(0, n)
     print(label)
-    for i, nm in enumerate(names[:15]):
+    for i, nm in enumerate(names):
         col = c[:, i]
         print("  %-8s min %7d  median %7d  p90 %7d  max %7d" % (nm, col.min(), np.median(col), np.percentile(col, 90), col.max()))
