@@ -162,10 +162,23 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
             tf = fminf(fmaxf(tf, 1.0f), (float)(L - 1)); // also takes care of inf / NaN (lanes without an angle)
             const int t = (int)ceilf(tf);
             const float fxb = __fadd_rn(fx0, (float)t), fxa = __fsub_rn(fxb, 1.0f);
-            const bool ok = (LFD_BIN(fxa, ys) == b0) && (LFD_BIN(fxb, ys) == be);
+            const unsigned ba = LFD_BIN(fxa, ys), bb = LFD_BIN(fxb, ys);
+            const bool ok = (ba == b0) && (bb == be);
             if (__ballot(!ok) == 0ull) {
                 atomicAdd((int *)(accb + ((b0 << sh) + lanebase)), t);
                 atomicAdd((int *)(accb + ((be << sh) + lanebase)), L - t);
+                continue;
+            }
+            // One pixel off is common where bin borders sit on whole pixels (theta = 0: x cos / rho crosses
+            // r + 1/2 at x = rho r + rho / 2, and whether float arithmetic lands above or below is a coin
+            // toss): look one pixel further on the side that disagreed.
+            const bool high = (ba == be); // the estimate overshot: x0 + t - 1 is already in the second bin
+            const unsigned bc = LFD_BIN(high ? __fsub_rn(fxa, 1.0f) : __fadd_rn(fxb, 1.0f), ys);
+            const int t2 = ok ? t : (high ? t - 1 : t + 1);
+            const bool ok2 = ok || (high ? (bc == b0) : (ba == b0 && bb == b0 && bc == be));
+            if (__ballot(!ok2) == 0ull) {
+                atomicAdd((int *)(accb + ((b0 << sh) + lanebase)), t2);
+                atomicAdd((int *)(accb + ((be << sh) + lanebase)), L - t2);
                 continue;
             }
             for (int j = 0; j < L; j++) // rare: exact walk

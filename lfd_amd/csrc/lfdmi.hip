@@ -89,6 +89,7 @@ struct lfdmi_ctx {
     int t_n[TG_COUNT] = {0};
     long long t_units[TG_COUNT] = {0}; // frames (images) the timed launches actually worked on
     bool want_stage_images = false;    // lfdmi_detect_batch writes the equ stage image only on request
+    int vote_split = 4;                // pieces a frame's Hough list is cut into at most
     int pe_rows = 12;                  // rows per band of k_prep_erode
     bool fuse_prep_erode = true;       // dim pass: prep + histogram + erosion in one kernel (LFDMI_FUSE_PREP_ERODE=0: separate)
     bool frame_ccl = true;             // per-frame LDS connectivity kernels (k_frame.h)
@@ -185,6 +186,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     ctx->device = device; ctx->H = max_h; ctx->W = max_w; ctx->G = max_inflight;
     if (const char *e = getenv("LFDMI_FRAME_CCL")) ctx->frame_ccl = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_FUSE_PREP_ERODE")) ctx->fuse_prep_erode = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_VOTE_SPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->vote_split = v; }
     if (const char *e = getenv("LFDMI_PE_ROWS")) { int v = atoi(e); if (v >= 2 && v <= 64) ctx->pe_rows = v; }
     if (const char *e = getenv("LFDMI_FRAME_RUNCAP")) { int v = atoi(e); if (v >= 0 && v < FRAME_RUNCAP) ctx->frame_runcap = v; }
     if (const char *e = getenv("LFDMI_DC_STRIP")) { int v = atoi(e); if (v >= 1 && v <= 256) ctx->dc_strip = v; } // tuning knob
@@ -615,7 +617,7 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
     {
         // cut each pixel list into pieces so that a launch carries several workgroups per CU
         int nsplit = 1;
-        while (nsplit < 4 && nslabs * n_img * nc * nsplit < 6144) nsplit <<= 1;
+        while (nsplit < ctx->vote_split && nslabs * n_img * nc * nsplit < 6144) nsplit <<= 1;
         int acc_n = (na + 2) * (nr + 2);
         { Span sp(ctx, KID_PIXLIST, need_detect);
         // per-slot accumulator pairs are 2 * acc_cap apart; the kernel indexes by slot itself
