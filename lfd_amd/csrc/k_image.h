@@ -99,9 +99,17 @@ __device__ __forceinline__ unsigned prep_f64(double x, int mode, double mf, doub
 
 #define PREP_ROWS 4
 
+// Cell occupancy bitmap handed from the prep kernels to k_dilate_canny_w: per band of 16 image rows
+// CELLBM_WORDS u64, bit c = "some byte of columns 16 c .. 16 c + 15 of this band is non-zero" (a superset is
+// fine: the consumer only skips tiles whose cells are all clear and checks the loaded bytes otherwise).
+#define CELLBM_ROWS 16
+#define CELLBM_COLS 16
+#define CELLBM_WORDS 8 // 512 cells: image widths up to 8191
+static_assert(16 % PREP_ROWS == 0, "a workgroup's rows lie in one band");
+
 __global__ void __launch_bounds__(256)
 k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double minFlux,
-            double addFlux, uint8_t *gray, int *hist, const int *active) {
+            double addFlux, uint8_t *gray, int *hist, u64 *cellbm, int bm_bands, const int *active) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     __shared__ int sh[4][256];
@@ -113,29 +121,32 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
     int zeros = 0;
     int r0 = blockIdx.x * PREP_ROWS;
     float mf = (float)minFlux, af = (float)addFlux;
+    unsigned nzpos = 0; // bit i: this lane met a non-zero value at its i-th column position (any of the rows)
     for (int r = r0; r < r0 + PREP_ROWS && r < h; r++) {
         int sr = flip ? (h - 1 - r) : r;
         if (dtype == 1 && (w & 3) == 0) {
             const float4 *s = (const float4 *)((const float *)src + (size_t)g * N + (size_t)sr * w);
             uchar4 *d = (uchar4 *)(gout + (size_t)r * w);
-            for (int x4 = threadIdx.x; x4 < (w >> 2); x4 += 256) {
+            for (int x4 = threadIdx.x, i = 0; x4 < (w >> 2); x4 += 256, i++) {
                 float4 v = s[x4];
                 unsigned a = prep_f32(v.x, mode, mf, af), b = prep_f32(v.y, mode, mf, af),
                          c = prep_f32(v.z, mode, mf, af), e = prep_f32(v.w, mode, mf, af);
                 d[x4] = make_uchar4((unsigned char)a, (unsigned char)b, (unsigned char)c, (unsigned char)e);
+                if (a | b | c | e) nzpos |= 1u << i;
                 if (a) atomicAdd(&sh[wv][a], 1); else zeros++;
                 if (b) atomicAdd(&sh[wv][b], 1); else zeros++;
                 if (c) atomicAdd(&sh[wv][c], 1); else zeros++;
                 if (e) atomicAdd(&sh[wv][e], 1); else zeros++;
             }
         } else {
-            for (int x = threadIdx.x; x < w; x += 256) {
+            for (int x = threadIdx.x, i = 0; x < w; x += 256, i++) {
                 unsigned a;
                 size_t k = (size_t)g * N + (size_t)sr * w + x;
                 if (dtype == 0) a = ((const uint8_t *)src)[k];
                 else if (dtype == 1) a = prep_f32(((const float *)src)[k], mode, mf, af);
                 else a = prep_f64(((const double *)src)[k], mode, minFlux, addFlux);
                 gout[(size_t)r * w + x] = (uint8_t)a;
+                if (a) nzpos |= 1u << i;
                 if (a) atomicAdd(&sh[wv][a], 1); else zeros++;
             }
         }
@@ -143,6 +154,21 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
     // zeros dominate sky frames: count them in registers, one LDS add per wave
     for (int off = 32; off > 0; off >>= 1) zeros += __shfl_down(zeros, off);
     if (lfd_lane() == 0 && zeros) atomicAdd(&sh[wv][0], zeros);
+    // occupied cells of this workgroup's rows (one band): position i of wave wv covers ppl pixels per lane
+    // from column 256 ppl i + 64 ppl wv on, i.e. (64 ppl / 16) cells
+    if (cellbm && r0 < h) {
+        const int ppl = (dtype == 1 && (w & 3) == 0) ? 4 : 1, lpc = CELLBM_COLS / ppl; // lanes per cell: 4 or 16
+        u64 *bw = cellbm + ((size_t)g * bm_bands + r0 / CELLBM_ROWS) * CELLBM_WORDS;
+        for (int i = 0; (256 * ppl) * i < w; i++) {
+            u64 m = __ballot((nzpos >> i) & 1u);
+            if (!m || lfd_lane() != 0) continue;
+            u64 cells = 0;
+            for (int k = 0; k < 64 / lpc; k++)
+                if ((m >> (k * lpc)) & (lpc == 4 ? 0xFull : 0xFFFFull)) cells |= 1ull << k;
+            int c0 = (256 * ppl * i + 64 * ppl * wv) / CELLBM_COLS; // first cell of this wave's stretch (16 or 4 cells)
+            atomicOr((unsigned long long *)&bw[c0 >> 6], cells << (c0 & 63));
+        }
+    }
     __syncthreads();
     int b = threadIdx.x;
     int s = sh[0][b] + sh[1][b] + sh[2][b] + sh[3][b];
@@ -163,7 +189,7 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
 #define PE_THREADS 1024
 __global__ void __launch_bounds__(PE_THREADS)
 k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float af, uint8_t *dst, int *hist, int kh, int kw,
-             int BR, const int *active) {
+             int BR, u64 *cellbm, int bm_bands, const int *active) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t smb[];
@@ -260,6 +286,9 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
             outw[q] = __builtin_bit_cast(uint32_t, mE) | (__builtin_bit_cast(uint32_t, mO) << 8);
         }
         *(uint4 *)(d + (size_t)gy * w + 16 * x16) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+        // a lane's 16 bytes are one cell of the occupancy bitmap
+        if (cellbm && (outw[0] | outw[1] | outw[2] | outw[3]))
+            atomicOr((unsigned long long *)&cellbm[((size_t)g * bm_bands + gy / CELLBM_ROWS) * CELLBM_WORDS + (x16 >> 6)], 1ull << (x16 & 63));
     }
 }
 
@@ -864,6 +893,8 @@ k_dilate_canny_v(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
 #define DCW_TS 112           // tin / px row stride in bytes: 96 used, 16-byte aligned, rows spread over the banks
 #define DCW_NWD 18           // word columns per row: tile columns -4 .. 67
 #define DCW_MAXKH 13         // DCW_PH + kh - 1 <= 32 rows: one 32-bit mask per column
+#define DCW_MAXS 8            // tiles per strip (one wave walks a strip left to right)
+static_assert(DCW_TH == CELLBM_ROWS && CANNY_TW == 4 * CELLBM_COLS, "a tile is one band high and four cells wide");
 
 template <class F>
 __device__ __forceinline__ void dcw_for_live(u64 live, uint32_t colmask, int lane, F f) {
@@ -886,13 +917,16 @@ __device__ __forceinline__ void dcw_for_live(u64 live, uint32_t colmask, int lan
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
 k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *strong, const uint8_t *lut, int h, int w,
-                 int kh, int kw, int low, int high, const int *active, int nc, int tiles_x, int nstrips, int S) {
-    int L = blockIdx.x, xcd = L & 7, jb_ = L >> 3, per = tiles_x * nstrips;
+                 int kh, int kw, int low, int high, const int *active, int nc, int tiles_x, int nstripx, int S, const u64 *cellbm,
+                 int bm_bands) {
+    const int tiles_y = (h + DCW_TH - 1) / DCW_TH;
+    int L = blockIdx.x, xcd = L & 7, jb_ = L >> 3, per = tiles_y * nstripx;
     int g = (jb_ / per) * 8 + xcd;
     if (g >= nc) return;
     if (active && !active[g]) return;
     int rem = jb_ - (jb_ / per) * per;
-    int strip = rem / tiles_x, tx = rem - strip * tiles_x;
+    const int ty = rem / nstripx, tx0 = (rem - ty * nstripx) * S;
+    const int ntile = min(S, tiles_x - tx0); // tiles of this strip: tx0 .. tx0 + ntile - 1, left to right
     extern __shared__ __attribute__((aligned(16))) uint8_t smw[];
     const int PH = DCW_PH, MH = DCW_MH, NWD = DCW_NWD, TS = DCW_TS, TSW = DCW_TS / 4;
     const int IH = PH + kh - 1;
@@ -906,35 +940,57 @@ k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
     __shared__ uint32_t Pm[8];                         // input piece column p: rows holding a non-zero byte
     __shared__ u64 rowc[DCW_TH], rows[DCW_TH];         // NMS output bit rows of the tile
     const int lane = threadIdx.x;
-    const int x0 = tx * CANNY_TW;
     const int ay = kh / 2, ax = kw / 2;
     const size_t N = (size_t)h * w;
     const uint8_t *s = src + (size_t)g * N;
     const int wq = LFD_WQ(w);
     uint8_t *d = equ ? equ + (size_t)g * N : nullptr;
     const int npieces = IH * 6;                        // <= 192: three 16-byte pieces per lane
-    int iy[3], wx[3], gxp[3];
-    bool colok[3], has[3];
+    const int y0 = ty * DCW_TH;
+    int iy[3], wx[3];
+    bool rowok[3], has[3];
 #pragma unroll
     for (int p = 0; p < 3; p++) {
         int idx = lane + 64 * p;
         iy[p] = idx / 6;
         wx[p] = idx - iy[p] * 6;
         has[p] = idx < npieces;
-        gxp[p] = x0 - CANNY_HALO + 16 * wx[p];
-        colok[p] = has[p] && gxp[p] >= 0 && gxp[p] < w;
+        int gy = y0 - 2 - ay + iy[p];
+        rowok[p] = has[p] && gy >= 0 && gy < h;
     }
-    const int tiles_y = (h + DCW_TH - 1) / DCW_TH;
-    int ty = strip * S, ty_end = min(ty + S, tiles_y);
-    uint4 v[3];
-    {
-        int gy = ty * DCW_TH - 2 - ay;
+    // Cell occupancy from the prep kernel (cell_mark): which 16-pixel x 16-row cells of the input hold a
+    // non-zero byte.  A tile reads columns x0 - 16 .. x0 + 79 (cells 4 tx - 1 .. 4 tx + 4) of rows inside the
+    // bands ty - 1 .. ty + 1; if those 18 cells are clear its outputs are written without loading anything.
+    // bit j of `busy` = cell column 4 tx0 - 1 + j is occupied in one of the three bands.
+    u64 busy = ~0ull;
+    if (cellbm) {
+        u64 f = 0;
+        int band = ty - 1 + lane;
+        if (lane < 3 && band >= 0 && band < bm_bands) {
+            const u64 *bw = cellbm + ((size_t)g * bm_bands + band) * CELLBM_WORDS;
+            int c0 = 4 * tx0 - 1, cs = max(c0, 0), wi = cs >> 6, sh = cs & 63;
+            f = bw[wi] >> sh;
+            if (sh && wi + 1 < CELLBM_WORDS) f |= bw[wi + 1] << (64 - sh);
+            if (c0 < 0) f <<= 1;
+        }
+        unsigned lo = (unsigned)f, hi = (unsigned)(f >> 32);
+        lo = __builtin_amdgcn_readlane(lo, 0) | __builtin_amdgcn_readlane(lo, 1) | __builtin_amdgcn_readlane(lo, 2);
+        hi = __builtin_amdgcn_readlane(hi, 0) | __builtin_amdgcn_readlane(hi, 1) | __builtin_amdgcn_readlane(hi, 2);
+        busy = ((u64)hi << 32) | lo;
+    }
+    auto needed = [&](int t) { return ((busy >> (4 * t)) & 0x3Full) != 0; };
+    auto load_tile = [&](int t, uint4 *v) {
+        int xl = (tx0 + t) * CANNY_TW - CANNY_HALO;
 #pragma unroll
         for (int p = 0; p < 3; p++) {
             v[p] = make_uint4(0, 0, 0, 0); // out-of-image samples are ignored by a dilation
-            if (colok[p] && gy + iy[p] >= 0 && gy + iy[p] < h) v[p] = *(const uint4 *)(s + (size_t)(gy + iy[p]) * w + gxp[p]);
+            int gx = xl + 16 * wx[p];
+            if (rowok[p] && gx >= 0 && gx < w) v[p] = *(const uint4 *)(s + (size_t)(y0 - 2 - ay + iy[p]) * w + gx);
         }
-    }
+    };
+    uint4 v[3];
+    v[0] = v[1] = v[2] = make_uint4(0, 0, 0, 0);
+    if (needed(0)) load_tile(0, v);
 #pragma unroll
     for (int p = 0; p < 4; p++) slut[lane + 64 * p] = lut ? lut[g * 256 + lane + 64 * p] : (uint8_t)(lane + 64 * p);
     if (lane < 8) Pm[lane] = 0u;
@@ -943,25 +999,20 @@ k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
     zw |= zw << 8; zw |= zw << 16;
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     const uint32_t mPH = (1u << PH) - 1, mMH = (1u << MH) - 1, mIH = IH >= 32 ? ~0u : ((1u << IH) - 1);
-    for (; ty < ty_end; ty++) {
-        const int y0 = ty * DCW_TH;
+    for (int t = 0; t < ntile; t++) {
+        const int tx = tx0 + t, x0 = tx * CANNY_TW;
         uint32_t anyv = 0;
+        if (needed(t)) {
 #pragma unroll
-        for (int p = 0; p < 3; p++)
-            if (has[p]) {
-                uint32_t nzv = v[p].x | v[p].y | v[p].z | v[p].w;
-                if (nzv) atomicOr(&Pm[wx[p]], 1u << iy[p]);
-                anyv |= nzv;
-                *(uint4 *)(tin + iy[p] * TS + wx[p] * 16) = v[p];
-            }
-        if (ty + 1 < ty_end) { // next tile's input: in flight while this tile is processed
-            int gy = y0 + DCW_TH - 2 - ay;
-#pragma unroll
-            for (int p = 0; p < 3; p++) {
-                v[p] = make_uint4(0, 0, 0, 0);
-                if (colok[p] && gy + iy[p] >= 0 && gy + iy[p] < h) v[p] = *(const uint4 *)(s + (size_t)(gy + iy[p]) * w + gxp[p]);
-            }
+            for (int p = 0; p < 3; p++)
+                if (has[p]) {
+                    uint32_t nzv = v[p].x | v[p].y | v[p].z | v[p].w;
+                    if (nzv) atomicOr(&Pm[wx[p]], 1u << iy[p]);
+                    anyv |= nzv;
+                    *(uint4 *)(tin + iy[p] * TS + wx[p] * 16) = v[p];
+                }
         }
+        if (t + 1 < ntile && needed(t + 1)) load_tile(t + 1, v); // next tile's input: in flight while this one is processed
         if (__ballot(anyv != 0) == 0ull) {
             // empty neighbourhood: the dilated tile and its ring are lut[0] everywhere: no gradient
             if (d) {

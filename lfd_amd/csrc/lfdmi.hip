@@ -70,6 +70,9 @@ struct lfdmi_ctx {
     int *counters = nullptr, *need_dim = nullptr;
     int2 *rsa = nullptr;               // k_frame_contours: (row slot, component) per candidate run, FRAME_RUNCAP per slot
     long long *prof = nullptr;         // LFDMI_FRAME_PROFILE=1: per-frame phase clocks of k_frame_contours (developer tool)
+    u64 *cellbm = nullptr;             // cell occupancy of the last prep output, bm_bands x CELLBM_WORDS words per slot
+    int bm_bands = 0;
+    bool use_cellbm = true;
     int *fb_fg = nullptr, *fb_bg = nullptr; // per slot: frame left to the multi-workgroup run kernels (k_frame.h)
     lfdmi_result *res_dev = nullptr;
     void *stage = nullptr;
@@ -189,7 +192,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     if (const char *e = getenv("LFDMI_VOTE_SPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->vote_split = v; }
     if (const char *e = getenv("LFDMI_PE_ROWS")) { int v = atoi(e); if (v >= 2 && v <= 64) ctx->pe_rows = v; }
     if (const char *e = getenv("LFDMI_FRAME_RUNCAP")) { int v = atoi(e); if (v >= 0 && v < FRAME_RUNCAP) ctx->frame_runcap = v; }
-    if (const char *e = getenv("LFDMI_DC_STRIP")) { int v = atoi(e); if (v >= 1 && v <= 256) ctx->dc_strip = v; } // tuning knob
+    if (const char *e = getenv("LFDMI_DC_STRIP")) { int v = atoi(e); if (v >= 1 && v <= DCW_MAXS) ctx->dc_strip = v; } // tuning knob
     ctx->N = (size_t)max_h * max_w;
     ctx->wq = LFD_WQ(max_w);
     size_t N = ctx->N, G = (size_t)max_inflight, BW = (size_t)max_h * ctx->wq;
@@ -224,6 +227,9 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
         RET(dmalloc(ctx, p, G * ctx->run_cap));
     if (getenv("LFDMI_FRAME_PROFILE")) RET(dmalloc(ctx, &ctx->prof, G * 8));
     RET(dmalloc(ctx, &ctx->rsa, G * FRAME_RUNCAP));
+    ctx->bm_bands = (max_h + CELLBM_ROWS - 1) / CELLBM_ROWS;
+    RET(dmalloc(ctx, &ctx->cellbm, G * ctx->bm_bands * CELLBM_WORDS));
+    if (const char *e = getenv("LFDMI_CELLBM")) ctx->use_cellbm = atoi(e) != 0;
     RET(dmalloc(ctx, &ctx->fb_fg, G));
     RET(dmalloc(ctx, &ctx->fb_bg, G));
     RET(dmalloc(ctx, &ctx->scanf_, G * BW));
@@ -367,10 +373,11 @@ static dim3 word_grid(int h, int w, int n) { return dim3((unsigned)((h * LFD_WQ(
 static int run_prep(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int mode,
                     double minFlux, double addFlux, const int *active) {
     HIPCHK(hipMemsetAsync(ctx->hist, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->cellbm, 0, (size_t)nc * ctx->bm_bands * CELLBM_WORDS * sizeof(u64), ctx->stream));
     {
         Span sp(ctx, KID_PREP_HIST);
         k_prep_hist<<<dim3((h + PREP_ROWS - 1) / PREP_ROWS, nc), 256, 0, ctx->stream>>>(
-            src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist, active);
+            src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist, ctx->cellbm, ctx->bm_bands, active);
         KCHK("k_prep_hist");
     }
     Span sp(ctx, KID_LUT);
@@ -471,16 +478,17 @@ static bool can_fuse_dilate_canny(const uint8_t *kernel, int kh, int kw, int w) 
 }
 
 static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, int w, const uint8_t *lut, int kh, int kw,
-                            const int *active) {
+                            const int *active, bool use_bm) {
     if (kh <= DCW_MAXKH) { // one wave per 64 x 16 tile, mask-driven (the sparse pass images)
         int IH = DCW_PH + kh - 1, MGB = DCW_MH * CANNY_MW * 2;
         size_t lds = (size_t)(IH * DCW_TS > MGB ? IH * DCW_TS : MGB) + (size_t)IH * DCW_NWD * 4 + (size_t)DCW_PH * DCW_TS;
         int tiles_x = (w + CANNY_TW - 1) / CANNY_TW, tiles_y = (h + DCW_TH - 1) / DCW_TH;
-        int S = ctx->dc_strip, nstrips = (tiles_y + S - 1) / S;
-        unsigned grid = 8u * ((nc + 7) / 8) * tiles_x * nstrips; // frame = 8 * (j / tiles) + (block & 7): one XCD per frame
+        int S = ctx->dc_strip, nstripx = (tiles_x + S - 1) / S;
+        unsigned grid = 8u * ((nc + 7) / 8) * tiles_y * nstripx; // frame = 8 * (j / strips) + (block & 7): one XCD per frame
         Span sp(ctx, KID_DILATE_CANNY);
         k_dilate_canny_w<<<grid, 64, lds, ctx->stream>>>(src, ctx->keep_equ ? ctx->equ : nullptr, ctx->equb, ctx->candb,
-                                                          ctx->strongb, lut, h, w, kh, kw, 0, 255, active, nc, tiles_x, nstrips, S);
+                                                          ctx->strongb, lut, h, w, kh, kw, 0, 255, active, nc, tiles_x, nstripx, S,
+                                                          use_bm ? ctx->cellbm : nullptr, ctx->bm_bands);
         KCHK("k_dilate_canny_w");
         return 0;
     }
@@ -689,12 +697,13 @@ static bool can_fuse_prep_erode(const lfdmi_ctx *ctx, int dtype, int w, const ui
 static int run_prep_erode(lfdmi_ctx *ctx, const void *src, int nc, int h, int w, int flip, int mode, double minFlux, double addFlux,
                           int kh, int kw, const int *active) {
     HIPCHK(hipMemsetAsync(ctx->hist, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->cellbm, 0, (size_t)nc * ctx->bm_bands * CELLBM_WORDS * sizeof(u64), ctx->stream));
     int BR = prep_erode_rows(ctx, w, kh);
     size_t lds = (size_t)(2 * BR + kh - 1) * (w + 32) + 16; // (+ one piece: the sliding window peeks one word ahead)
     {
         Span sp(ctx, KID_PREP_ERODE);
         k_prep_erode<<<dim3((h + BR - 1) / BR, nc), PE_THREADS, lds, ctx->stream>>>((const float *)src, h, w, flip, mode, (float)minFlux,
-                                                                               (float)addFlux, ctx->tmp, ctx->hist, kh, kw, BR, active);
+                                                                               (float)addFlux, ctx->tmp, ctx->hist, kh, kw, BR, ctx->cellbm, ctx->bm_bands, active);
         KCHK("k_prep_erode");
     }
     Span sp(ctx, KID_LUT);
@@ -719,7 +728,8 @@ static int run_pass(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, i
         }
     }
     if (can_fuse_dilate_canny(p->dilateKernel, p->dilate_kh, p->dilate_kw, w)) {
-        RET(run_dilate_canny(ctx, dil_src, nc, h, w, ctx->lut, p->dilate_kh, p->dilate_kw, active));
+        // the prep kernel of this pass left the cell occupancy of its output (a superset of the eroded image's)
+        RET(run_dilate_canny(ctx, dil_src, nc, h, w, ctx->lut, p->dilate_kh, p->dilate_kw, active, ctx->use_cellbm));
         RET(run_canny(ctx, ctx->equ, nc, h, w, 0, 255, active, true));
     } else {
         RET(run_morph(ctx, dil_src, ctx->equ, ctx->equb, ctx->lut, p->dilateKernel, p->dilate_kh, p->dilate_kw, 0, nc, h, w, active));
