@@ -241,3 +241,26 @@ def test_fused_prep_erode_matches_separate_kernels(oracle, monkeypatch):
     ctx = _native.Context(0, 1489, 2048, 4)
     assert same(ctx.detect_batch(frames.copy(), pb, pd)[0], want)
     ctx.close()
+
+
+def test_cell_bitmap_and_general_run_kernels_do_not_change_results(monkeypatch):
+    """LFDMI_CELLBM=0 (every tile of the fused dilate + Canny kernel loads its input) and
+    LFDMI_FRAME_CCL=0 (multi-workgroup run kernels instead of the per-frame LDS kernels) against
+    the default fast paths: identical records and edge images."""
+    from lfd_amd import _native, synth
+    pb, pd, prs = params()
+    frames = np.stack([synth.make_frame(k, with_catalog=False)[0] for k in range(6)])
+    outs = []
+    for env in ({}, {"LFDMI_CELLBM": "0"}, {"LFDMI_FRAME_CCL": "0"}):
+        for k in ("LFDMI_CELLBM", "LFDMI_FRAME_CCL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = _native.Context(0, 1489, 2048, 6)
+        res = ctx.detect_batch(frames.copy(), pb, pd)
+        outs.append((res.tobytes(), [ctx.get_stage(i, _native.STAGE_CANNY, 1489, 2048) for i in range(6)]))
+        ctx.close()
+    for o in outs[1:]:
+        assert o[0] == outs[0][0]
+        for a, b in zip(o[1], outs[0][1]):
+            assert np.array_equal(a, b)
