@@ -23,14 +23,16 @@ __device__ __forceinline__ void py_slice(long start, long stop, long len, int *a
     *a = (int)start; *b = (int)stop;
 }
 
+// one WAVE per catalogue object (four per workgroup, no workgroup barrier): lane 0 evaluates the
+// tests, the wave zero-fills the square row by row
 __global__ void __launch_bounds__(256)
 k_removestars(float *frames, int h, int w, int max_obj, const int *count, const float *rowc,
               const float *colc, const float *psfmag, const float *petro90, const int *nobserve,
               const int *ndetect, RsDev p) {
-    int f = blockIdx.y, i = blockIdx.x;
+    int f = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= count[f]) return;
-    __shared__ int box[4];
-    if (threadIdx.x == 0) {
+    int r0 = 0, r1 = 0, c0 = 0, c1 = 0;
+    if (lane == 0) {
         size_t o5 = ((size_t)f * max_obj + i) * 5, o1 = (size_t)f * max_obj + i;
         int fi = p.filter_index;
         long x = (long)ceil((double)colc[o5 + fi]);
@@ -51,21 +53,22 @@ k_removestars(float *frames, int h, int w, int max_obj, const int *count, const 
         if (pet > 0) dxy = (long)((double)pet / p.pixscale) + 10;
         if (dxy > p.maxxy) dxy = p.defaultxy;
         ok = ok && (nobserve[o1] == ndetect[o1]);
-        int r0 = 0, r1 = 0, c0 = 0, c1 = 0;
         if (ok) {
             py_slice(x - dxy, x + dxy, h, &r0, &r1);
             py_slice(y - dxy, y + dxy, w, &c0, &c1);
         }
-        box[0] = r0; box[1] = r1; box[2] = c0; box[3] = c1;
     }
-    __syncthreads();
-    int r0 = box[0], r1 = box[1], c0 = box[2], c1 = box[3];
-    int nr = r1 - r0, nc = c1 - c0;
-    if (nr <= 0 || nc <= 0) return;
+    r0 = __builtin_amdgcn_readfirstlane(r0); r1 = __builtin_amdgcn_readfirstlane(r1);
+    c0 = __builtin_amdgcn_readfirstlane(c0); c1 = __builtin_amdgcn_readfirstlane(c1);
+    int nc = c1 - c0;
+    if (r1 <= r0 || nc <= 0) return;
     float *img = frames + (size_t)f * h * w;
-    for (int k = threadIdx.x; k < nr * nc; k += blockDim.x) {
-        int r = r0 + k / nc, c = c0 + k % nc;
-        img[(size_t)r * w + c] = 0.0f;
+    if (nc <= 32) { // two rows per step
+        for (int r = r0 + (lane >> 5); r < r1; r += 2)
+            if ((lane & 31) < nc) img[(size_t)r * w + c0 + (lane & 31)] = 0.0f;
+    } else {
+        for (int r = r0; r < r1; r++)
+            for (int c = c0 + lane; c < c1; c += 64) img[(size_t)r * w + c] = 0.0f;
     }
 }
 

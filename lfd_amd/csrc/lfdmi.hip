@@ -986,7 +986,7 @@ static int run_removestars(lfdmi_ctx *ctx, float *frames_dev, int f0, int nc, in
     p.defaultxy = rs->defaultxy; p.maxxy = rs->maxxy; p.magcount = rs->magcount; p.filter_index = rs->filter_index;
     p.pixscale = rs->pixscale; p.maxmagdiff = rs->maxmagdiff; p.filter_cap = rs->filter_cap;
     Span sp(ctx, KID_REMOVESTARS);
-    k_removestars<<<dim3(cat->max_obj, nc), 256, 0, ctx->stream>>>(frames_dev, h, w, cat->max_obj, dev.count, dev.rowc, dev.colc,
+    k_removestars<<<dim3((cat->max_obj + 3) / 4, nc), 256, 0, ctx->stream>>>(frames_dev, h, w, cat->max_obj, dev.count, dev.rowc, dev.colc,
                                                                    dev.psfmag, dev.petro90, dev.nobserve, dev.ndetect, p);
     KCHK("k_removestars");
     return 0;
