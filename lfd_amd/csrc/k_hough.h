@@ -22,9 +22,13 @@ __device__ __forceinline__ uint32_t chunk_entry(int y, int x0, int len) {
 }
 
 __global__ void __launch_bounds__(256)
-k_pixlist(const u64 *bits, uint32_t *list, int *counters, int cidx, int nnz_idx, int chunk_max, int h, int w, size_t list_cap,
-          int *accum_clear, int acc_n, size_t acc_stride, const int *active, int need_detect) {
-    int g = blockIdx.y;
+k_pixlist(const u64 *bits0, const u64 *bits1, uint32_t *list0, uint32_t *list1, int *counters, int chunk_max, int h, int w,
+          size_t list_cap, int *accum_clear, int acc_n, size_t acc_stride, const int *active, int need_detect) {
+    int g = blockIdx.y, im = blockIdx.z; // image 0: equ, image 1: box_img
+    const u64 *bits = im ? bits1 : bits0;
+    uint32_t *list = im ? list1 : list0;
+    const int cidx = im ? C_NPIX_BOX : C_NPIX_EQU, nnz_idx = im ? C_NNZ_BOX : C_NNZ_EQU;
+    if (accum_clear) accum_clear += (size_t)im * acc_stride;
     if (active && !active[g]) return;
     int *cnt = counters + g * C_COUNT;
     if (need_detect && !cnt[C_DETECT]) return;
