@@ -9,7 +9,10 @@
 // always point to the smaller id, so every component's root is its raster-first run either way.
 // A frame with more runs than the LDS table holds is left to the multi-workgroup kernels of
 // k_ccl.h: each k_frame_* kernel writes a per-frame `fallback` flag those are launched with as
-// their `active` mask (they exit at once when the flag is clear).
+// their `active` mask (they exit at once when the flag is clear), and raises PASS_FLAG_GENERAL in
+// the frame's pass flags.  The host launches the general kernels only once a context has seen such
+// a frame (22 empty launches per pass otherwise): a chunk that raises the flag while they were not
+// launched is simply run again with them (lfdmi.hip: general_on).
 //
 // Every phase walks the work list through frame_pipeline(): the global loads of an item (its
 // words, their scan entries) do not depend on any table, so the loads of the NEXT item and the
@@ -19,6 +22,7 @@
 #include "k_ccl.h"
 #include "k_rect.h"
 
+#define PASS_FLAG_GENERAL 256 // pass_flags bit: this frame needs the general (multi-workgroup) run kernels
 #define FRAME_THREADS 1024
 #define FRAME_HOLECAP 1024 // hash slots for the holes of a frame (more holes: looked up in the global tables)
 #define FRAME_RUNCAP 32768 // runs per frame the LDS label table holds (128 KB); busier frames take the k_ccl.h kernels
@@ -83,7 +87,8 @@ struct FgWordItem { int idx, id0; u64 c, cp, m; };
 // k_runs_merge8, k_runs_flatten(fg) and k_edge_from_cand.
 __global__ void __launch_bounds__(FRAME_THREADS)
 k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_fg, const int *counters, int *Lf, int *YMf,
-           int *FLf, int *ROWf, u64 *edge, int h, int w, int run_cap, int lds_cap, const int *active, int *fallback) {
+           int *FLf, int *ROWf, u64 *edge, int h, int w, int run_cap, int lds_cap, const int *active, int *fallback,
+           int *pass_flags) {
     const int g = blockIdx.x;
     if (active && !active[g]) {
         if (threadIdx.x == 0) fallback[g] = 0;
@@ -93,7 +98,10 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
     const size_t fo = (size_t)g * h * wq, ro = (size_t)g * run_cap;
     const int nwork = counters[g * C_COUNT + C_NFGW], nrun = counters[g * C_COUNT + C_NRUNF];
     const bool fits = nrun <= lds_cap; // lds_cap <= FRAME_RUNCAP (k_scan_runs flags nrun > run_cap as an overflow)
-    if (threadIdx.x == 0) fallback[g] = fits ? 0 : 1;
+    if (threadIdx.x == 0) {
+        fallback[g] = fits ? 0 : 1;
+        if (!fits) atomicOr(&pass_flags[g], PASS_FLAG_GENERAL); // tells the host the general kernels are needed
+    }
     if (!fits) return;
     extern __shared__ int sm_frame[];
     int *L = sm_frame;
@@ -273,7 +281,7 @@ struct ExtItem { int idx, id0, sbc, sbu, sbd; u64 e, ep, en, c, cp, u, up, d, dp
 // kept in LDS.  Same tables, same values (the order of the keys is as arbitrary as before).
 __global__ void __launch_bounds__(FRAME_THREADS)
 k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, int4 *keys, int *bigkeys, int *medkeys, int2 *rowext,
-                 int2 *rsa, int h, int w, int key_cap, int slot_cap, int lds_cap, const int *active, int *fallback, long long *prof) {
+                 int2 *rsa, int h, int w, int key_cap, int slot_cap, int lds_cap, const int *active, int *fallback, int *pass_flags, long long *prof) {
     // developer profile (prof != nullptr): wall-clock ticks (10 ns) at the end of every phase, per frame
     const long long t0 = prof ? wall_clock64() : 0;
     int pk = 0;
@@ -292,7 +300,10 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
     const int nwork = counters[g * C_COUNT + C_NBGW], nrun = counters[g * C_COUNT + C_NRUNB];
     const int nwf = counters[g * C_COUNT + C_NFGW], nrunf = counters[g * C_COUNT + C_NRUNF];
     const bool fits = nrun <= lds_cap && nrunf <= lds_cap; // (then k_frame_fg took the frame too: FLf is set)
-    if (threadIdx.x == 0) fallback[g] = fits ? 0 : 1;
+    if (threadIdx.x == 0) {
+        fallback[g] = fits ? 0 : 1;
+        if (!fits) atomicOr(&pass_flags[g], PASS_FLAG_GENERAL);
+    }
     if (!fits) return;
     extern __shared__ int sm_frame[];
     int *L = sm_frame;

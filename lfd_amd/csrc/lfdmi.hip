@@ -95,6 +95,9 @@ struct lfdmi_ctx {
     int vote_split = 4;                // pieces a frame's Hough list is cut into at most
     int pe_rows = 12;                  // rows per band of k_prep_erode
     bool fuse_prep_erode = true;       // dim pass: prep + histogram + erosion in one kernel (LFDMI_FUSE_PREP_ERODE=0: separate)
+    // general run kernels beside the per-frame ones: launched once this context has met a frame that needs them
+    // (or always, for the per-operator entry points and with LFDMI_FRAME_CCL=0)
+    bool general_seen = false, general_on = true;
     bool frame_ccl = true;             // per-frame LDS connectivity kernels (k_frame.h)
     int frame_runcap = FRAME_RUNCAP;   // runs per frame they take (LFDMI_FRAME_RUNCAP lowers it: tests of the fallback path)
     int dc_strip = 8;                  // tiles per wave strip in k_dilate_canny_w
@@ -447,8 +450,10 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
         Span sp(ctx, KID_FRAME_FG);
         size_t lds = (size_t)(FRAME_RUNCAP + 2 * (FRAME_RUNCAP / 32)) * sizeof(int);
         k_frame_fg<<<nc, FRAME_THREADS, lds, ctx->stream>>>(ctx->candb, ctx->strongb, ctx->scanf_, ctx->wl_fg, ctx->counters, ctx->Lf,
-                                                            ctx->YMf, ctx->FLf, ctx->ROWf, ctx->edgeb, h, w, rc, ctx->frame_runcap, active, ctx->fb_fg);
+                                                            ctx->YMf, ctx->FLf, ctx->ROWf, ctx->edgeb, h, w, rc, ctx->frame_runcap, active, ctx->fb_fg,
+                                                            ctx->pass_flags);
         KCHK("k_frame_fg");
+        if (!ctx->general_on) return 0; // (a frame that did not fit raises PASS_FLAG_GENERAL: the caller runs the chunk again)
         active = ctx->fb_fg;
     }
     { Span sp(ctx, KID_RUNS_INIT_FG);
@@ -532,10 +537,11 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
         size_t lds = (size_t)(FRAME_RUNCAP + 4 * (FRAME_RUNCAP / 32)) * sizeof(int);
         k_frame_contours<<<nc, FRAME_THREADS, lds, ctx->stream>>>(rt, ctx->wl_fg, ctx->wl_bg, ctx->counters, ctx->keys, ctx->bigkeys,
                                                                   ctx->medkeys, ctx->rowext, ctx->rsa, h, w, ctx->key_cap, ctx->slot_cap,
-                                                                  ctx->frame_runcap, active, ctx->fb_bg, ctx->prof);
+                                                                  ctx->frame_runcap, active, ctx->fb_bg, ctx->pass_flags, ctx->prof);
         KCHK("k_frame_contours");
         gen = ctx->fb_bg;
     }
+    if (!ctx->frame_ccl || ctx->general_on) {
     { Span sp(ctx, KID_RUNS_INIT_BG);
       k_runs_init<<<lg, 256, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->scanb_, ctx->Lb, ctx->YMb, ctx->FLb, ctx->ROWb, h, w, rc,
                                                ctx->wl_bg, ctx->counters, C_NBGW, gen);
@@ -557,6 +563,7 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     { Span sp(ctx, KID_EXTREMES);
     k_extremes<<<lg, 256, 0, ctx->stream>>>(rt, ctx->rowext, h, w, ctx->slot_cap, ctx->wl_fg, ctx->counters, gen);
     KCHK("k_extremes"); }
+    }
     { Span sp(ctx, KID_RECTS);
     // Three independent kernels by key height (short: a lane per key; medium / tall: a wave per key).
     // Each is a handful of long serial hulls, so they run side by side: fork two helper streams off
@@ -1005,6 +1012,23 @@ extern "C" int lfdmi_remove_stars(lfdmi_ctx *ctx, float *img, int n, int h, int 
 }
 
 // ---- C-ABI: whole passes ------------------------------------------------------------------
+// Whole-pass entry points launch the general run kernels only once the context has met a frame the per-frame
+// LDS kernels could not take; a chunk that meets the first such frame is run again with them.
+struct GeneralGuard {
+    lfdmi_ctx *c;
+    explicit GeneralGuard(lfdmi_ctx *ctx) : c(ctx) { c->general_on = !c->frame_ccl || c->general_seen; }
+    ~GeneralGuard() { c->general_on = true; }
+    bool again(const int *flags, int n) {
+        if (c->general_on) return false;
+        bool need = false;
+        for (int i = 0; i < n; i++) need = need || (flags[i] & PASS_FLAG_GENERAL);
+        if (!need) return false;
+        c->general_seen = true;
+        c->general_on = true;
+        return true;
+    }
+};
+
 static int pass_api(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, int w, int flip, int prep_mode, bool dim,
                     const lfdmi_params *p, lfdmi_result *results, float *lines_equ, float *lines_box, int loc) {
     RET(check_shape(ctx, n, h, w));
@@ -1021,13 +1045,17 @@ static int pass_api(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, in
         int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
         const void *d;
         RET(in_ptr(ctx, img, (size_t)c0 * N * es, (size_t)nc * N * es, loc, &d));
-        k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, ctx->pass_flags, nc);
-        KCHK("k_init_results");
-        RET(run_pass(ctx, d, dtype, nc, h, w, flip, prep_mode, dim, p, nullptr, nullptr));
-        HIPCHK(hipMemcpyAsync(host.data(), ctx->res_dev, (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(hl.data(), ctx->lines, (size_t)nc * 2 * K * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(flags.data(), ctx->pass_flags, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        GeneralGuard gg(ctx);
+        for (;;) { // (again, with the general run kernels, if a frame turned out to need them)
+            k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, ctx->pass_flags, nc);
+            KCHK("k_init_results");
+            RET(run_pass(ctx, d, dtype, nc, h, w, flip, prep_mode, dim, p, nullptr, nullptr));
+            HIPCHK(hipMemcpyAsync(host.data(), ctx->res_dev, (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(hl.data(), ctx->lines, (size_t)nc * 2 * K * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(flags.data(), ctx->pass_flags, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (!gg.again(flags.data(), nc)) break;
+        }
         {
             int na[2] = {nc, 0}, nd[2] = {0, 0};
             for (int i = 0; i < nc; i++) nd[0] += (flags[i] & (dim ? 4 : 1)) != 0;
@@ -1074,12 +1102,14 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
         int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
         const void *d;
         RET(in_ptr(ctx, frames, (size_t)c0 * N * 4, (size_t)nc * N * 4, loc, &d));
-        k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, ctx->pass_flags, nc);
-        KCHK("k_init_results");
         if (cat) {
             RET(run_removestars(ctx, (float *)d, c0, nc, h, w, cat, rs));
             if (loc == LFDMI_HOST) RET(out_copy(ctx, frames, (size_t)c0 * N * 4, d, (size_t)nc * N * 4, loc));
         }
+        GeneralGuard gg(ctx);
+        for (;;) { // (again, with the general run kernels, if a frame turned out to need them)
+        k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, ctx->pass_flags, nc);
+        KCHK("k_init_results");
         ctx->cur_pass = 0;
         RET(run_pass(ctx, d, LFDMI_F32, nc, h, w, 1, LFDMI_PREP_BRIGHT, false, bright, nullptr, ctx->need_dim));
         ctx->cur_pass = 1;
@@ -1088,6 +1118,8 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
         HIPCHK(hipMemcpyAsync(host.data(), ctx->res_dev, (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(flags.data(), ctx->pass_flags, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (!gg.again(flags.data(), nc)) break;
+        }
         {
             int na[2] = {nc, 0}, nd[2] = {0, 0};
             for (int i = 0; i < nc; i++) { nd[0] += flags[i] & 1; na[1] += (flags[i] >> 1) & 1; nd[1] += (flags[i] >> 2) & 1; }
