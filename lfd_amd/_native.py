@@ -29,7 +29,7 @@ SYMBOLS = (
     "lfdmi_max_inflight", "lfdmi_prep_u8", "lfdmi_equalize_hist", "lfdmi_dilate", "lfdmi_erode",
     "lfdmi_canny", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
     "lfdmi_hough_dims", "lfdmi_remove_stars", "lfdmi_process_bright", "lfdmi_process_dim",
-    "lfdmi_detect_batch", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_get_timing",
+    "lfdmi_detect_batch", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_timing_select", "lfdmi_get_timing",
     "lfdmi_timing_slots", "lfdmi_timing_name",
 )
 
@@ -190,6 +190,14 @@ class Context:
 
     def enable_timing(self, on=True):
         self._chk(self._lib.lfdmi_enable_timing(self._h, int(on)))
+
+    def timing_select(self, name=None):
+        """Bracket only the launches of one timing slot (kernel name as in get_timing), or all (None)."""
+        slot = -1
+        if name is not None:
+            names = [self._lib.lfdmi_timing_name(i).decode() for i in range(self._lib.lfdmi_timing_slots())]
+            slot = names.index(name)
+        self._chk(self._lib.lfdmi_timing_select(self._h, slot))
 
     def get_timing(self):
         """{kernel name: (total device ms, launches, frames worked on)} since enable_timing(True)."""

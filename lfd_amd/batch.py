@@ -79,6 +79,10 @@ class BatchDetector:
         for c in self.ctxs:
             c.enable_timing(on)
 
+    def timing_select(self, name=None):
+        for c in self.ctxs:
+            c.timing_select(name)
+
     def get_timing(self):
         out = {}
         for c in self.ctxs:
