@@ -276,6 +276,27 @@ __device__ __forceinline__ void rect_from_hull(const HV &hv, double minLen, doub
                                                size_t quad_base, bool writer) {
     float cx = 0, cy = 0, sw = 0, sh = 0, angle = 0;
     if (hv.n > 2) {
+        // Cheap certain rejection before the calipers: the rectangle contains the hull (area sw * sh >= A) and
+        // its longer side is a projection extent of the hull (<= its diameter <= the bounding-box diagonal D),
+        // so length / width = length^2 / (sw * sh) <= D^2 / A.  A roundish contour (the Canny ring of a star,
+        // D^2 / A ~ 1.3) can never pass `length / width > lwTresh`; the 0.1 % margin is three orders of
+        // magnitude above the float32 noise of the exact computation.  Integer shoelace, exact.
+        {
+            int2 p0 = hv.at(0);
+            int xmin = p0.x, xmax = p0.x, ymin = p0.y, ymax = p0.y;
+            long long a2 = 0;
+            int2 prev = p0;
+            for (int i = 1; i < hv.n; i++) {
+                int2 q = hv.at(i);
+                a2 += (long long)prev.x * q.y - (long long)q.x * prev.y;
+                xmin = min(xmin, q.x); xmax = max(xmax, q.x); ymin = min(ymin, q.y); ymax = max(ymax, q.y);
+                prev = q;
+            }
+            a2 += (long long)prev.x * p0.y - (long long)p0.x * prev.y;
+            if (a2 < 0) a2 = -a2;
+            double d2 = (double)(xmax - xmin) * (xmax - xmin) + (double)(ymax - ymin) * (ymax - ymin);
+            if (a2 > 0 && lwTresh > 0 && 2.0 * d2 < lwTresh * (double)a2 * 0.999) return;
+        }
         float out[6];
         rotating_calipers_dev(hv, out);
         cx = __fadd_rn(out[0], __fmul_rn(__fadd_rn(out[2], out[4]), 0.5f));
