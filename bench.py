@@ -142,8 +142,9 @@ def main():
             torch.cuda.synchronize()
 
     # Per-launch HIP events cost ~6 % of a step when every one of its ~40 launches is bracketed, so inside
-    # the timed region only the dominant kernel is (two launches per step).  Which kernel that is comes from the
-    # warm-up steps (all launches bracketed); the per-kernel table of the JSON line comes from one extra,
+    # the timed region only the few largest kernels are (those that move pixels; the warm-up steps, fully
+    # bracketed, nominate four -- a cold first launch can distort a single winner); the dominant one is then
+    # chosen from the timed region's own sums.  The per-kernel table of the JSON line comes from one extra,
     # fully bracketed step AFTER the timed region.
     res = None
     det.enable_timing(not args.no_kernel_timing)
@@ -151,8 +152,8 @@ def main():
         res = step()
     torch.cuda.synchronize()
     warm = det.get_timing()
-    dominant = max(warm.items(), key=lambda kv: kv[1][0])[0] if any(v[1] for v in warm.values()) else "k_dilate_canny"
-    det.timing_select(dominant)
+    cands = sorted((k for k, v in warm.items() if v[1] and STAGE_BYTES_PER_PX.get(k, 0.0) > 0), key=lambda k: -warm[k][0])[:4]
+    det.timing_select(cands or ["k_dilate_canny", "k_prep_hist", "k_hough_vote", "k_prep_erode"])
     det.enable_timing(not args.no_kernel_timing)  # (re-arms and clears the sums)
     fence()
     t0 = time.perf_counter()

@@ -184,11 +184,11 @@ int lfdmi_get_counters(lfdmi_ctx *ctx, int slot0, int n, int32_t *dst);
  * actually worked on (a dim-pass launch only works on frames the bright pass left undecided,
  * a Hough launch only on frames with a detected rectangle) since lfdmi_enable_timing(ctx, 1).
  * lfdmi_timing_slots() slots, named by lfdmi_timing_name(i) (the kernel's name).
- * lfdmi_timing_select(ctx, slot) restricts the bracketing to one slot's launches (slot < 0: all
- * again): the ~80 event records of a fully timed step cost ~6 % of it, two records per step do
- * not, so bench.py times only the dominant kernel inside its timed region. */
+ * lfdmi_timing_select(ctx, mask) restricts the bracketing to the slots whose bit is set in mask
+ * (0: all again): the ~80 event records of a fully timed step cost ~6 % of it, a handful per step
+ * do not, so bench.py times only the few largest kernels inside its timed region. */
 int lfdmi_enable_timing(lfdmi_ctx *ctx, int on);
-int lfdmi_timing_select(lfdmi_ctx *ctx, int slot);
+int lfdmi_timing_select(lfdmi_ctx *ctx, uint64_t mask);
 int lfdmi_get_timing(lfdmi_ctx *ctx, float *ms, int32_t *launches, int64_t *units);
 int lfdmi_timing_slots(void);
 const char *lfdmi_timing_name(int slot);

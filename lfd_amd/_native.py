@@ -191,13 +191,15 @@ class Context:
     def enable_timing(self, on=True):
         self._chk(self._lib.lfdmi_enable_timing(self._h, int(on)))
 
-    def timing_select(self, name=None):
-        """Bracket only the launches of one timing slot (kernel name as in get_timing), or all (None)."""
-        slot = -1
-        if name is not None:
-            names = [self._lib.lfdmi_timing_name(i).decode() for i in range(self._lib.lfdmi_timing_slots())]
-            slot = names.index(name)
-        self._chk(self._lib.lfdmi_timing_select(self._h, slot))
+    def timing_select(self, names=None):
+        """Bracket only the launches of the given timing slots (kernel names as in get_timing), or all (None)."""
+        mask = 0
+        if names:
+            known = [self._lib.lfdmi_timing_name(i).decode() for i in range(self._lib.lfdmi_timing_slots())]
+            for nm in ([names] if isinstance(names, str) else names):
+                mask |= 1 << known.index(nm)
+        self._lib.lfdmi_timing_select.argtypes = [C.c_void_p, C.c_uint64]
+        self._chk(self._lib.lfdmi_timing_select(self._h, mask))
 
     def get_timing(self):
         """{kernel name: (total device ms, launches, frames worked on)} since enable_timing(True)."""

@@ -79,9 +79,9 @@ class BatchDetector:
         for c in self.ctxs:
             c.enable_timing(on)
 
-    def timing_select(self, name=None):
+    def timing_select(self, names=None):
         for c in self.ctxs:
-            c.timing_select(name)
+            c.timing_select(names)
 
     def get_timing(self):
         out = {}

@@ -86,7 +86,7 @@ struct lfdmi_ctx {
     int tab_h = 0, tab_w = 0, numangle = 0, numrho = 0;
     // timing
     bool timing = false;
-    int timing_only = -1;              // >= 0: only this timing slot's launches are bracketed (lfdmi_timing_select)
+    uint64_t timing_mask = 0;          // non-zero: only these timing slots' launches are bracketed (lfdmi_timing_select)
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> ev_pool;
     float t_ms[TG_COUNT] = {0};
@@ -135,7 +135,7 @@ struct Span {
     lfdmi_ctx *c;
     int idx = -1;
     Span(lfdmi_ctx *ctx, int group, int det = 0) : c(ctx) {
-        if (!c->timing || (c->timing_only >= 0 && group != c->timing_only)) return;
+        if (!c->timing || (c->timing_mask && !((c->timing_mask >> group) & 1ull))) return;
         TimedSpan s;
         s.group = group;
         s.pass = ctx->cur_pass;
@@ -311,9 +311,10 @@ extern "C" int lfdmi_enable_timing(lfdmi_ctx *ctx, int on) {
     memset(ctx->t_units, 0, sizeof ctx->t_units);
     return 0;
 }
-extern "C" int lfdmi_timing_select(lfdmi_ctx *ctx, int slot) {
-    if (!ctx || slot >= TG_COUNT) return LFDMI_ERR_ARG;
-    ctx->timing_only = slot < 0 ? -1 : slot;
+extern "C" int lfdmi_timing_select(lfdmi_ctx *ctx, uint64_t mask) {
+    static_assert(TG_COUNT <= 64, "one bit per timing slot");
+    if (!ctx) return LFDMI_ERR_ARG;
+    ctx->timing_mask = mask;
     return 0;
 }
 extern "C" int lfdmi_get_timing(lfdmi_ctx *ctx, float *ms, int32_t *launches, int64_t *units) {
