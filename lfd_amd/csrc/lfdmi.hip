@@ -68,6 +68,8 @@ struct lfdmi_ctx {
     u64 *peaks = nullptr;
     float *lines = nullptr, *tab = nullptr;
     int *counters = nullptr, *need_dim = nullptr;
+    uint8_t *zero_block = nullptr;     // cellbm | hist | counters
+    size_t zero_bytes = 0;
     int2 *rsa = nullptr;               // k_frame_contours: (row slot, component) per candidate run, FRAME_RUNCAP per slot
     long long *prof = nullptr;         // LFDMI_FRAME_PROFILE=1: per-frame phase clocks of k_frame_contours (developer tool)
     u64 *cellbm = nullptr;             // cell occupancy of the last prep output, bm_bands x CELLBM_WORDS words per slot
@@ -219,7 +221,6 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     RET(dmalloc(ctx, &ctx->equ, G * N));
     RET(dmalloc(ctx, &ctx->lut, G * 256));
     RET(dmalloc(ctx, &ctx->mask, (size_t)LFDMI_MAX_MORPH_K * LFDMI_MAX_MORPH_K * 2));
-    RET(dmalloc(ctx, &ctx->hist, G * 256));
     RET(dmalloc(ctx, &ctx->candb, G * BW));
     RET(dmalloc(ctx, &ctx->strongb, G * BW));
     RET(dmalloc(ctx, &ctx->edgeb, G * BW));
@@ -232,7 +233,6 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     if (getenv("LFDMI_FRAME_PROFILE")) RET(dmalloc(ctx, &ctx->prof, G * 8));
     RET(dmalloc(ctx, &ctx->rsa, G * FRAME_RUNCAP));
     ctx->bm_bands = (max_h + CELLBM_ROWS - 1) / CELLBM_ROWS;
-    RET(dmalloc(ctx, &ctx->cellbm, G * ctx->bm_bands * CELLBM_WORDS));
     if (const char *e = getenv("LFDMI_CELLBM")) ctx->use_cellbm = atoi(e) != 0;
     RET(dmalloc(ctx, &ctx->fb_fg, G));
     RET(dmalloc(ctx, &ctx->fb_bg, G));
@@ -252,7 +252,16 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     RET(dmalloc(ctx, &ctx->peaks, G * 2 * ctx->peak_cap));
     RET(dmalloc(ctx, &ctx->lines, G * 2 * LFDMI_MAX_SET_LINES * 2));
     RET(dmalloc(ctx, &ctx->tab, (size_t)2 * MAX_ANGLES));
-    RET(dmalloc(ctx, &ctx->counters, G * C_COUNT));
+    {   // counters, histograms and the cell bitmap start every pass at zero: one block, one fill per pass
+        size_t nb_cnt = G * C_COUNT * sizeof(int), nb_hist = G * 256 * sizeof(int), nb_bm = G * ctx->bm_bands * CELLBM_WORDS * sizeof(u64);
+        uint8_t *blk = nullptr;
+        RET(dmalloc(ctx, &blk, nb_bm + nb_hist + nb_cnt));
+        ctx->cellbm = (u64 *)blk;
+        ctx->hist = (int *)(blk + nb_bm);
+        ctx->counters = (int *)(blk + nb_bm + nb_hist);
+        ctx->zero_block = blk;
+        ctx->zero_bytes = nb_bm + nb_hist + nb_cnt;
+    }
     RET(dmalloc(ctx, &ctx->need_dim, G));
     RET(dmalloc(ctx, &ctx->pass_flags, G));
     RET(dmalloc(ctx, &ctx->res_dev, G));
@@ -381,9 +390,11 @@ static dim3 word_grid(int h, int w, int n) { return dim3((unsigned)((h * LFD_WQ(
 
 // ---- stage runners (device pointers only, nc <= G images in workspace slots 0..nc-1) --------
 static int run_prep(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int mode,
-                    double minFlux, double addFlux, const int *active) {
-    HIPCHK(hipMemsetAsync(ctx->hist, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->cellbm, 0, (size_t)nc * ctx->bm_bands * CELLBM_WORDS * sizeof(u64), ctx->stream));
+                    double minFlux, double addFlux, const int *active, bool zeroed = false) {
+    if (!zeroed) {
+        HIPCHK(hipMemsetAsync(ctx->hist, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->cellbm, 0, (size_t)nc * ctx->bm_bands * CELLBM_WORDS * sizeof(u64), ctx->stream));
+    }
     {
         Span sp(ctx, KID_PREP_HIST);
         k_prep_hist<<<dim3((h + PREP_ROWS - 1) / PREP_ROWS, nc), 256, 0, ctx->stream>>>(
@@ -705,9 +716,7 @@ static bool can_fuse_prep_erode(const lfdmi_ctx *ctx, int dtype, int w, const ui
 }
 
 static int run_prep_erode(lfdmi_ctx *ctx, const void *src, int nc, int h, int w, int flip, int mode, double minFlux, double addFlux,
-                          int kh, int kw, const int *active) {
-    HIPCHK(hipMemsetAsync(ctx->hist, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->cellbm, 0, (size_t)nc * ctx->bm_bands * CELLBM_WORDS * sizeof(u64), ctx->stream));
+                          int kh, int kw, const int *active) { // (hist / cellbm zeroed by the caller)
     int BR = prep_erode_rows(ctx, w, kh);
     size_t lds = (size_t)(2 * BR + kh - 1) * (w + 32) + 16; // (+ one piece: the sliding window peeks one word ahead)
     {
@@ -725,13 +734,13 @@ static int run_prep_erode(lfdmi_ctx *ctx, const void *src, int nc, int h, int w,
 // one detection pass on nc images already resident at src (device): fills ctx->res_dev
 static int run_pass(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int prep_mode, bool dim,
                     const lfdmi_params *p, const int *active, int *need_dim) {
-    RET(zero_counters(ctx, nc));
+    HIPCHK(hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream)); // counters, histograms, cell bitmap
     const uint8_t *dil_src = ctx->gray;
     if (dim && can_fuse_prep_erode(ctx, dtype, w, p->erodeKernel, p->erode_kh, p->erode_kw)) {
         RET(run_prep_erode(ctx, src, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, p->erode_kh, p->erode_kw, active));
         dil_src = ctx->tmp;
     } else {
-        RET(run_prep(ctx, src, dtype, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, active));
+        RET(run_prep(ctx, src, dtype, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, active, true));
         if (dim) {
             RET(run_morph(ctx, ctx->gray, ctx->tmp, nullptr, nullptr, p->erodeKernel, p->erode_kh, p->erode_kw, 1, nc, h, w, active));
             dil_src = ctx->tmp;
