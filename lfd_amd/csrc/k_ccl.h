@@ -11,7 +11,7 @@
 // sequential Suzuki-Abe trace.  Work is proportional to the number of runs (~ edge pixels +
 // rows), not to the image area.
 //
-// Runs carry COMPACT ids: k_scan_runs stores, per 64-bit word, how many runs start before it
+// Runs carry COMPACT ids: the scan kernels (k_scan_count / k_scan_bases / k_scan_write) store, per 64-bit word, how many runs start before it
 // (exclusive scan in raster order), so the run that holds pixel (y, x) is
 //   scan[word] + popcount(start bits of the word at columns <= x) - 1
 // -- an O(1) lookup -- and all label arrays have one entry per run (a few thousand per frame,
@@ -38,7 +38,7 @@ __device__ __forceinline__ u64 start_bits(const u64 *row, int wq, int val, int W
     return c & ~((c << 1) | prev_msb);
 }
 
-// The candidate-pass scan (k_scan_runs below) also builds both work lists of a frame:
+// The candidate-pass scan (k_scan_write below) also builds both work lists of a frame:
 //   fg: words holding candidate bits (edge runs are a subset of candidate runs);
 //   bg: words where a 0-run of the edge image can start or a vertical 0-0 contact stretch can
 //       begin -- an edge bit in this word or at the end of the previous word, in this row or the
@@ -57,90 +57,103 @@ __device__ __forceinline__ u64 start_bits(const u64 *row, int wq, int val, int W
 #define SCAN_THREADS 1024
 
 // scan[word] = number of `val`-runs that start in earlier words of the frame (raster order);
-// counters[cidx] = total number of runs.  One workgroup per frame; lane = word (coalesced),
-// 64-word segments: per-segment totals by wave reduction, a scan of the (< 2048) segment totals
-// in LDS, then a wave-level scan inside each segment.
+// counters[cidx] = total number of runs.  Three short, wide kernels (a single 1024-thread workgroup per frame
+// reading its frame twice was bound by its own load latency): counting and writing parallelise over 64-word
+// segments, only the scan of the per-segment counts is per frame.
 #define SCAN_MAX_SEG 4096
+//   k_scan_count: per 64-word segment (one wave each) the run starts and the work-list entries -> segcnt
+//   k_scan_bases: per frame, exclusive scan of the segment counts in place, totals -> counters
+//   k_scan_write: per segment, the per-word scan values, the work-list entries (raster order), the clear
+#define SCANW_WAVES 4 // segments per workgroup
+__device__ __forceinline__ void scan_word(const u64 *b, int i, int nw, int wq, int val, int W, bool lists, int *c, bool *tf, bool *tb) {
+    *c = 0; *tf = false; *tb = false;
+    if (i >= nw) return;
+    int y = i / wq, q = i - y * wq;
+    *c = __popcll(start_bits(b + (size_t)y * wq, q, val, W));
+    if (lists) {
+        u64 m = b[i];
+        *tf = m != 0;
+        if (q > 0) m |= b[i - 1] >> 63;
+        if (y > 0) { m |= b[i - wq]; if (q > 0) m |= b[i - wq - 1] >> 63; }
+        *tb = (m != 0) || (q == 0);
+    }
+}
+
+__global__ void __launch_bounds__(64 * SCANW_WAVES)
+k_scan_count(const u64 *bits, int val, int4 *segcnt, int h, int w, int lists, const int *active) {
+    int g = blockIdx.y;
+    if (active && !active[g]) return;
+    const int wq = LFD_WQ(w), nw = h * wq, nseg = (nw + 63) >> 6;
+    int seg = blockIdx.x * SCANW_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (seg >= nseg) return;
+    int c; bool tf, tb;
+    scan_word(bits + (size_t)g * nw, (seg << 6) + lane, nw, wq, val, w, lists != 0, &c, &tf, &tb);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    int nf = __popcll(__ballot(tf)), nb = __popcll(__ballot(tb));
+    if (lane == 0) segcnt[(size_t)g * SCAN_MAX_SEG + seg] = make_int4(c, nf, nb, 0);
+}
+
 __global__ void __launch_bounds__(SCAN_THREADS)
-k_scan_runs(const u64 *bits, int val, int *scan, int *counters, int cidx, int h, int w, int run_cap, int *wl_fg, int *wl_bg,
-            u64 *clear, const int *active) {
+k_scan_bases(int4 *segcnt, int *counters, int cidx, int h, int w, int run_cap, int lists, const int *active) {
     int g = blockIdx.x;
     if (active && !active[g]) return;
-    const int wq = LFD_WQ(w), nw = h * wq;
-    const int nseg = (nw + 63) >> 6;
-    const u64 *b = bits + (size_t)g * nw;
-    int *sc = scan + (size_t)g * nw;
-    __shared__ int segtot[SCAN_MAX_SEG];
-    __shared__ int nfg, nbg;
-    if (threadIdx.x == 0) { nfg = 0; nbg = 0; }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = SCAN_THREADS / 64;
-    const u64 lt = (1ull << lane) - 1ull;
-    for (int seg = wv; seg < nseg; seg += nwv) {
-        int i = (seg << 6) + lane, c = 0;
-        bool tf = false, tb = false;
-        if (i < nw) {
-            int y = i / wq, q = i - y * wq;
-            c = __popcll(start_bits(b + (size_t)y * wq, q, val, w));
-            if (wl_fg) { // work lists of the frame (candidate pass only), see the comment above
-                u64 m = b[i];
-                tf = m != 0;
-                if (q > 0) m |= b[i - 1] >> 63;
-                if (y > 0) { m |= b[i - wq]; if (q > 0) m |= b[i - wq - 1] >> 63; }
-                tb = (m != 0) || (q == 0);
-            }
-        }
-        if (wl_fg) {
-            u64 bf = __ballot(tf), bb = __ballot(tb);
-            int basef = 0, baseb = 0;
-            if (lane == 0) {
-                if (bf) basef = atomicAdd(&nfg, __popcll(bf));
-                if (bb) baseb = atomicAdd(&nbg, __popcll(bb));
-            }
-            basef = __shfl(basef, 0);
-            baseb = __shfl(baseb, 0);
-            if (tf) wl_fg[(size_t)g * nw + basef + __popcll(bf & lt)] = i;
-            if (tb) wl_bg[(size_t)g * nw + baseb + __popcll(bb & lt)] = i;
-        }
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-        if (lane == 0) segtot[seg] = c;
+    const int nseg = (h * LFD_WQ(w) + 63) >> 6;
+    int4 *sg = segcnt + (size_t)g * SCAN_MAX_SEG;
+    const int per = SCAN_MAX_SEG / SCAN_THREADS; // 4 consecutive segments per thread
+    int t0 = threadIdx.x * per, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int4 v[SCAN_MAX_SEG / SCAN_THREADS];
+    int lc = 0, lf = 0, lb = 0;
+    for (int k = 0; k < per; k++) {
+        v[k] = t0 + k < nseg ? sg[t0 + k] : make_int4(0, 0, 0, 0);
+        lc += v[k].x; lf += v[k].y; lb += v[k].z;
     }
-    __syncthreads();
-    // exclusive scan of the segment totals (nseg <= SCAN_MAX_SEG; each thread owns up to 4 entries)
-    __shared__ int part[SCAN_THREADS];
-    const int per = (nseg + SCAN_THREADS - 1) / SCAN_THREADS;
-    int s0 = threadIdx.x * per, s1 = min(nseg, s0 + per), local = 0;
-    for (int k = s0; k < s1; k++) local += segtot[k];
-    part[threadIdx.x] = local;
-    __syncthreads();
-    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
-        int v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+    int ic = lc, if_ = lf, ib = lb;
+    for (int off = 1; off < 64; off <<= 1) {
+        int a = __shfl_up(ic, off), b2 = __shfl_up(if_, off), c2 = __shfl_up(ib, off);
+        if (lane >= off) { ic += a; if_ += b2; ib += c2; }
     }
-    int run = part[threadIdx.x] - local;
-    for (int k = s0; k < s1; k++) { int t = segtot[k]; segtot[k] = run; run += t; }
+    __shared__ int wt[SCAN_THREADS / 64][3];
+    if (lane == 63) { wt[wv][0] = ic; wt[wv][1] = if_; wt[wv][2] = ib; }
     __syncthreads();
-    for (int seg = wv; seg < nseg; seg += nwv) {
-        int i = (seg << 6) + lane, c = 0;
-        if (i < nw) { int y = i / wq; c = __popcll(start_bits(b + (size_t)y * wq, i - y * wq, val, w)); }
-        int incl = c;
-        for (int off = 1; off < 64; off <<= 1) {
-            int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
+    int bc = 0, bf = 0, bb = 0;
+    for (int k = 0; k < wv; k++) { bc += wt[k][0]; bf += wt[k][1]; bb += wt[k][2]; }
+    int rc = bc + ic - lc, rf = bf + if_ - lf, rb = bb + ib - lb;
+    for (int k = 0; k < per; k++)
+        if (t0 + k < nseg) {
+            sg[t0 + k] = make_int4(rc, rf, rb, 0);
+            rc += v[k].x; rf += v[k].y; rb += v[k].z;
         }
-        if (i < nw) {
-            sc[i] = segtot[seg] + incl - c;
-            // this pass touches every word anyway: clear the bit image a later kernel fills sparsely
-            // (hipMemsetAsync's fill kernel manages only ~350 GB/s)
-            if (clear) clear[(size_t)g * nw + i] = 0ull;
-        }
-    }
     if (threadIdx.x == SCAN_THREADS - 1) {
-        counters[g * C_COUNT + cidx] = part[threadIdx.x];
-        if (part[threadIdx.x] > run_cap) counters[g * C_COUNT + C_OVERFLOW] = 1;
-        if (wl_fg) { counters[g * C_COUNT + C_NFGW] = nfg; counters[g * C_COUNT + C_NBGW] = nbg; }
+        counters[g * C_COUNT + cidx] = rc;
+        if (rc > run_cap) counters[g * C_COUNT + C_OVERFLOW] = 1;
+        if (lists) { counters[g * C_COUNT + C_NFGW] = rf; counters[g * C_COUNT + C_NBGW] = rb; }
+    }
+}
+
+__global__ void __launch_bounds__(64 * SCANW_WAVES)
+k_scan_write(const u64 *bits, int val, const int4 *segcnt, int *scan, int h, int w, int *wl_fg, int *wl_bg, u64 *clear,
+             const int *active) {
+    int g = blockIdx.y;
+    if (active && !active[g]) return;
+    const int wq = LFD_WQ(w), nw = h * wq, nseg = (nw + 63) >> 6;
+    int seg = blockIdx.x * SCANW_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (seg >= nseg) return;
+    int i = (seg << 6) + lane, c; bool tf, tb;
+    scan_word(bits + (size_t)g * nw, i, nw, wq, val, w, wl_fg != nullptr, &c, &tf, &tb);
+    int incl = c;
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    int4 base = segcnt[(size_t)g * SCAN_MAX_SEG + seg];
+    if (wl_fg) {
+        u64 bf = __ballot(tf), bb = __ballot(tb), lt = (1ull << lane) - 1ull;
+        if (tf) wl_fg[(size_t)g * nw + base.y + __popcll(bf & lt)] = i;
+        if (tb) wl_bg[(size_t)g * nw + base.z + __popcll(bb & lt)] = i;
+    }
+    if (i < nw) {
+        scan[(size_t)g * nw + i] = base.x + incl - c;
+        if (clear) clear[(size_t)g * nw + i] = 0ull;
     }
 }
 

@@ -97,7 +97,7 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
     const int wq = LFD_WQ(w);
     const size_t fo = (size_t)g * h * wq, ro = (size_t)g * run_cap;
     const int nwork = counters[g * C_COUNT + C_NFGW], nrun = counters[g * C_COUNT + C_NRUNF];
-    const bool fits = nrun <= lds_cap; // lds_cap <= FRAME_RUNCAP (k_scan_runs flags nrun > run_cap as an overflow)
+    const bool fits = nrun <= lds_cap; // lds_cap <= FRAME_RUNCAP (k_scan_bases flags nrun > run_cap as an overflow)
     if (threadIdx.x == 0) {
         fallback[g] = fits ? 0 : 1;
         if (!fits) atomicOr(&pass_flags[g], PASS_FLAG_GENERAL); // tells the host the general kernels are needed

@@ -75,6 +75,7 @@ struct lfdmi_ctx {
     u64 *cellbm = nullptr;             // cell occupancy of the last prep output, bm_bands x CELLBM_WORDS words per slot
     int bm_bands = 0;
     bool use_cellbm = true;
+    int4 *segcnt = nullptr;            // per 64-word segment: run starts, fg / bg list entries (then their exclusive sums)
     int *fb_fg = nullptr, *fb_bg = nullptr; // per slot: frame left to the multi-workgroup run kernels (k_frame.h)
     lfdmi_result *res_dev = nullptr;
     void *stage = nullptr;
@@ -234,6 +235,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     RET(dmalloc(ctx, &ctx->rsa, G * FRAME_RUNCAP));
     ctx->bm_bands = (max_h + CELLBM_ROWS - 1) / CELLBM_ROWS;
     if (const char *e = getenv("LFDMI_CELLBM")) ctx->use_cellbm = atoi(e) != 0;
+    RET(dmalloc(ctx, &ctx->segcnt, G * SCAN_MAX_SEG));
     RET(dmalloc(ctx, &ctx->fb_fg, G));
     RET(dmalloc(ctx, &ctx->fb_bg, G));
     RET(dmalloc(ctx, &ctx->scanf_, G * BW));
@@ -445,6 +447,20 @@ static int run_morph(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, u64 *bits
 }
 
 // Canny = NMS bit rows + hysteresis by run labelling; leaves edge bits in ctx->edgeb and the
+// per-word run-count scan (compact run ids) + work lists + clearing of a sparse bit image: three wide kernels
+static int run_scan(lfdmi_ctx *ctx, const u64 *bits, int val, int *scan, int cidx, int nc, int h, int w, int *wl_fg, int *wl_bg,
+                    u64 *clear, const int *active) {
+    int nseg = (h * LFD_WQ(w) + 63) / 64;
+    dim3 grid((nseg + SCANW_WAVES - 1) / SCANW_WAVES, nc);
+    k_scan_count<<<grid, 64 * SCANW_WAVES, 0, ctx->stream>>>(bits, val, ctx->segcnt, h, w, wl_fg != nullptr, active);
+    KCHK("k_scan_count");
+    k_scan_bases<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->segcnt, ctx->counters, cidx, h, w, ctx->run_cap, wl_fg != nullptr, active);
+    KCHK("k_scan_bases");
+    k_scan_write<<<grid, 64 * SCANW_WAVES, 0, ctx->stream>>>(bits, val, ctx->segcnt, scan, h, w, wl_fg, wl_bg, clear, active);
+    KCHK("k_scan_write");
+    return 0;
+}
+
 // 8-connected labels of the surviving components in ctx->Lf
 static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, double low_d, double high_d, const int *active,
                      bool nms_done = false) {
@@ -460,9 +476,7 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
     dim3 lg(WORDLIST_BLOCKS, nc);
     int rc = ctx->run_cap;
     { Span sp(ctx, KID_RUNS_INIT_FG);
-      k_scan_runs<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->candb, 1, ctx->scanf_, ctx->counters, C_NRUNF, h, w, rc, ctx->wl_fg,
-                                                        ctx->wl_bg, ctx->edgeb, active);
-      KCHK("k_scan_runs(fg)");
+      RET(run_scan(ctx, ctx->candb, 1, ctx->scanf_, C_NRUNF, nc, h, w, ctx->wl_fg, ctx->wl_bg, ctx->edgeb, active));
     }
     if (ctx->frame_ccl) { // frames that fit the LDS tables; the rest (fallback flag) take the kernels below
         Span sp(ctx, KID_FRAME_FG);
@@ -541,9 +555,7 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     dim3 lg(WORDLIST_BLOCKS, nc);
     int rc = ctx->run_cap;
     { Span sp(ctx, KID_RUNS_INIT_BG);
-      k_scan_runs<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->edgeb, 0, ctx->scanb_, ctx->counters, C_NRUNB, h, w, rc, nullptr, nullptr,
-                                                        ctx->boxb, active);
-      KCHK("k_scan_runs(bg)"); }
+      RET(run_scan(ctx, ctx->edgeb, 0, ctx->scanb_, C_NRUNB, nc, h, w, nullptr, nullptr, ctx->boxb, active)); }
     RunTabs rt;
     rt.cand = ctx->candb; rt.edge = ctx->edgeb; rt.scanf = ctx->scanf_; rt.scanb = ctx->scanb_;
     rt.Lf = ctx->Lf; rt.YMf = ctx->YMf; rt.SBf = ctx->SBf; rt.ROWf = ctx->ROWf; rt.FLf = ctx->FLf;
