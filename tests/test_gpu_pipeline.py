@@ -264,3 +264,30 @@ def test_cell_bitmap_and_general_run_kernels_do_not_change_results(monkeypatch):
         assert o[0] == outs[0][0]
         for a, b in zip(o[1], outs[0][1]):
             assert np.array_equal(a, b)
+
+
+def test_dense_noise_frames_take_the_general_kernels_and_match_the_oracle(oracle):
+    """Frames the per-frame LDS kernels cannot hold (noise everywhere: far more than 32 768 runs) are
+    flagged on the device, the chunk is run again with the general multi-workgroup kernels, and the records
+    still equal the oracle's; later chunks of the same context launch the general kernels right away."""
+    from lfd_amd import _native
+    pb, pd, prs = params()
+    rng = np.random.default_rng(7)
+    h, w = 600, 768
+    frames = []
+    for k in range(3):
+        f = rng.uniform(1.0, 200.0, (h, w)).astype(np.float32)   # texture everywhere: ~60-100 k candidate runs per pass
+        f[100 + 40 * k:108 + 40 * k, :] = 250.0                  # a bright bar so that something elongated exists
+        frames.append(f)
+    frames.append(np.zeros((h, w), np.float32))           # and an empty frame in the same chunk
+    batch = np.stack(frames)
+    ctx = _native.Context(0, h, w, 4)
+    res = ctx.detect_batch(batch.copy(), pb, pd)
+    runs = ctx.get_counters(0, 4)[:, 12]
+    assert runs[:3].min() > 32768, runs                   # really beyond the LDS tables
+    for i in range(4):
+        want = oracle.detect_frame(frames[i].copy(), pb, pd)
+        assert same(res[i], want), (i, want, res[i])
+    res2 = ctx.detect_batch(batch.copy(), pb, pd)         # general kernels now launched up front
+    assert res2.tobytes() == res.tobytes()
+    ctx.close()
