@@ -291,3 +291,20 @@ def test_dense_noise_frames_take_the_general_kernels_and_match_the_oracle(oracle
     res2 = ctx.detect_batch(batch.copy(), pb, pd)         # general kernels now launched up front
     assert res2.tobytes() == res.tobytes()
     ctx.close()
+
+
+@pytest.mark.parametrize("shape", [(16, 16), (33, 48), (64, 64), (100, 272), (130, 1040), (97, 131), (40, 2048)])
+def test_small_and_odd_shapes_full_pipe(oracle, shape):
+    """The whole pipe on small frames: widths that are / are not multiples of 16 and 64 (fused tile kernels vs
+    the generic ones), a single tile row, frames narrower than a tile; bright, dim and empty streak kinds."""
+    from lfd_amd import _native, synth
+    pb, pd, prs = params()
+    rs_g, rs_o = rs_pair(oracle, prs)
+    h, w = shape
+    ctx = _native.Context(0, h, w, 3)
+    frames, cats = zip(*[synth.make_portable_frame(k, shape, n_star=max(2, h * w // 20000))[:2] for k in (0, 1, 2)])
+    res = ctx.detect_batch(np.stack(frames).copy(), pb, pd, synth.pack_catalogs(list(cats)), rs_g)
+    for i in range(3):
+        want = oracle.detect_frame(frames[i].copy(), pb, pd, cats[i], rs_o)
+        assert same(res[i], want), (shape, i, want, res[i])
+    ctx.close()
