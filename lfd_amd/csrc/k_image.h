@@ -28,7 +28,7 @@ __device__ __forceinline__ void py_slice(long start, long stop, long len, int *a
 __global__ void __launch_bounds__(256)
 k_removestars(float *frames, int h, int w, int max_obj, const int *count, const float *rowc,
               const float *colc, const float *psfmag, const float *petro90, const int *nobserve,
-              const int *ndetect, RsDev p) {
+              const int *ndetect, RsDev p, int4 *boxes) {
     int f = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= count[f]) return;
     int r0 = 0, r1 = 0, c0 = 0, c1 = 0;
@@ -60,6 +60,8 @@ k_removestars(float *frames, int h, int w, int max_obj, const int *count, const 
     }
     r0 = __builtin_amdgcn_readfirstlane(r0); r1 = __builtin_amdgcn_readfirstlane(r1);
     c0 = __builtin_amdgcn_readfirstlane(c0); c1 = __builtin_amdgcn_readfirstlane(c1);
+    // the square, for a caller whose frames live in host memory (it blots its own copy: lfdmi.hip)
+    if (boxes && lane == 0) boxes[(size_t)f * max_obj + i] = make_int4(r0, r1, c0, c1);
     int nc = c1 - c0;
     if (r1 <= r0 || nc <= 0) return;
     float *img = frames + (size_t)f * h * w;

@@ -308,3 +308,23 @@ def test_small_and_odd_shapes_full_pipe(oracle, shape):
         want = oracle.detect_frame(frames[i].copy(), pb, pd, cats[i], rs_o)
         assert same(res[i], want), (shape, i, want, res[i])
     ctx.close()
+
+
+def test_host_frames_are_blotted_in_place_without_a_copy_back(oracle):
+    """Frames handed over as a host array: remove_stars must leave the caller's array exactly as the
+    reference would (the library zero-fills it on the host from the squares the device computed; the
+    frames themselves cross PCIe once), over two chunks and with a ragged last chunk."""
+    from lfd_amd import _native, synth
+    pb, pd, prs = params()
+    rs_g, rs_o = rs_pair(oracle, prs)
+    ks = list(range(40, 47))
+    frames, cats = zip(*[synth.make_frame(k)[:2] for k in ks])
+    batch = np.stack(frames)
+    ctx = _native.Context(0, 1489, 2048, 4)                     # 7 frames through 4 slots: chunks of 4 and 3
+    res = ctx.detect_batch(batch, pb, pd, synth.pack_catalogs(list(cats)), rs_g)
+    for i in range(len(ks)):
+        ref = frames[i].copy()
+        want = oracle.detect_frame(ref, pb, pd, cats[i], rs_o)  # ref is blotted in place
+        assert same(res[i], want)
+        assert np.array_equal(batch[i], ref)
+    ctx.close()
