@@ -220,7 +220,10 @@ def main():
                          "frac_of_measured_copy_6290": round(achieved / 6290.0, 5),
                          "avg_launch_ms": round(ms / max(1, launches), 4),
                          "frames_per_launch": round(units / max(1, launches), 2),
-                         "algorithmic_bytes_per_frame": bytes_per_frame},
+                         "algorithmic_bytes_per_frame": bytes_per_frame,
+                         "note": "priced against HBM as SURVEY 8(d) prescribes; the SQ counters in profiles/README.md show "
+                                 "this kernel limited by vector-unit issue and LDS round trips on its occupied tiles"
+                                 if name == "k_dilate_canny" else ""},
             "kernels": kern,
         }
         if args.cpu_sample > 0:
