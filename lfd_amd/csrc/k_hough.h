@@ -77,6 +77,11 @@ k_pixlist(const u64 *bits0, const u64 *bits1, uint32_t *list0, uint32_t *list1, 
 }
 
 #define VOTE_THREADS 1024
+// Bins an angle slab can reach: r = (x cos + y sin) / rho over the image rectangle covers only a part of the
+// (numrho) accumulator rows -- 0 .. 127 of 356 for angles 0 - 63 deg of an SDSS frame -- so a workgroup's LDS slab
+// holds rows lo .. hi only (host: vote_ranges): less than half the LDS, two to three workgroups per CU.
+#define VOTE_MAX_SLABS 16
+struct VoteRanges { int lo[VOTE_MAX_SLABS], hi[VOTE_MAX_SLABS]; }; // centred bin index r (0 = rho 0), inclusive
 
 // Accumulator layouts.  OpenCV indexes accum[(n+1)*(numrho+2) + r+1] ("base"); that value is
 // still what orders equal-vote lines.  In memory the accumulator is kept TRANSPOSED,
@@ -93,23 +98,25 @@ template <int AWL> // log2 of the angles per workgroup
 __global__ void __launch_bounds__(VOTE_THREADS)
 k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, const float *tab,
              int *accum, int numangle, int numrho, int nsplit, size_t list_cap, size_t acc_cap,
-             const int *active, int need_detect) {
+             const int *active, int need_detect, VoteRanges rng) {
     constexpr int aw_log2 = AWL;
     int g = blockIdx.z, im = blockIdx.y;
     int slab = blockIdx.x / nsplit, split = blockIdx.x - slab * nsplit;
     if (active && !active[g]) return;
     const int *cnt = counters + g * C_COUNT;
     if (need_detect && !cnt[C_DETECT]) return;
-    extern __shared__ int acc[]; // numrho * AW votes + 64 spare words for lanes without an angle
+    extern __shared__ int acc[]; // nb * AW votes (rows lo .. hi of this slab) + 64 spare words for lanes without an angle
     const int AW = 1 << aw_log2;
     int a0 = slab * AW;
     int na = min(AW, numangle - a0);
+    const int lo = slab < VOTE_MAX_SLABS ? rng.lo[slab] : -((numrho - 1) / 2);
+    const int nb = (slab < VOTE_MAX_SLABS ? rng.hi[slab] : numrho - 1 - (numrho - 1) / 2) - lo + 1;
     int n = cnt[im ? C_NPIX_BOX : C_NPIX_EQU];
     if ((size_t)n > list_cap) n = (int)list_cap;
     int per = ((n + nsplit - 1) / nsplit + 63) / 64 * 64;
     int begin = min(n, split * per), end = min(n, begin + per);
     if (nsplit > 1 && begin >= end) return; // nothing to add
-    for (int k = threadIdx.x; k < numrho * AW + 64; k += VOTE_THREADS) acc[k] = 0;
+    for (int k = threadIdx.x; k < nb * AW + 64; k += VOTE_THREADS) acc[k] = 0;
     __syncthreads();
     const uint32_t *list = (im ? list1 : list0) + (size_t)g * list_cap;
     int lane = threadIdx.x & 63;
@@ -124,7 +131,8 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     // |v| < 2^22) uses the 1.5*2^23 trick: bits(v + 12582912.f) = 0x4B400000 + rint(v); the
     // constant is folded into the base (address arithmetic is mod 2^32).  Lanes without an angle
     // have c = s = 0, hence rint = 0, and their base points at the spare words: no select.
-    const unsigned cell = act ? (unsigned)(((numrho - 1) / 2) * AW + lane) : (unsigned)(numrho * AW + lane);
+    // (an inactive lane votes bin rint(0) = 0: its base is shifted so that lands in the spare words)
+    const unsigned cell = act ? (unsigned)((-lo) * AW + lane) : (unsigned)(nb * AW + lane);
     const unsigned lanebase = (cell << 2) - (0x4B400000u << (aw_log2 + 2));
     char *accb = (char *)acc;
     // A list entry is a chunk of horizontal neighbours (y, x0 .. x0 + len - 1), len <= min(16, rho) (k_pixlist).
@@ -193,17 +201,19 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     __syncthreads();
     int *ag = accum + ((size_t)g * 2 + im) * acc_cap;
     const int ts = numangle + 2; // transposed row length
+    const int r0 = (numrho - 1) / 2 + lo; // accumulator row of the slab's first bin
     if (nsplit > 1) {
-        for (int k = threadIdx.x; k < numrho * AW; k += VOTE_THREADS) {
-            int rr = k >> aw_log2, al = k & (AW - 1);
+        for (int k = threadIdx.x; k < nb * AW; k += VOTE_THREADS) {
+            int rr = r0 + (k >> aw_log2), al = k & (AW - 1);
             int v = acc[k];
             if (v && al < na) atomicAdd(&ag[(size_t)(rr + 1) * ts + a0 + al + 1], v);
         }
         return;
     }
-    for (int k = threadIdx.x; k < numrho * AW; k += VOTE_THREADS) {
+    for (int k = threadIdx.x; k < numrho * AW; k += VOTE_THREADS) { // rows outside lo .. hi are zero
         int rr = k >> aw_log2, al = k & (AW - 1);
-        if (al < na) ag[(size_t)(rr + 1) * ts + a0 + al + 1] = acc[k];
+        int rl = rr - r0;
+        if (al < na) ag[(size_t)(rr + 1) * ts + a0 + al + 1] = (rl >= 0 && rl < nb) ? acc[rl * AW + al] : 0;
     }
     // guard cells: bins -1 and numrho for this slab's angles; angles -1 and numangle for all bins
     for (int k = threadIdx.x; k < na; k += VOTE_THREADS) {

@@ -90,6 +90,7 @@ struct lfdmi_ctx {
     // cached Hough tables
     double tab_rho = -1, tab_theta = -1;
     int tab_h = 0, tab_w = 0, numangle = 0, numrho = 0;
+    std::vector<float> tab_host;       // host copy of the trig table (slab ranges of the vote kernel)
     // timing
     bool timing = false;
     uint64_t timing_mask = 0;          // non-zero: only these timing slots' launches are bracketed (lfdmi_timing_select)
@@ -645,6 +646,7 @@ static int ensure_tables(lfdmi_ctx *ctx, int h, int w, double rho_d, double thet
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(ctx->tab, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->tab_host = t;
     ctx->tab_rho = rho_d; ctx->tab_theta = theta_d; ctx->tab_h = h; ctx->tab_w = w;
     ctx->numangle = na; ctx->numrho = nr;
     return 0;
@@ -678,12 +680,35 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         KCHK("k_pixlist"); }
         Span sp(ctx, KID_VOTE, need_detect);
         dim3 vgrid(nslabs * nsplit, n_img, nc);
-        size_t vlds = ((size_t)nr << aw_log2) * 4 + 256;
+        // rows of the accumulator each angle slab can reach: r = x c + y s over the image rectangle (+- 2 bins of slack)
+        VoteRanges rng;
+        int half = (nr - 1) / 2, nbmax = 1;
+        for (int sl = 0; sl < VOTE_MAX_SLABS; sl++) { rng.lo[sl] = -half; rng.hi[sl] = nr - 1 - half; }
+        if (nslabs <= VOTE_MAX_SLABS && (int)ctx->tab_host.size() == 2 * na) {
+            for (int sl = 0; sl < nslabs; sl++) {
+                double rmin = 0, rmax = 0;
+                for (int n = sl * AW; n < na && n < (sl + 1) * AW; n++) {
+                    double c = ctx->tab_host[n], sn = ctx->tab_host[na + n];
+                    for (int cx = 0; cx < 2; cx++)
+                        for (int cy = 0; cy < 2; cy++) {
+                            double r = (cx ? w : 0) * c + (cy ? h : 0) * sn;
+                            rmin = r < rmin ? r : rmin;
+                            rmax = r > rmax ? r : rmax;
+                        }
+                }
+                int lo = (int)floor(rmin) - 2, hi = (int)ceil(rmax) + 2;
+                rng.lo[sl] = lo < -half ? -half : lo;
+                rng.hi[sl] = hi > nr - 1 - half ? nr - 1 - half : hi;
+            }
+        }
+        for (int sl = 0; sl < nslabs && sl < VOTE_MAX_SLABS; sl++) nbmax = std::max(nbmax, rng.hi[sl] - rng.lo[sl] + 1);
+        if (nslabs > VOTE_MAX_SLABS) nbmax = nr;
+        size_t vlds = ((size_t)nbmax << aw_log2) * 4 + 256;
 #define LFD_LAUNCH_VOTE(L)                                                                                          \
     case L:                                                                                                         \
         k_hough_vote<L><<<vgrid, VOTE_THREADS, vlds, ctx->stream>>>(ctx->pix_equ, ctx->pix_box, ctx->counters, ctx->tab, \
                                                                    ctx->accum, na, nr, nsplit, ctx->list_cap,       \
-                                                                   ctx->acc_cap, active, need_detect);              \
+                                                                   ctx->acc_cap, active, need_detect, rng);         \
         break;
         switch (aw_log2) {
             LFD_LAUNCH_VOTE(6) LFD_LAUNCH_VOTE(5) LFD_LAUNCH_VOTE(4) LFD_LAUNCH_VOTE(3) LFD_LAUNCH_VOTE(2)
