@@ -16,6 +16,7 @@
 // The Hough inputs are dilated blobs and filled rectangles: runs of 10-100 pixels, so a frame's list is
 // ~12x shorter than its pixel count, and the vote kernel handles a chunk with two accumulator updates
 // per angle instead of one per pixel (see k_hough_vote).  Image sides up to 8191 (13 bits).
+#define PIXLIST_WORDS 8 // words per thread of k_pixlist
 #define CHUNK_MAX 16 // (4 bits; the host passes min(CHUNK_MAX, floor(rho)) so that a chunk spans less than one bin)
 __device__ __forceinline__ uint32_t chunk_entry(int y, int x0, int len) {
     return ((uint32_t)(len - 1) << 26) | ((uint32_t)y << 13) | (uint32_t)x0;
@@ -33,46 +34,54 @@ k_pixlist(const u64 *bits0, const u64 *bits1, uint32_t *list0, uint32_t *list1, 
     int *cnt = counters + g * C_COUNT;
     if (need_detect && !cnt[C_DETECT]) return;
     int wq = LFD_WQ(w);
-    int idx = blockIdx.x * 256 + threadIdx.x;
     // zero this image's vote accumulator on the way (needed when the vote kernel merges split
     // lists with atomics; hipMemsetAsync's fill kernel is several times slower)
     if (accum_clear)
-        for (int k = idx; k < acc_n; k += gridDim.x * 256) accum_clear[(size_t)g * 2 * acc_stride + k] = 0;
-    u64 c = 0;
-    int y = 0, q = 0;
-    if (idx < h * wq) {
-        y = idx / wq; q = idx - y * wq;
-        c = bits[(size_t)g * h * wq + idx] & valid_mask(q, w);
-    }
-    // chunks of this word: every maximal stretch of set bits, cut every CHUNK_MAX pixels
-    int n = 0;
-    for (u64 r = c; r;) {
-        int b = __ffsll((long long)r) - 1;
-        u64 inv = ~(r >> b);
-        int len = inv ? (__ffsll((long long)inv) - 1) : (64 - b);
-        r &= ~((len >= 64 ? ~0ull : ((1ull << len) - 1)) << b);
-        n += (len + chunk_max - 1) / chunk_max;
-    }
-    // wave-aggregated allocation: inclusive scan of n, one atomic per wave
-    int lane = lfd_lane(), incl = n, px = __popcll(c);
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
-    for (int off = 32; off > 0; off >>= 1) px += __shfl_down(px, off);
-    int total = __shfl(incl, 63);
-    int base = 0;
-    if (lane == 63 && total) base = atomicAdd(&cnt[cidx], total);
-    if (lane == 0 && px) atomicAdd(&cnt[nnz_idx], px);
-    base = __shfl(base, 63);
-    int o = base + incl - n;
+        for (int k = blockIdx.x * 256 + threadIdx.x; k < acc_n; k += gridDim.x * 256) accum_clear[(size_t)g * 2 * acc_stride + k] = 0;
+    // PIXLIST_WORDS words per thread: a workgroup per 256 words spent its life on the two dependent loads in front
+    // of the work (active flag, detection counter) -- 95 000 workgroups per launch, most of them with nothing to do
+    const int nw = h * wq;
     uint32_t *lg = list + (size_t)g * list_cap;
-    for (u64 r = c; r;) {
-        int b = __ffsll((long long)r) - 1;
-        u64 inv = ~(r >> b);
-        int len = inv ? (__ffsll((long long)inv) - 1) : (64 - b);
-        r &= ~((len >= 64 ? ~0ull : ((1ull << len) - 1)) << b);
-        for (int x0 = (q << 6) + b; len > 0; x0 += chunk_max, len -= chunk_max) lg[o++] = chunk_entry(y, x0, min(len, chunk_max));
+    const int lane = lfd_lane();
+    for (int it = 0; it < PIXLIST_WORDS; it++) {
+        int idx = (blockIdx.x * PIXLIST_WORDS + it) * 256 + threadIdx.x;
+        if (idx - (int)threadIdx.x >= nw) break;
+        u64 c = 0;
+        int y = 0, q = 0;
+        if (idx < nw) {
+            y = idx / wq; q = idx - y * wq;
+            c = bits[(size_t)g * nw + idx] & valid_mask(q, w);
+        }
+        if (__ballot(c != 0) == 0ull) continue; // a wave of empty words (most of them)
+        // chunks of this word: every maximal stretch of set bits, cut every chunk_max pixels
+        int n = 0;
+        for (u64 r = c; r;) {
+            int b = __ffsll((long long)r) - 1;
+            u64 inv = ~(r >> b);
+            int len = inv ? (__ffsll((long long)inv) - 1) : (64 - b);
+            r &= ~((len >= 64 ? ~0ull : ((1ull << len) - 1)) << b);
+            n += (len + chunk_max - 1) / chunk_max;
+        }
+        // wave-aggregated allocation: inclusive scan of n, one atomic per wave
+        int incl = n, px = __popcll(c);
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        for (int off = 32; off > 0; off >>= 1) px += __shfl_down(px, off);
+        int total = __shfl(incl, 63);
+        int base = 0;
+        if (lane == 63 && total) base = atomicAdd(&cnt[cidx], total);
+        if (lane == 0 && px) atomicAdd(&cnt[nnz_idx], px);
+        base = __shfl(base, 63);
+        int o = base + incl - n;
+        for (u64 r = c; r;) {
+            int b = __ffsll((long long)r) - 1;
+            u64 inv = ~(r >> b);
+            int len = inv ? (__ffsll((long long)inv) - 1) : (64 - b);
+            r &= ~((len >= 64 ? ~0ull : ((1ull << len) - 1)) << b);
+            for (int x0 = (q << 6) + b; len > 0; x0 += chunk_max, len -= chunk_max) lg[o++] = chunk_entry(y, x0, min(len, chunk_max));
+        }
     }
 }
 

@@ -674,7 +674,7 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         // per-slot accumulator pairs are 2 * acc_cap apart; the kernel indexes by slot itself
         // a chunk must span less than one rho bin: |cos| / rho per pixel
         int chunk_max = rho >= CHUNK_MAX ? CHUNK_MAX : (rho >= 1 ? (int)rho : 1);
-        k_pixlist<<<dim3(wg.x, wg.y, n_img), 256, 0, ctx->stream>>>(ctx->equb, ctx->boxb, ctx->pix_equ, ctx->pix_box, ctx->counters, chunk_max,
+        k_pixlist<<<dim3((wg.x + PIXLIST_WORDS - 1) / PIXLIST_WORDS, wg.y, n_img), 256, 0, ctx->stream>>>(ctx->equb, ctx->boxb, ctx->pix_equ, ctx->pix_box, ctx->counters, chunk_max,
                                                                     h, w, ctx->list_cap, nsplit > 1 ? ctx->accum : nullptr, acc_n, ctx->acc_cap,
                                                                     active, need_detect);
         KCHK("k_pixlist"); }
