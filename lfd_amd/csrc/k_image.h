@@ -922,16 +922,15 @@ __device__ __forceinline__ void dcw_for_live(u64 live, uint32_t colmask, int lan
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
 k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *strong, const uint8_t *lut, int h, int w,
-                 int kh, int kw, int low, int high, const int *active, int nc, int tiles_x, int nstripx, int S, const u64 *cellbm,
-                 int bm_bands) {
+                 int kh, int kw, int low, int high, const int *active, int nc, int tiles_x, int nstripx, int S, int SS,
+                 const u64 *cellbm, int bm_bands) {
     const int tiles_y = (h + DCW_TH - 1) / DCW_TH;
     int L = blockIdx.x, xcd = L & 7, jb_ = L >> 3, per = tiles_y * nstripx;
     int g = (jb_ / per) * 8 + xcd;
     if (g >= nc) return;
     if (active && !active[g]) return;
     int rem = jb_ - (jb_ / per) * per;
-    const int ty = rem / nstripx, tx0 = (rem - ty * nstripx) * S;
-    const int ntile = min(S, tiles_x - tx0); // tiles of this strip: tx0 .. tx0 + ntile - 1, left to right
+    const int ty = rem / nstripx, txs = (rem - ty * nstripx) * S * SS; // SS strips of S tiles, left to right
     extern __shared__ __attribute__((aligned(16))) uint8_t smw[];
     const int PH = DCW_PH, MH = DCW_MH, NWD = DCW_NWD, TS = DCW_TS, TSW = DCW_TS / 4;
     const int IH = PH + kh - 1;
@@ -963,6 +962,18 @@ k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
         int gy = y0 - 2 - ay + iy[p];
         rowok[p] = has[p] && gy >= 0 && gy < h;
     }
+#pragma unroll
+    for (int p = 0; p < 4; p++) slut[lane + 64 * p] = lut ? lut[g * 256 + lane + 64 * p] : (uint8_t)(lane + 64 * p);
+    if (lane < 8) Pm[lane] = 0u;
+    __syncthreads();
+    uint32_t zw = slut[0]; // background of the dilated, equalised image
+    zw |= zw << 8; zw |= zw << 16;
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const uint32_t mPH = (1u << PH) - 1, mMH = (1u << MH) - 1, mIH = IH >= 32 ? ~0u : ((1u << IH) - 1);
+    for (int sub = 0; sub < SS; sub++) {
+    const int tx0 = txs + sub * S;
+    if (tx0 >= tiles_x) break;
+    const int ntile = min(S, tiles_x - tx0); // tiles of this strip: tx0 .. tx0 + ntile - 1
     // Cell occupancy from the prep kernel (cell_mark): which 16-pixel x 16-row cells of the input hold a
     // non-zero byte.  A tile reads columns x0 - 16 .. x0 + 79 (cells 4 tx - 1 .. 4 tx + 4) of rows inside the
     // bands ty - 1 .. ty + 1; if those 18 cells are clear its outputs are written without loading anything.
@@ -996,14 +1007,6 @@ k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
     uint4 v[3];
     v[0] = v[1] = v[2] = make_uint4(0, 0, 0, 0);
     if (needed(0)) load_tile(0, v);
-#pragma unroll
-    for (int p = 0; p < 4; p++) slut[lane + 64 * p] = lut ? lut[g * 256 + lane + 64 * p] : (uint8_t)(lane + 64 * p);
-    if (lane < 8) Pm[lane] = 0u;
-    __syncthreads();
-    uint32_t zw = slut[0]; // background of the dilated, equalised image
-    zw |= zw << 8; zw |= zw << 16;
-    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    const uint32_t mPH = (1u << PH) - 1, mMH = (1u << MH) - 1, mIH = IH >= 32 ? ~0u : ((1u << IH) - 1);
     for (int t = 0; t < ntile; t++) {
         const int tx = tx0 + t, x0 = tx * CANNY_TW;
         uint32_t anyv = 0;
@@ -1235,6 +1238,7 @@ k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
             cand[o] = rowc[lane];
             strong[o] = rows[lane];
         }
+    }
     }
 }
 

@@ -108,6 +108,7 @@ struct lfdmi_ctx {
     bool general_seen = false, general_on = true;
     bool frame_ccl = true;             // per-frame LDS connectivity kernels (k_frame.h)
     int frame_runcap = FRAME_RUNCAP;   // runs per frame they take (LFDMI_FRAME_RUNCAP lowers it: tests of the fallback path)
+    int dc_substrips = 4;              // strips a wave of k_dilate_canny_w walks one after the other
     int dc_strip = 8;                  // tiles per wave strip in k_dilate_canny_w
     bool keep_equ = true;              // write the equalised+dilated stage image (off in lfdmi_detect_batch)
     int cur_pass = 0;                  // 0 = bright / stand-alone operator, 1 = dim pass of detect_batch
@@ -203,6 +204,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     if (const char *e = getenv("LFDMI_VOTE_SPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->vote_split = v; }
     if (const char *e = getenv("LFDMI_PE_ROWS")) { int v = atoi(e); if (v >= 2 && v <= 64) ctx->pe_rows = v; }
     if (const char *e = getenv("LFDMI_FRAME_RUNCAP")) { int v = atoi(e); if (v >= 0 && v < FRAME_RUNCAP) ctx->frame_runcap = v; }
+    if (const char *e = getenv("LFDMI_DC_SUBSTRIPS")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->dc_substrips = v; }
     if (const char *e = getenv("LFDMI_DC_STRIP")) { int v = atoi(e); if (v >= 1 && v <= DCW_MAXS) ctx->dc_strip = v; } // tuning knob
     ctx->N = (size_t)max_h * max_w;
     ctx->wq = LFD_WQ(max_w);
@@ -525,11 +527,11 @@ static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, i
         int IH = DCW_PH + kh - 1, MGB = DCW_MH * CANNY_MW * 2;
         size_t lds = (size_t)(IH * DCW_TS > MGB ? IH * DCW_TS : MGB) + (size_t)IH * DCW_NWD * 4 + (size_t)DCW_PH * DCW_TS;
         int tiles_x = (w + CANNY_TW - 1) / CANNY_TW, tiles_y = (h + DCW_TH - 1) / DCW_TH;
-        int S = ctx->dc_strip, nstripx = (tiles_x + S - 1) / S;
+        int S = ctx->dc_strip, SS = ctx->dc_substrips, nstripx = (tiles_x + S * SS - 1) / (S * SS);
         unsigned grid = 8u * ((nc + 7) / 8) * tiles_y * nstripx; // frame = 8 * (j / strips) + (block & 7): one XCD per frame
         Span sp(ctx, KID_DILATE_CANNY);
         k_dilate_canny_w<<<grid, 64, lds, ctx->stream>>>(src, ctx->keep_equ ? ctx->equ : nullptr, ctx->equb, ctx->candb,
-                                                          ctx->strongb, lut, h, w, kh, kw, 0, 255, active, nc, tiles_x, nstripx, S,
+                                                          ctx->strongb, lut, h, w, kh, kw, 0, 255, active, nc, tiles_x, nstripx, S, SS,
                                                           use_bm ? ctx->cellbm : nullptr, ctx->bm_bands);
         KCHK("k_dilate_canny_w");
         return 0;
