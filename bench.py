@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=256)
     ap.add_argument("--inflight", type=int, default=256)
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches (streams) per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=24, help="frames timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=40, help="frames timed through the CPU oracle (0 = skip)")
     ap.add_argument("--gen-workers", type=int, default=-1)
     ap.add_argument("--no-removestars", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
