@@ -1,23 +1,26 @@
 #!/usr/bin/env python3
-"""Headline benchmark: SDSS frames/s of the full detecttrails pipe on N MI355X.
+"""Headline benchmark: frames/s of the detecttrails hot path on N MI355X.
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus 1 --steps 5 --warmup 1                      # BASELINE configs[2] (default)
+    python bench.py --workload lsst                                     # BASELINE configs[4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (remove_stars -> flip -> bright pass -> dim pass where
-the bright pass found nothing; detecttrails.py:119-131) over this rank's batch of synthetic
-2048x1489 float32 frames (BASELINE.json configs[2]: batch = 256 per GPU),
-already resident in HBM.  Weak scaling: every rank owns --frames-per-gpu frames, no data-path
-collective; one barrier-bracketed timed region, max over ranks.  Rank 0 prints ONE JSON line.
+workload sdss (BASELINE.json configs[2], the configuration the metric is quoted on): one "step" = one pass of the
+full pipe (remove_stars -> flip -> bright pass -> dim pass where the bright pass found nothing;
+detecttrails.py:119-131) over this rank's batch of 256 synthetic 2048x1489 float32 frames, resident in HBM.
+workload lsst (configs[4]): one step = the dim pass with a 9x9 erosion (processfield.py:453-506) over this rank's
+batch of 4096x4096 float32 frames, HoughLines evaluated at rho = 20, 10 and 5 ("multi-scale Hough": SURVEY.md 8d).
+Weak scaling: every rank owns --frames-per-gpu frames, no data-path collective; one barrier-bracketed timed
+region, max over ranks.  Rank 0 prints ONE JSON line.
 
-roofline: the library brackets launches with HIP events on the launch stream.  Bracketing all ~40
-launches of a step costs ~6 % of it, so inside the timed region only the dominant kernel's launches
-are bracketed (found during the warm-up steps); it is priced with SURVEY.md 8(d)'s algorithmic bytes
-of its stage x the frames its launches worked on.  The "kernels" table comes from one extra, fully
-bracketed step run after the timed region.  cpu_baseline: the C oracle
-(oracle/, a port of the reference's algorithm; the reference's own OpenCV path cannot run
-here or on the GPU box) on a bounded sample of the same frames, one host thread.
+roofline: the library brackets launches with HIP events on the launch stream.  Bracketing all ~40 launches of a
+step costs ~6 % of it, so inside the timed region only the few largest kernels are bracketed (nominated by the
+fully bracketed warm-up steps); the dominant one is priced with ITS share of SURVEY.md 8(d)'s algorithmic bytes
+(KERNEL_BYTES_PER_PX: every stage's bytes are charged exactly once across its kernels) x the frames its launches
+worked on.  `stages` and `canny_hough` come from one extra, fully bracketed step run after the timed region.
+cpu_baseline: the C oracle (oracle/, a port of the reference's algorithm; the reference's own OpenCV path cannot
+run here or on the GPU box) on a bounded sample of the same frames: one host thread, and all host cores.
 """
 import argparse
 import json
@@ -32,40 +35,52 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
-# SURVEY.md 8(d) algorithmic bytes per pixel of the stage each kernel belongs to
-STAGE_BYTES_PER_PX = {
-    "k_removestars": 0.0, "k_prep_hist": 5.0, "k_lut": 0.0, "k_morph(erode)": 2.0, "k_morph(dilate)": 2.0,
-    # Canny stage (u8 in, u8 out) = NMS + hysteresis kernels
-    "k_canny_nms": 2.0, "k_runs_init(fg)": 2.0, "k_runs_merge8": 2.0, "k_runs_flatten(fg)": 2.0, "k_edge_from_cand": 2.0,
-    # contours + minAreaRect + fillPoly stage (edges in, box_img out)
-    "k_runs_init(bg)": 2.0, "k_runs_merge4_bg": 2.0, "k_runs_flatten(bg)": 2.0, "k_keys": 2.0, "k_extremes": 2.0,
-    "k_rects": 2.0, "k_fill_quads": 2.0,
-    # HoughLines reads each of the two images once
-    "k_pixlist": 2.0, "k_hough_vote": 2.0, "k_hough_peaks": 2.0, "k_hough_topk": 2.0, "k_hough_sort": 1.0,
-    "k_finalize": 0.0, "misc": 0.0,
-    # fused dilate (2N) + Canny NMS (the Canny stage's 2N) tile kernel
-    "k_dilate_canny": 4.0,
-    # per-frame LDS connectivity kernels (k_frame.h): same stages as the run kernels they replace
-    "k_frame_fg": 2.0, "k_frame_bg": 2.0, "k_frame_keys": 2.0,
-    # dim pass: prep (5N) + erode (2N) in one band kernel
-    "k_prep_erode": 7.0,
+# algorithmic bytes per pixel of every stage of a pass, and the kernels (timing slots of the library)
+# that make up the stage.  A kernel that spans two stages appears with a share of each (bytes, fraction of its time).
+#   prep 5N | erode 2N | dilate 2N | Canny 2N | contours+rect+fill 2N | Hough 1N per image
+STAGES = {
+    "prep": (5.0, {"k_prep_hist": 1.0, "k_lut": 1.0, "k_removestars": 1.0}),
+    "prep+erode": (7.0, {"k_prep_erode": 1.0}),
+    "erode": (2.0, {"k_morph(erode)": 1.0}),
+    "dilate": (2.0, {"k_morph(dilate)": 1.0, "k_dilate_canny": 0.55}),
+    # Canny = NMS (the Sobel / NMS stages are ~45 % of the fused tile kernel: stage ablation in profiles/README.md)
+    # + hysteresis (candidate-run scan, per-frame union-find, general fallback kernels)
+    "canny": (2.0, {"k_dilate_canny": 0.45, "k_canny_nms": 1.0, "k_runs_init(fg)": 1.0, "k_frame_fg": 1.0, "k_runs_merge8": 1.0,
+                    "k_runs_flatten(fg)": 1.0, "k_edge_from_cand": 1.0}),
+    "contours+rect+fill": (2.0, {"k_runs_init(bg)": 1.0, "k_frame_bg": 1.0, "k_frame_keys": 1.0, "k_runs_merge4_bg": 1.0,
+                                 "k_runs_flatten(bg)": 1.0, "k_keys": 1.0, "k_extremes": 1.0, "k_rects": 1.0, "k_fill_quads": 1.0}),
+    # two images per frame with a detected rectangle, 1N each
+    "hough": (2.0, {"k_pixlist": 1.0, "k_hough_vote": 1.0, "k_hough_peaks": 1.0, "k_hough_topk": 1.0, "k_hough_sort": 1.0}),
 }
+# bytes per pixel charged to ONE kernel when it is the dominant one: its stage's bytes split over the stage's kernels
+# so that nothing is counted twice (the fused tile kernel: dilate 2N + the image read of the Canny stage, 1N; the other
+# 1N of Canny -- its edge-map output -- belongs to the hysteresis kernels)
+KERNEL_BYTES_PER_PX = {
+    "k_prep_hist": 5.0, "k_prep_erode": 7.0, "k_morph(erode)": 2.0, "k_morph(dilate)": 2.0, "k_dilate_canny": 3.0, "k_canny_nms": 1.0,
+    "k_runs_init(fg)": 0.25, "k_frame_fg": 0.75, "k_runs_init(bg)": 0.25, "k_frame_bg": 1.0, "k_rects": 0.5, "k_fill_quads": 0.25,
+    "k_pixlist": 0.5, "k_hough_vote": 1.25, "k_hough_peaks": 0.25,
+}
+TRAFFIC_KEYS = {"k_morph(dilate)": "k_morph_rect_v<0>", "k_morph(erode)": "k_morph_rect_v<1>", "k_canny_nms": "k_canny_nms_v",
+                "k_dilate_canny": "k_dilate_canny_w", "k_frame_bg": "k_frame_contours"}
 
 
-def _gen(k):
-    from lfd_amd import synth
-    img, cat, _ = synth.make_frame(k)
-    return img, cat
-
-
-def make_frames(k0, n, workers):
-    if workers > 1:
-        import multiprocessing as mp
-        with mp.get_context("fork").Pool(workers) as pool:
-            out = pool.map(_gen, range(k0, k0 + n), chunksize=max(1, n // (workers * 4)))
-    else:
-        out = [_gen(k) for k in range(k0, k0 + n)]
-    return [o[0] for o in out], [o[1] for o in out]
+def load_traffic(name, cfg):
+    """HBM bytes per launch of kernel `name` from the committed PMC passes (profiles/r*_traffic.json), for this config only."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                tj = json.load(f)
+            c = tj["config"]
+            if (c.get("workload", "sdss"), c["frames_per_gpu"], c["inflight"], c["lanes"], c["shape"]) != cfg:
+                continue
+            key = TRAFFIC_KEYS.get(name, name.split("(")[0])
+            for k, v in tj["kernels"].items():
+                if k == key or k.startswith(key + "<"):
+                    return v["hbm_bytes_per_launch"], os.path.basename(path)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def main():
@@ -73,16 +88,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames-per-gpu", type=int, default=256)
-    ap.add_argument("--inflight", type=int, default=256)
+    ap.add_argument("--workload", choices=("sdss", "lsst"), default="sdss")
+    ap.add_argument("--frames-per-gpu", type=int, default=None, help="default 256 (configs[2]: 256 per GPU; configs[4]: 2048 over 8 GPUs)")
+    ap.add_argument("--inflight", type=int, default=None, help="frames per launch (default: the whole batch)")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches (streams) per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=40, help="frames timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="frames timed through the CPU oracle on one thread (0 = skip)")
     ap.add_argument("--gen-workers", type=int, default=-1)
     ap.add_argument("--no-removestars", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="developer: leave the per-launch HIP events off (no roofline entry) to see what they cost")
     ap.add_argument("--host-frames", action="store_true",
-                    help="hand the frames over as host buffers (PCIe-inclusive rate; never the headline value)")
+                    help="developer: time ONLY the host-resident (PCIe-inclusive) path as the headline value of this run")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the secondary PCIe-inclusive measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -93,18 +110,24 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
 
-    n = args.frames_per_gpu
+    from lfd_amd import synth
+    lsst = args.workload == "lsst"
+    shape = synth.LSST_SHAPE if lsst else synth.SDSS_SHAPE
+    n = args.frames_per_gpu or 256
+    inflight = args.inflight or n
+    cpu_sample = args.cpu_sample if args.cpu_sample is not None else (2 if lsst else 40)
     k0 = rank * n
     workers = args.gen_workers
     if workers < 0:
         workers = max(1, min(16, (os.cpu_count() or 8) // max(1, world)))
     t0 = time.time()
-    frames, cats = make_frames(k0, n, workers)  # before anything touches the GPU (fork-safe)
+    # child processes (never forks of this one: safe under a profiler's preloaded library), frames into shared memory
+    host, cats = synth.make_frames(k0, n, shape, workers, with_catalog=not lsst)
     t_gen = time.time() - t0
 
     import torch
     import torch.distributed as dist
-    from lfd_amd import _native, synth
+    from lfd_amd import _native
     from lfd_amd.batch import BatchDetector
     from lfd_amd.detecttrails import default_params
 
@@ -116,24 +139,32 @@ def main():
 
     pb, pd, prs = default_params()
     rs = _native.make_rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
-    h, w = frames[0].shape
-    host = np.stack(frames)
+    h, w = shape
+    rhos = [20.0, 10.0, 5.0]
+    if lsst:
+        pd = dict(pd, erodeKernel=np.ones((9, 9), np.uint8))
     dframes = torch.from_numpy(host).to(dev)
-    cat = None
-    if not args.no_removestars:
+    cat = packed = None
+    if not lsst and not args.no_removestars:
         packed = synth.pack_catalogs(cats)
         cat = {k: torch.from_numpy(v).to(dev) for k, v in packed.items()}
     stream = torch.cuda.current_stream().cuda_stream
-    det = BatchDetector(local_rank, (h, w), args.inflight, stream=stream, lanes=args.lanes)
+    det = BatchDetector(local_rank, (h, w), inflight, stream=stream, lanes=args.lanes)
 
-    if args.host_frames:
-        hcat = None if args.no_removestars else packed
-
-        def step():
-            return det.detect(host, pb, pd, hcat, rs)
+    if lsst:
+        def run(frames, _cat):
+            return det.multiscale(frames, pd, rhos, dim=True, flip=True)
     else:
-        def step():
-            return det.detect(dframes, pb, pd, cat, rs)
+        def run(frames, c):
+            return det.detect(frames, pb, pd, c, rs)
+
+    def step_dev():
+        return run(dframes, cat)
+
+    def step_host():
+        return run(host, None if (lsst or args.no_removestars) else packed)
+
+    step = step_host if args.host_frames else step_dev
 
     def fence():
         torch.cuda.synchronize()
@@ -152,7 +183,7 @@ def main():
         res = step()
     torch.cuda.synchronize()
     warm = det.get_timing()
-    cands = sorted((k for k, v in warm.items() if v[1] and STAGE_BYTES_PER_PX.get(k, 0.0) > 0), key=lambda k: -warm[k][0])[:4]
+    cands = sorted((k for k, v in warm.items() if v[1] and KERNEL_BYTES_PER_PX.get(k, 0.0) > 0), key=lambda k: -warm[k][0])[:4]
     det.timing_select(cands or ["k_dilate_canny", "k_prep_hist", "k_hough_vote", "k_prep_erode"])
     det.enable_timing(not args.no_kernel_timing)  # (re-arms and clears the sums)
     fence()
@@ -168,6 +199,21 @@ def main():
     torch.cuda.synchronize()
     table = det.get_timing()
     det.enable_timing(False)
+    host_leg = None
+    if not args.host_frames and not args.no_host_leg:  # secondary: frames handed over as host buffers (PCIe-inclusive; never `value`)
+        step_host()
+        fence()
+        t0 = time.perf_counter()
+        m = max(1, min(args.steps, 3))
+        for _ in range(m):
+            step_host()
+        fence()
+        host_leg = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([host_leg], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            host_leg = float(t.item())
+        host_leg = (world * n * m / host_leg, m)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -175,71 +221,121 @@ def main():
 
     cnt = det.get_counters()[:n]  # last pass of every slot: Hough cost is 180 votes per non-zero pixel
     nnz_equ, nnz_box = cnt[:, 15][cnt[:, 8] > 0], cnt[:, 16][cnt[:, 8] > 0]
-    found_b = int((res["found"] == 1).sum())
-    found_d = int((res["found"] == 2).sum())
+    res0 = res[0] if lsst else res       # lsst: [scale, frame]
+    found_b = int((res0["found"] == 1).sum())
+    found_d = int((res0["found"] == 2).sum())
     errors = int((res["status"] != 0).sum())
 
     if rank == 0:
         total_frames = world * n * args.steps
         value = total_frames / elapsed
+        N = h * w
         # dominant kernel by device time inside the timed region
         if not any(v[1] for v in timing.values()):
             timing = {"misc": (1e-9, 1, 1)}
         name, (ms, launches, units) = max(timing.items(), key=lambda kv: kv[1][0])
-        bytes_per_frame = STAGE_BYTES_PER_PX[name] * h * w
+        bytes_per_frame = KERNEL_BYTES_PER_PX.get(name, 0.0) * N
         achieved = (bytes_per_frame * units) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic = None
-        try:  # HBM bytes per launch from the committed PMC passes, valid for the default workload only
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                tj = json.load(f)
-            c = tj["config"]
-            if (c["frames_per_gpu"], c["inflight"], c["lanes"], c["shape"]) == (n, args.inflight, args.lanes, [h, w]):
-                key = {"k_morph(dilate)": "k_morph_rect_v<0>", "k_morph(erode)": "k_morph_rect_v<1>",
-                       "k_canny_nms": "k_canny_nms_v", "k_hough_vote": "k_hough_vote<6>",
-                       "k_dilate_canny": "k_dilate_canny_w", "k_frame_bg": "k_frame_contours"}.get(name, name.split("(")[0])
-                traffic = tj["kernels"][key]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            traffic = None
+        avg_ms = ms / max(1, launches)
+        traffic, traffic_src = load_traffic(name, (args.workload, n, inflight, args.lanes, [h, w]))
         kern = {k: {"ms_per_step": round(v[0], 4), "launches_per_step": v[1], "frames_per_step": v[2]}
                 for k, v in table.items() if v[1]}  # one fully bracketed step after the timed region
+        # per-stage view of that step: every stage's algorithmic bytes once, over the summed time of its kernels
+        stages = {}
+        for sname, (bpp, ks) in STAGES.items():
+            t_ms = sum(table[k][0] * share for k, share in ks.items() if k in table and table[k][1])
+            if t_ms <= 0:
+                continue
+            lead = max((k for k in ks if k in table and table[k][1]), key=lambda k: table[k][0] * ks[k])
+            frames_st = table[lead][2]  # (Hough: frames with a rectangle, summed over the launches of every scale)
+            gb = bpp * N * frames_st / 1e9
+            stages[sname] = {"ms_per_step": round(t_ms, 4), "algorithmic_GB": round(gb, 4), "GBps": round(gb / (t_ms * 1e-3), 1),
+                             "frac_of_peak": round(gb / (t_ms * 1e-3) / HBM_PEAK_GBPS, 4)}
+        ch = None
+        if "canny" in stages and "hough" in stages:  # what north_star asks for: Canny (2N) + Hough (1N per image) over their kernels
+            gb = stages["canny"]["algorithmic_GB"] + stages["hough"]["algorithmic_GB"]
+            t_ms = stages["canny"]["ms_per_step"] + stages["hough"]["ms_per_step"]
+            t_lo = t_ms + sum(table[k][0] * 0.55 for k in ("k_dilate_canny",) if k in table)  # the whole fused tile kernel charged to Canny
+            ch = {"algorithmic_GB": round(gb, 4), "ms_per_step": round(t_ms, 4), "GBps": round(gb / (t_ms * 1e-3), 1),
+                  "frac": round(gb / (t_ms * 1e-3) / HBM_PEAK_GBPS, 4),
+                  "frac_if_fused_tile_kernel_is_all_canny": round(gb / (t_lo * 1e-3) / HBM_PEAK_GBPS, 4),
+                  "target": 0.5}
+        if lsst:
+            metric = "LSST-scale frames/sec (4096x4096) dim pass, 9x9 erosion, multi-scale Hough"
+            workload = ("configs[4]: dim pass with 9x9 erosion + HoughLines at rho 20/10/5, batch=%d synthetic 4096x4096 float32 frames "
+                        "per GPU, %s" % (n, "HOST-resident (PCIe-inclusive)" if args.host_frames else "device-resident"))
+        else:
+            metric = "SDSS frames/sec (2048x1489) full detecttrails pipe"
+            workload = ("configs[2]: full removestars+bright+dim pipe, batch=%d synthetic SDSS 2048x1489 float32 frames per GPU, %s"
+                        % (n, "HOST-resident (PCIe-inclusive)" if args.host_frames else "device-resident"))
         out = {
-            "metric": "SDSS frames/sec (2048x1489) full detecttrails pipe", "value": round(value, 2),
+            "metric": metric, "value": round(value, 2),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: full removestars+bright+dim pipe, batch=%d synthetic SDSS "
-                                   "2048x1489 float32 frames per GPU, %s" % (n, "HOST-resident (PCIe-inclusive)" if args.host_frames else "device-resident"),
-                       "frames_per_gpu": n, "inflight": args.inflight, "lanes": args.lanes, "shape": [h, w],
-                       "removestars": not args.no_removestars, "parallelism": "frame-parallel x%d" % world,
+            "config": {"workload": workload,
+                       "frames_per_gpu": n, "inflight": inflight, "lanes": args.lanes, "shape": [h, w],
+                       "removestars": (not lsst) and not args.no_removestars, "parallelism": "frame-parallel x%d" % world,
                        "found_bright": found_b, "found_dim": found_d, "frame_errors": errors,
+                       "hough_rhos": rhos if lsst else [20.0],
                        "hough_nnz_equ_median": int(np.median(nnz_equ)) if len(nnz_equ) else 0,
                        "hough_nnz_box_median": int(np.median(nnz_box)) if len(nnz_box) else 0,
+                       "workspace_GB": round(det.workspace_bytes() / 1e9, 2), "frames_spilled_to_worst_case_workspace": det.spill_count(),
                        "gen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         "measured_traffic_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if traffic and avg_ms > 0 else None,
                          "frac_of_measured_copy_6290": round(achieved / 6290.0, 5),
-                         "avg_launch_ms": round(ms / max(1, launches), 4),
+                         "avg_launch_ms": round(avg_ms, 4),
                          "frames_per_launch": round(units / max(1, launches), 2),
                          "algorithmic_bytes_per_frame": bytes_per_frame,
-                         "note": "priced against HBM as SURVEY 8(d) prescribes; the SQ counters in profiles/README.md show "
-                                 "this kernel limited by vector-unit issue and LDS round trips on its occupied tiles"
-                                 if name == "k_dilate_canny" else ""},
+                         "algorithmic_bytes_per_px": KERNEL_BYTES_PER_PX.get(name, 0.0),
+                         "canny_hough": ch,
+                         "note": "algorithmic bytes as SURVEY 8(d) prescribes, each stage charged once across its kernels; "
+                                 "measured_traffic_frac = PMC HBM bytes per launch / launch time / peak: a kernel whose measured "
+                                 "fraction is far below 1 is limited by vector-unit issue / LDS round trips, not by HBM"},
+            "stages": stages,
             "kernels": kern,
         }
-        if args.cpu_sample > 0:
+        if host_leg:
+            out["host_resident"] = {"value": round(host_leg[0], 2), "unit": "frames/s", "steps": host_leg[1],
+                                    "note": "same step with the frames handed over as host buffers (PCIe-inclusive); never `value`"}
+        if cpu_sample > 0:
+            from concurrent.futures import ThreadPoolExecutor
             from oracle import lfd_oracle as O
             rs_o = O.rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
-            m = min(args.cpu_sample, n)
-            t0 = time.perf_counter()
-            agree = 0
-            for i in range(m):
+
+            def cpu_frame(i):
+                if lsst:
+                    rec = [O.process_dim(host[i].copy(), dict(pd, houghMethod=r), flip=True) for r in rhos]
+                    return all(all(rr[k] == res[s][i][k].item() for k in rr) for s, rr in enumerate(rec))
                 r = O.detect_frame(host[i].copy(), pb, pd, None if args.no_removestars else cats[i], rs_o)
-                agree += all(r[k] == res[i][k].item() for k in r)
+                return all(r[k] == res[i][k].item() for k in r)
+
+            m = min(cpu_sample, n)
+            t0 = time.perf_counter()
+            agree = sum(cpu_frame(i) for i in range(m))
             dt = time.perf_counter() - t0
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except (AttributeError, OSError):
+                avail = os.cpu_count() or 1
+            cores = max(1, min(avail, 16 * max(1, world), n))     # this process's share of the host (16 cores per GPU on the pool)
+            what = "3 x process_dim (rho 20/10/5)" if lsst else "detect_frame"
             out["cpu_baseline"] = {"value": round(m / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": "first %d frames of rank 0's batch through oracle/ (C, -O2, 1 thread), "
-                                             "%d/%d identical to the GPU records" % (m, agree, m),
-                                   "host_cores_available": os.cpu_count()}
+                                   "sample": "first %d frames of rank 0's batch through oracle/ (C, -O2, 1 thread; %s), "
+                                             "%d/%d identical to the GPU records" % (m, what, agree, m),
+                                   "host_cores_available": avail}
+            # all host cores: one oracle call per thread (ctypes releases the GIL), a bounded sample again
+            per = max(1, int(round(m / dt * 12.0)))               # ~12 s of work per core
+            ma = min(n, cores * per)
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                agree_a = sum(ex.map(cpu_frame, range(ma)))
+            dta = time.perf_counter() - t0
+            out["cpu_baseline"]["all_cores"] = {"value": round(ma / dta, 3), "unit": "frames/s", "cores": cores,
+                                                "sample": "%d frames on %d threads, %d/%d identical to the GPU records" % (ma, cores, agree_a, ma)}
         print(json.dumps(out), flush=True)
     det.close()
     if use_dist:

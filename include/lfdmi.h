@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LFDMI_VERSION 100
+#define LFDMI_VERSION 200
 
 enum lfdmi_status {
     LFDMI_OK = 0,
@@ -49,7 +49,7 @@ enum { LFDMI_RETR_EXTERNAL = 0, LFDMI_RETR_LIST = 1, LFDMI_RETR_CCOMP = 2, LFDMI
 enum { LFDMI_CHAIN_APPROX_NONE = 1, LFDMI_CHAIN_APPROX_SIMPLE = 2, LFDMI_CHAIN_APPROX_TC89_L1 = 3,
        LFDMI_CHAIN_APPROX_TC89_KCOS = 4 };
 /* lfdmi_get_stage selectors (device images of the last process/detect call, per slot) */
-enum { LFDMI_STAGE_GRAY = 0, LFDMI_STAGE_EQU = 1, LFDMI_STAGE_CANNY = 2, LFDMI_STAGE_BOX = 3 };
+enum { LFDMI_STAGE_GRAY = 0, LFDMI_STAGE_EQU = 1, LFDMI_STAGE_CANNY = 2, LFDMI_STAGE_BOX = 3, LFDMI_STAGE_ERODED = 4 };
 
 typedef struct lfdmi_ctx lfdmi_ctx;
 
@@ -100,9 +100,33 @@ typedef struct {
     int32_t rejected_by_theta;    /* check_theta returned True in the last pass that ran */
 } lfdmi_result;
 
+/* Workspace sizing.  Per in-flight frame the workspace holds dense 8-bit planes, bit rows and a set of
+ * tables whose theoretical maxima (a checkerboard: H*(W/2+1) runs, N/2 contours, 2N contour rows, N Hough
+ * chunks) are ~100 B/px, while sky frames use less than 1 % of that (tools/cap_survey.py).  A context is
+ * therefore created with the capacities below (per frame; N = max_h*max_w); a frame that needs more in
+ * any table is detected on the device (no table is ever indexed past its capacity), and the library
+ * runs it again, alone, through a worst-case workspace it keeps for that purpose (created on first
+ * use, one frame in flight), so no input can fail for lack of table space.  A field <= 0 means "the
+ * theoretical maximum"; caps == NULL means the defaults of lfdmi_default_caps. */
+typedef struct {
+    int32_t run_cap;   /* runs per bit image (Canny candidates / background of the edge image); default N/16 */
+    int32_t key_cap;   /* contours (edge components + holes); default N/256 */
+    int32_t slot_cap;  /* contour rows (one (xmin,xmax) slot per row of every contour); default N/16 */
+    int32_t list_cap;  /* Hough input chunks (runs of <= 16 px) per image; default N/16 */
+    int32_t peak_cap;  /* Hough local maxima per image (rounded up to a power of two); default 65536 */
+    double min_rho;    /* HoughLines accumulators are sized for rho >= min_rho (theta >= pi/180); default 5;
+                          a call with a finer rho runs through the worst-case workspace */
+} lfdmi_caps;
+void lfdmi_default_caps(int max_h, int max_w, lfdmi_caps *out);
+
 int lfdmi_version(void);
-/* max_inflight = frames processed concurrently (workspace is sized for that many). */
+/* max_inflight = frames processed concurrently (workspace is sized for that many, default capacities). */
 int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflight, lfdmi_ctx **out);
+int lfdmi_ctx_create_sized(int device, int max_h, int max_w, int max_inflight, const lfdmi_caps *caps,
+                           lfdmi_ctx **out);
+/* device bytes the workspace holds; frames re-run through the worst-case workspace since creation */
+int64_t lfdmi_ctx_bytes(lfdmi_ctx *ctx);
+int64_t lfdmi_spill_count(lfdmi_ctx *ctx);
 void lfdmi_ctx_destroy(lfdmi_ctx *ctx);
 const char *lfdmi_last_error(lfdmi_ctx *ctx);
 /* run on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own */
@@ -161,6 +185,16 @@ int lfdmi_process_bright(lfdmi_ctx *ctx, const void *img, int dtype, int n, int 
 int lfdmi_process_dim(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, int w, int flip,
                       int after_bright, const lfdmi_params *p, lfdmi_result *results,
                       float *lines_equ, float *lines_box, int loc);
+/* One pass with HoughLines evaluated at several rho ("multi-scale Hough", BASELINE.json configs[4]; the
+ * reference itself always calls the classic transform once, processfield.py:370-371,488-489): the front
+ * end (mask .. fit_minAreaRect) runs once, then HoughLines(equ) / HoughLines(box_img) / check_theta for
+ * every rhos[s].  results[s * n + i] is exactly what lfdmi_process_bright / _dim returns for frame i with
+ * houghMethod = rhos[s] (p->houghMethod itself is ignored).  dim != 0: process_field_dim (after_bright as
+ * in lfdmi_process_dim); dim == 0: process_field_bright.  1 <= n_scales <= LFDMI_MAX_SCALES. */
+#define LFDMI_MAX_SCALES 4
+int lfdmi_process_multiscale(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, int w, int flip,
+                             int dim, int after_bright, const lfdmi_params *p, int n_scales,
+                             const double *rhos, lfdmi_result *results, int loc);
 /* process_field's hot part (detecttrails.py:119-131) for n float32 frames:
  * remove_stars (cat may be NULL) -> flip -> bright -> dim where bright found nothing.
  * frames are mutated by remove_stars only, as in the reference.  results: n records in HOST
@@ -169,8 +203,9 @@ int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w,
                        const lfdmi_catalog *cat, const lfdmi_rs_params *rs,
                        const lfdmi_params *bright, const lfdmi_params *dim, lfdmi_result *results,
                        int loc);
-/* copy a stage image (u8, h x w) of in-flight slot `slot` of the LAST call to dst */
-int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, uint8_t *dst, int loc);
+/* copy a stage image (u8, h x w) of in-flight slot `slot` of the LAST call to dst; h, w must be the shape of
+ * that call (LFDMI_ERR_ARG otherwise: dst is then too small or too large for what the workspace holds) */
+int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, int h, int w, uint8_t *dst, int loc);
 /* diagnostics: the work counters of in-flight slots [slot0, slot0 + n) as left by the LAST pass
  * (LFDMI_COUNTERS int32 values per slot; order: keys, row slots, rectangles, equ list entries, box
  * list entries (pixel chunks the Hough kernels vote with), equ peaks, box peaks, overflow flag,
@@ -192,6 +227,9 @@ int lfdmi_timing_select(lfdmi_ctx *ctx, uint64_t mask);
 int lfdmi_get_timing(lfdmi_ctx *ctx, float *ms, int32_t *launches, int64_t *units);
 int lfdmi_timing_slots(void);
 const char *lfdmi_timing_name(int slot);
+/* developer tool (LFDMI_FRAME_PROFILE=1 in the environment when the context is created): per-phase clocks
+ * (8 x int64 per slot, 10 ns ticks) of the last per-frame contour kernel launch, slots 0 .. n-1 */
+int lfdmi_debug_frame_profile(lfdmi_ctx *ctx, int n, long long *dst);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblfdmi.so")
 HOST, DEVICE = 0, 1
 U8, F32, F64 = 0, 1, 2
 PREP_NONE, PREP_BRIGHT, PREP_DIM, PREP_BRIGHT_THEN_DIM = 0, 1, 2, 3
-STAGE_GRAY, STAGE_EQU, STAGE_CANNY, STAGE_BOX = 0, 1, 2, 3
+STAGE_GRAY, STAGE_EQU, STAGE_CANNY, STAGE_BOX, STAGE_ERODED = 0, 1, 2, 3, 4
+MAX_SCALES = 4
 MAX_SET_LINES = 64
 MAX_MORPH_K = 31
 
@@ -25,7 +26,8 @@ ERR_ARG, ERR_DTYPE, ERR_HIP, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_NOLINES = -1, -2
 
 # every symbol include/lfdmi.h declares (checked by the CPU test-suite)
 SYMBOLS = (
-    "lfdmi_version", "lfdmi_ctx_create", "lfdmi_ctx_destroy", "lfdmi_last_error", "lfdmi_set_stream",
+    "lfdmi_version", "lfdmi_default_caps", "lfdmi_ctx_create", "lfdmi_ctx_create_sized", "lfdmi_ctx_bytes", "lfdmi_spill_count",
+    "lfdmi_ctx_destroy", "lfdmi_last_error", "lfdmi_set_stream", "lfdmi_process_multiscale", "lfdmi_debug_frame_profile",
     "lfdmi_max_inflight", "lfdmi_prep_u8", "lfdmi_equalize_hist", "lfdmi_dilate", "lfdmi_erode",
     "lfdmi_canny", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
     "lfdmi_hough_dims", "lfdmi_remove_stars", "lfdmi_process_bright", "lfdmi_process_dim",
@@ -47,6 +49,12 @@ class Params(C.Structure):
                 ("dilate_kh", C.c_int32), ("dilate_kw", C.c_int32), ("dilateKernel", C.c_void_p),
                 ("erode_kh", C.c_int32), ("erode_kw", C.c_int32), ("erodeKernel", C.c_void_p),
                 ("minFlux", C.c_double), ("addFlux", C.c_double)]
+
+
+class Caps(C.Structure):
+    """lfdmi_caps: per-frame table capacities of a workspace (<= 0: the theoretical maximum)."""
+    _fields_ = [("run_cap", C.c_int32), ("key_cap", C.c_int32), ("slot_cap", C.c_int32), ("list_cap", C.c_int32),
+                ("peak_cap", C.c_int32), ("min_rho", C.c_double)]
 
 
 class RsParams(C.Structure):
@@ -92,6 +100,11 @@ def lib():
         _lib.lfdmi_ctx_destroy.restype = None
         _lib.lfdmi_ctx_destroy.argtypes = [C.c_void_p]
         _lib.lfdmi_hough_dims.restype = None
+        _lib.lfdmi_default_caps.restype = None
+        _lib.lfdmi_ctx_bytes.restype = C.c_int64
+        _lib.lfdmi_ctx_bytes.argtypes = [C.c_void_p]
+        _lib.lfdmi_spill_count.restype = C.c_int64
+        _lib.lfdmi_spill_count.argtypes = [C.c_void_p]
         _lib.lfdmi_timing_name.restype = C.c_char_p
     return _lib
 
@@ -154,11 +167,23 @@ def make_rs_params(filter, defaultxy, filter_caps, maxxy, pixscale, magcount, ma
 class Context:
     """One GPU, one HIP stream, workspace for ``max_inflight`` frames of up to max_h x max_w."""
 
-    def __init__(self, device=0, max_h=1489, max_w=2048, max_inflight=8):
+    def __init__(self, device=0, max_h=1489, max_w=2048, max_inflight=8, caps=None):
+        """caps: None = the library's default table capacities (frames that need more are re-run through a
+        worst-case workspace inside the library); "worst" = every table at its theoretical maximum; or a dict
+        with any of run_cap / key_cap / slot_cap / list_cap / peak_cap / min_rho (others keep their defaults)."""
         self._h = C.c_void_p()
         self._lib = lib()
-        rc = self._lib.lfdmi_ctx_create(int(device), int(max_h), int(max_w), int(max_inflight),
-                                        C.byref(self._h))
+        if caps is None:
+            rc = self._lib.lfdmi_ctx_create(int(device), int(max_h), int(max_w), int(max_inflight),
+                                            C.byref(self._h))
+        else:
+            c = Caps()
+            if caps != "worst":
+                self._lib.lfdmi_default_caps(int(max_h), int(max_w), C.byref(c))
+                for k, v in dict(caps).items():
+                    setattr(c, k, v)
+            rc = self._lib.lfdmi_ctx_create_sized(int(device), int(max_h), int(max_w), int(max_inflight),
+                                                  C.byref(c), C.byref(self._h))
         if rc:
             msg = self._lib.lfdmi_last_error(self._h).decode() if self._h else "context creation failed"
             h, self._h = self._h, C.c_void_p()
@@ -184,6 +209,14 @@ class Context:
     def _chk(self, rc):
         if rc:
             raise NativeError(rc, self._lib.lfdmi_last_error(self._h).decode())
+
+    def workspace_bytes(self):
+        """Device bytes of the workspace (worst-case spill workspace included once it exists)."""
+        return int(self._lib.lfdmi_ctx_bytes(self._h))
+
+    def spill_count(self):
+        """Frames this context has re-run through its worst-case workspace."""
+        return int(self._lib.lfdmi_spill_count(self._h))
 
     def set_stream(self, stream_handle):
         self._chk(self._lib.lfdmi_set_stream(self._h, C.c_void_p(stream_handle or 0)))
@@ -392,6 +425,18 @@ class Context:
     def process_dim(self, img, params, flip=False, after_bright=False):
         return self._pass(self._lib.lfdmi_process_dim, img, params, True, flip, (int(after_bright),))
 
+    def process_multiscale(self, img, params, rhos, dim=True, flip=False, after_bright=False):
+        """One pass with HoughLines evaluated at every rho of ``rhos``; returns a structured array
+        [len(rhos), n] (or [len(rhos)] for a single image): row s == process_dim/bright with houghMethod=rhos[s]."""
+        img, n, h, w, sq = self._batch(img)
+        loc = DEVICE if _is_dev(img) else HOST
+        p, keep = make_params(params, dim=dim)
+        rh = (C.c_double * len(rhos))(*[float(r) for r in rhos])
+        res = np.zeros((len(rhos), n), RESULT_DTYPE)
+        self._chk(self._lib.lfdmi_process_multiscale(self._h, _ptr(img), _dtype_code(img), n, h, w, int(flip), int(dim),
+                                                     int(after_bright), C.byref(p), len(rhos), rh, _ptr(res), loc))
+        return res[:, 0] if sq else res
+
     def detect_batch(self, frames, params_bright, params_dim, cat=None, rs=None):
         """frames: float32 (n,h,w) numpy or torch-CUDA; returns a structured array of n results."""
         frames, n, h, w, sq = self._batch(frames)
@@ -417,5 +462,5 @@ class Context:
 
     def get_stage(self, slot, which, h, w):
         out = np.empty((h, w), np.uint8)
-        self._chk(self._lib.lfdmi_get_stage(self._h, int(slot), int(which), _ptr(out), HOST))
+        self._chk(self._lib.lfdmi_get_stage(self._h, int(slot), int(which), int(h), int(w), _ptr(out), HOST))
         return out

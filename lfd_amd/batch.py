@@ -58,11 +58,11 @@ class BatchDetector:
     this is the same frame-parallel sharding as across GPUs, one level down.
     """
 
-    def __init__(self, device=0, shape=(1489, 2048), inflight=32, stream=None, lanes=1):
+    def __init__(self, device=0, shape=(1489, 2048), inflight=32, stream=None, lanes=1, caps=None):
         from concurrent.futures import ThreadPoolExecutor
         self.lanes = max(1, int(lanes))
         per = max(1, inflight // self.lanes)
-        self.ctxs = [_native.Context(device, shape[0], shape[1], per) for _ in range(self.lanes)]
+        self.ctxs = [_native.Context(device, shape[0], shape[1], per, caps=caps) for _ in range(self.lanes)]
         self.ctx = self.ctxs[0]
         if stream is not None and self.lanes == 1:
             self.ctx.set_stream(stream)
@@ -91,6 +91,12 @@ class BatchDetector:
                 out[k] = (a[0] + ms, a[1] + n, a[2] + u)
         return out
 
+    def workspace_bytes(self):
+        return sum(c.workspace_bytes() for c in self.ctxs)
+
+    def spill_count(self):
+        return sum(c.spill_count() for c in self.ctxs)
+
     def get_counters(self):
         """Work counters ([slots, 20] int32, see lfdmi_get_counters) the last pass left, all lanes."""
         return np.concatenate([c.get_counters() for c in self.ctxs])
@@ -100,6 +106,16 @@ class BatchDetector:
         if cat is None:
             return None
         return {k: v[a:b] for k, v in cat.items()}
+
+    def multiscale(self, frames, params, rhos, dim=True, flip=True, after_bright=False):
+        """One pass (dim or bright) with HoughLines at every rho of ``rhos`` over the batch: records [len(rhos), n]."""
+        if self.lanes == 1:
+            return self.ctx.process_multiscale(frames, params, rhos, dim=dim, flip=flip, after_bright=after_bright)
+        n = frames.shape[0]
+        bounds = shard_bounds(n, self.lanes)
+        futs = [self.pool.submit(c.process_multiscale, frames[a:b], params, rhos, dim, flip, after_bright)
+                for c, (a, b) in zip(self.ctxs, bounds) if b > a]
+        return np.concatenate([f.result() for f in futs], axis=1)
 
     def detect(self, frames, params_bright, params_dim, catalogs=None, rs=None):
         """frames: (n, h, w) float32, numpy (staged through the library) or a torch CUDA tensor

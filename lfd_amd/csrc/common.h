@@ -31,6 +31,14 @@ enum {
 
 __device__ __forceinline__ int lfd_lane() { return threadIdx.x & 63; }
 
+// A slot is skipped by a kernel when the pass does not work on it (`active` mask) or when an earlier kernel of
+// this pass found one of its tables too small (C_OVERFLOW): ids beyond a table's capacity must never be used
+// as indices, so every kernel downstream of a capacity check leaves such a frame alone.  The host runs the
+// frame again through the worst-case workspace (lfdmi.hip: spill).
+__device__ __forceinline__ bool slot_off(const int *active, const int *counters, int g) {
+    return (active && !active[g]) || counters[g * C_COUNT + C_OVERFLOW] != 0;
+}
+
 // mask of valid bits of word wq in a row of W pixels
 __device__ __forceinline__ u64 valid_mask(int wq, int W) {
     int rem = W - (wq << 6);

@@ -47,7 +47,7 @@ __device__ __forceinline__ u64 start_bits(const u64 *row, int wq, int val, int W
 // every run kernel walks its frame's work list with a fixed grid
 #define LFD_WORDLIST_LOOP(cidx_)                                                          \
     int g = blockIdx.y;                                                                   \
-    if (active && !active[g]) return;                                                     \
+    if (slot_off(active, counters, g)) return;                                            \
     const int wq = LFD_WQ(w);                                                             \
     const int nwork_ = counters[g * C_COUNT + (cidx_)];                                   \
     const int *wl_ = wlist + (size_t)g * h * wq;                                          \

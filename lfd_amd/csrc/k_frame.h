@@ -90,7 +90,7 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
            int *FLf, int *ROWf, u64 *edge, int h, int w, int run_cap, int lds_cap, const int *active, int *fallback,
            int *pass_flags) {
     const int g = blockIdx.x;
-    if (active && !active[g]) {
+    if (slot_off(active, counters, g)) {
         if (threadIdx.x == 0) fallback[g] = 0;
         return;
     }
@@ -291,7 +291,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
     int *Lb = t.Lb, *YMb = t.YMb, *FLb = t.FLb, *ROWb = t.ROWb;
     const int run_cap = t.run_cap;
     const int g = blockIdx.x;
-    if (active && !active[g]) {
+    if (slot_off(active, counters, g)) {
         if (threadIdx.x == 0) fallback[g] = 0;
         return;
     }

@@ -30,7 +30,7 @@ k_pixlist(const u64 *bits0, const u64 *bits1, uint32_t *list0, uint32_t *list1, 
     uint32_t *list = im ? list1 : list0;
     const int cidx = im ? C_NPIX_BOX : C_NPIX_EQU, nnz_idx = im ? C_NNZ_BOX : C_NNZ_EQU;
     if (accum_clear) accum_clear += (size_t)im * acc_stride;
-    if (active && !active[g]) return;
+    if (slot_off(active, counters, g)) return;
     int *cnt = counters + g * C_COUNT;
     if (need_detect && !cnt[C_DETECT]) return;
     int wq = LFD_WQ(w);
@@ -74,6 +74,10 @@ k_pixlist(const u64 *bits0, const u64 *bits1, uint32_t *list0, uint32_t *list1, 
         if (lane == 63 && total) base = atomicAdd(&cnt[cidx], total);
         if (lane == 0 && px) atomicAdd(&cnt[nnz_idx], px);
         base = __shfl(base, 63);
+        if ((size_t)base + (size_t)total > list_cap) { // list full: the frame is run again through the worst-case workspace
+            if (lane == 0) cnt[C_OVERFLOW] = 1;
+            continue;
+        }
         int o = base + incl - n;
         for (u64 r = c; r;) {
             int b = __ffsll((long long)r) - 1;
@@ -89,7 +93,7 @@ k_pixlist(const u64 *bits0, const u64 *bits1, uint32_t *list0, uint32_t *list1, 
 // Bins an angle slab can reach: r = (x cos + y sin) / rho over the image rectangle covers only a part of the
 // (numrho) accumulator rows -- 0 .. 127 of 356 for angles 0 - 63 deg of an SDSS frame -- so a workgroup's LDS slab
 // holds rows lo .. hi only (host: vote_ranges): less than half the LDS, two to three workgroups per CU.
-#define VOTE_MAX_SLABS 16
+#define VOTE_MAX_SLABS 32
 struct VoteRanges { int lo[VOTE_MAX_SLABS], hi[VOTE_MAX_SLABS]; }; // centred bin index r (0 = rho 0), inclusive
 
 // Accumulator layouts.  OpenCV indexes accum[(n+1)*(numrho+2) + r+1] ("base"); that value is
@@ -111,7 +115,7 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     constexpr int aw_log2 = AWL;
     int g = blockIdx.z, im = blockIdx.y;
     int slab = blockIdx.x / nsplit, split = blockIdx.x - slab * nsplit;
-    if (active && !active[g]) return;
+    if (slot_off(active, counters, g)) return;
     const int *cnt = counters + g * C_COUNT;
     if (need_detect && !cnt[C_DETECT]) return;
     extern __shared__ int acc[]; // nb * AW votes (rows lo .. hi of this slab) + 64 spare words for lanes without an angle
@@ -240,7 +244,7 @@ __global__ void __launch_bounds__(256)
 k_hough_peaks(const int *accum, u64 *peaks, int *counters, int numangle, int numrho, int threshold,
               size_t acc_cap, size_t peak_cap, const int *active, int need_detect) {
     int g = blockIdx.z, im = blockIdx.y;
-    if (active && !active[g]) return;
+    if (slot_off(active, counters, g)) return;
     int *cnt = counters + g * C_COUNT;
     if (need_detect && !cnt[C_DETECT]) return;
     const int *ag = accum + ((size_t)g * 2 + im) * acc_cap;
@@ -256,6 +260,7 @@ k_hough_peaks(const int *accum, u64 *peaks, int *counters, int numangle, int num
             int base = (n + 1) * (numrho + 2) + r + 1;
             int o = atomicAdd(&cnt[im ? C_NPEAK_BOX : C_NPEAK_EQU], 1);
             if ((size_t)o < peak_cap) pg[o] = ((u64)(uint32_t)v << 32) | (u64)(uint32_t)(0x7fffffff - base);
+            else cnt[C_OVERFLOW] = 1; // a truncated peak list could lose a top line: run the frame again (spill workspace)
         }
     }
 }
@@ -289,7 +294,7 @@ __global__ void __launch_bounds__(256)
 k_hough_topk(const u64 *peaks, const int *counters, float *lines, int K, int numrho, float rho,
              float theta, size_t peak_cap, const int *active, int need_detect) {
     int g = blockIdx.y, im = blockIdx.x;
-    if (active && !active[g]) return;
+    if (slot_off(active, counters, g)) return;
     const int *cnt = counters + g * C_COUNT;
     if (need_detect && !cnt[C_DETECT]) return;
     const u64 *pg = peaks + ((size_t)g * 2 + im) * peak_cap;
@@ -337,6 +342,7 @@ k_hough_sort(u64 *peaks, const int *counters, float *lines, int max_lines, int n
              float theta, size_t peak_cap) {
     int g = blockIdx.y, im = blockIdx.x;
     const int *cnt = counters + g * C_COUNT;
+    if (cnt[C_OVERFLOW]) return; // truncated lists: the host runs the image again through the worst-case workspace
     u64 *pg = peaks + ((size_t)g * 2 + im) * peak_cap;
     int n = cnt[im ? C_NPEAK_BOX : C_NPEAK_EQU];
     if ((size_t)n > peak_cap) n = (int)peak_cap;
@@ -442,6 +448,15 @@ __global__ void k_finalize(const float *lines, const int *counters, lfdmi_result
     res[g] = r;
     pass_flags[g] |= (tp.which == 1) ? (r.detection ? 1 : 0) : (2 | (r.detection ? 4 : 0));
     if (need_dim) need_dim[g] = (r.found == 0 && r.status == 0) ? 1 : 0;
+}
+
+// multi-scale Hough: the list / peak counters of the previous rho are cleared before the next one is evaluated
+// (C_OVERFLOW stays: a frame that overflowed at any scale is run again as a whole)
+__global__ void k_hough_reset(int *counters, int G) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    int *cnt = counters + g * C_COUNT;
+    cnt[C_NPIX_EQU] = 0; cnt[C_NPIX_BOX] = 0; cnt[C_NPEAK_EQU] = 0; cnt[C_NPEAK_BOX] = 0; cnt[C_NNZ_EQU] = 0; cnt[C_NNZ_BOX] = 0;
 }
 
 __global__ void k_init_results(lfdmi_result *res, int *pass_flags, int G) {

@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256)
 k_keys(RunTabs t, int4 *keys, int *bigkeys, int *medkeys, int2 *rowext, int *counters, int h, int w, int key_cap, int slot_cap,
        const int *wlist_fg, const int *wlist_bg, const int *active) {
     int g = blockIdx.y;
-    if (active && !active[g]) return;
+    if (slot_off(active, counters, g)) return;
     int wq = LFD_WQ(w);
     size_t fo = (size_t)g * h * wq, ro = (size_t)g * t.run_cap;
     int *cnt = counters + g * C_COUNT;
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256)
 k_extremes(RunTabs t, int2 *rowext, int h, int w, int slot_cap, const int *wlist, const int *counters,
            const int *active) {
     int g = blockIdx.y;
-    if (active && !active[g]) return;
+    if (slot_off(active, counters, g)) return;
     int wq = LFD_WQ(w);
     size_t fo = (size_t)g * h * wq, ro = (size_t)g * t.run_cap;
     const int nwork = counters[g * C_COUNT + C_NFGW];
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(64)
 k_rects(const int4 *keys, const int2 *rowext, int2 *hullbuf, int *quads, int *counters, int h,
         int w, int key_cap, int slot_cap, double minLen, double lwTresh, const int *active) {
     int g = blockIdx.y;
-    if (active && !active[g]) return;
+    if (slot_off(active, counters, g)) return;
     int *cnt = counters + g * C_COUNT;
     int nkeys = min(cnt[C_NKEYS], key_cap);
     const int4 *kg = keys + (size_t)g * key_cap;
@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(64)
 k_rects_big(const int4 *keys, const int *bigkeys, int cidx, const int2 *rowext, int *quads, int *counters, int h, int w,
             int key_cap, int slot_cap, int cap, double minLen, double lwTresh, const int *active) {
     int g = blockIdx.y;
-    if (active && !active[g]) return;
+    if (slot_off(active, counters, g)) return;
     extern __shared__ int2 lds_pts[]; // 4 x cap
     int *cnt = counters + g * C_COUNT;
     int nbig = cnt[cidx];
@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(256)
 k_fill_quads(const int *quads, const int *counters, u64 *box, int h, int w, int key_cap,
              const int *active) {
     int g = blockIdx.y;
-    if (active && !active[g]) return;
+    if (slot_off(active, counters, g)) return;
     const int *cnt = counters + g * C_COUNT;
     int nq = min(cnt[C_NQUADS], key_cap);
     int wq = LFD_WQ(w);

@@ -62,7 +62,7 @@ struct lfdmi_ctx {
     int4 *keys = nullptr;
     int *bigkeys = nullptr, *medkeys = nullptr;
     int *wl_fg = nullptr, *wl_bg = nullptr; // work lists of active bit-row words
-    int2 *rowext = nullptr, *hullbuf = nullptr;
+    int2 *rowext = nullptr;
     int *quads = nullptr;
     uint32_t *pix_equ = nullptr, *pix_box = nullptr;
     int *accum = nullptr;
@@ -78,7 +78,19 @@ struct lfdmi_ctx {
     bool use_cellbm = true;
     int4 *segcnt = nullptr;            // per 64-word segment: run starts, fg / bg list entries (then their exclusive sums)
     int *fb_fg = nullptr, *fb_bg = nullptr; // per slot: frame left to the multi-workgroup run kernels (k_frame.h)
-    lfdmi_result *res_dev = nullptr;
+    lfdmi_result *res_dev = nullptr;   // G x LFDMI_MAX_SCALES records (one block of G per Hough scale)
+    // Workspace sizing (include/lfdmi.h: lfdmi_caps).  A compact context keeps a worst-case one for single frames
+    // (`spill`, created on first use): a frame whose tables overflow here (per-frame LFDMI_ERR_CAPACITY) is run
+    // again there, so no input fails for lack of table space.
+    bool worst = false;                // every table at its theoretical maximum (the spill workspace itself)
+    lfdmi_ctx *spill = nullptr;
+    long long n_spilled = 0;           // frames re-run through the spill workspace since creation
+    size_t bytes = 0;                  // device bytes of the workspace (dmalloc)
+    double min_rho = 1.0;              // accumulators / peak lists sized for HoughLines rho >= min_rho
+    void *scratch = nullptr;           // stand-alone HoughLines: sorted lines / untransposed accumulator
+    size_t scratch_bytes = 0;
+    int last_h = 0, last_w = 0;        // shape of the last call (lfdmi_get_stage)
+    int quiet_chunks = 0;              // chunks since a frame last needed the general run kernels (general_seen decays)
     int4 *rs_boxes = nullptr;          // remove_stars squares of the chunk (host-frame path)
     size_t rs_boxes_cap = 0;
     void *stage = nullptr;
@@ -87,10 +99,17 @@ struct lfdmi_ctx {
     size_t cat_bytes = 0;
     int key_cap = 0, slot_cap = 0;
     size_t acc_cap = 0, peak_cap = 0, list_cap = 0;
-    // cached Hough tables
-    double tab_rho = -1, tab_theta = -1;
-    int tab_h = 0, tab_w = 0, numangle = 0, numrho = 0;
-    std::vector<float> tab_host;       // host copy of the trig table (slab ranges of the vote kernel)
+    // cached Hough tables: the last few (rho, theta, shape) combinations keep their device trig table, so a
+    // multi-scale pass (rho = 20, 10, 5 on the same image) does not rebuild and re-upload tables per launch
+    struct HoughTab {
+        double rho = -1, theta = -1;
+        int h = 0, w = 0, numangle = 0, numrho = 0;
+        long long stamp = 0;
+        std::vector<float> host;       // host copy (slab ranges of the vote kernel; source of the upload)
+    } tabs[LFDMI_MAX_SCALES];
+    long long tab_clock = 0;
+    int tab_cur = 0;                   // entry the next Hough launch uses: device table = tab + tab_cur * 2 * MAX_ANGLES
+    int numangle = 0, numrho = 0;
     // timing
     bool timing = false;
     uint64_t timing_mask = 0;          // non-zero: only these timing slots' launches are bracketed (lfdmi_timing_select)
@@ -180,6 +199,7 @@ template <typename T> static int dmalloc(lfdmi_ctx *ctx, T **p, size_t count) {
     void *q = nullptr;
     HIPCHK(hipMalloc(&q, count * sizeof(T)));
     ctx->allocs.push_back(q);
+    ctx->bytes += count * sizeof(T);
     *p = (T *)q;
     return 0;
 }
@@ -194,7 +214,34 @@ extern "C" void lfdmi_hough_dims(int h, int w, double rho_d, double theta_d, int
     *numrho = (int)lrint(((w + h) * 2 + 1) / rho);
 }
 
-extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflight, lfdmi_ctx **out) {
+// theoretical maxima of the per-frame tables (a checkerboard image)
+static void worst_caps(int h, int w, lfdmi_caps *c) {
+    size_t N = (size_t)h * w;
+    c->run_cap = (int)((size_t)h * (w / 2 + 1) + 16);
+    c->key_cap = (int)(N / 2 + 16);
+    c->slot_cap = (int)(2 * N + 4 * (size_t)h + 16);
+    c->list_cap = (int)N;
+    c->peak_cap = 0; // numangle * numrho at min_rho
+    c->min_rho = 1.0;
+}
+
+extern "C" void lfdmi_default_caps(int max_h, int max_w, lfdmi_caps *out) {
+    // tools/cap_survey.py (SDSS batch, LSST-size dim / bright passes): runs <= N/165, contours <= N/3100, contour
+    // rows <= N/228, Hough chunks <= N/282, peaks <= 9 000 per image.  Defaults leave ~10x headroom; the floors keep
+    // small test images (dense random noise) out of the spill path.
+    size_t N = (size_t)max_h * max_w;
+    lfdmi_caps wc;
+    worst_caps(max_h, max_w, &wc);
+    auto pick = [](size_t want, size_t floor_, int worst) { size_t v = want > floor_ ? want : floor_; return (int)(v < (size_t)worst ? v : (size_t)worst); };
+    out->run_cap = pick(N / 16, 16384, wc.run_cap);
+    out->key_cap = pick(N / 256, 4096, wc.key_cap);
+    out->slot_cap = pick(N / 16, 16384, wc.slot_cap);
+    out->list_cap = pick(N / 16, 16384, wc.list_cap);
+    out->peak_cap = 65536;
+    out->min_rho = 5.0;
+}
+
+static int create_impl(int device, int max_h, int max_w, int max_inflight, const lfdmi_caps *caps_in, lfdmi_ctx **out) {
     if (!out || max_h <= 0 || max_w <= 0 || max_inflight <= 0 || max_h > 8191 || max_w > 8191) return LFDMI_ERR_ARG;
     lfdmi_ctx *ctx = new lfdmi_ctx();
     *out = ctx;
@@ -209,6 +256,25 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     ctx->N = (size_t)max_h * max_w;
     ctx->wq = LFD_WQ(max_w);
     size_t N = ctx->N, G = (size_t)max_inflight, BW = (size_t)max_h * ctx->wq;
+    // capacities: the caller's, the defaults, or (fields <= 0, LFDMI_WORST_CASE=1) the theoretical maxima
+    lfdmi_caps wc, caps;
+    worst_caps(max_h, max_w, &wc);
+    if (caps_in) caps = *caps_in; else lfdmi_default_caps(max_h, max_w, &caps);
+    if (const char *e = getenv("LFDMI_WORST_CASE")) if (atoi(e)) caps = wc;
+    auto cap = [](int v, int worst) { return (v <= 0 || v > worst) ? worst : v; };
+    ctx->run_cap = cap(caps.run_cap, wc.run_cap);
+    ctx->key_cap = cap(caps.key_cap, wc.key_cap);
+    ctx->slot_cap = cap(caps.slot_cap, wc.slot_cap);
+    ctx->list_cap = (size_t)cap(caps.list_cap, wc.list_cap);
+    ctx->min_rho = caps.min_rho >= 1.0 ? caps.min_rho : 1.0;
+    int na, nr;
+    lfdmi_hough_dims(max_h, max_w, ctx->min_rho, LFD_PI / 180, &na, &nr);
+    ctx->acc_cap = (size_t)(na + 2) * (nr + 2);
+    size_t peak_worst = next_pow2((size_t)na * nr);
+    ctx->peak_cap = caps.peak_cap > 0 ? next_pow2((size_t)caps.peak_cap) : peak_worst;
+    if (ctx->peak_cap > peak_worst) ctx->peak_cap = peak_worst;
+    ctx->worst = ctx->run_cap == wc.run_cap && ctx->key_cap == wc.key_cap && ctx->slot_cap == wc.slot_cap &&
+                 ctx->list_cap == (size_t)wc.list_cap && ctx->peak_cap == peak_worst && ctx->min_rho <= 1.0;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) {
@@ -216,13 +282,6 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
         HIPCHK(hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    ctx->key_cap = (int)(N / 2 + 16);
-    ctx->slot_cap = (int)(2 * N + 4 * (size_t)max_h + 16);
-    int na, nr;
-    lfdmi_hough_dims(max_h, max_w, 1.0, LFD_PI / 180, &na, &nr);
-    ctx->acc_cap = (size_t)(na + 2) * (nr + 2);
-    ctx->peak_cap = next_pow2((size_t)na * nr);
-    ctx->list_cap = N;
     RET(dmalloc(ctx, &ctx->gray, G * N));
     RET(dmalloc(ctx, &ctx->tmp, G * N));
     RET(dmalloc(ctx, &ctx->equ, G * N));
@@ -233,7 +292,6 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     RET(dmalloc(ctx, &ctx->edgeb, G * BW));
     RET(dmalloc(ctx, &ctx->equb, G * BW));
     RET(dmalloc(ctx, &ctx->boxb, G * BW));
-    ctx->run_cap = max_h * (max_w / 2 + 1) + 16; // most runs a bit image can hold
     for (int **p : {&ctx->Lf, &ctx->YMf, &ctx->FLf, &ctx->Lb, &ctx->YMb, &ctx->FLb, &ctx->SBf, &ctx->SBb, &ctx->PAb,
                     &ctx->ROWf, &ctx->ROWb})
         RET(dmalloc(ctx, p, G * ctx->run_cap));
@@ -252,14 +310,13 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     RET(dmalloc(ctx, &ctx->wl_fg, G * BW));
     RET(dmalloc(ctx, &ctx->wl_bg, G * BW));
     RET(dmalloc(ctx, &ctx->rowext, G * ctx->slot_cap));
-    RET(dmalloc(ctx, &ctx->hullbuf, G * ctx->slot_cap * 2));
     RET(dmalloc(ctx, &ctx->quads, G * ctx->key_cap * 8));
     RET(dmalloc(ctx, &ctx->pix_equ, G * ctx->list_cap));
     RET(dmalloc(ctx, &ctx->pix_box, G * ctx->list_cap));
     RET(dmalloc(ctx, &ctx->accum, G * 2 * ctx->acc_cap));
     RET(dmalloc(ctx, &ctx->peaks, G * 2 * ctx->peak_cap));
     RET(dmalloc(ctx, &ctx->lines, G * 2 * LFDMI_MAX_SET_LINES * 2));
-    RET(dmalloc(ctx, &ctx->tab, (size_t)2 * MAX_ANGLES));
+    RET(dmalloc(ctx, &ctx->tab, (size_t)LFDMI_MAX_SCALES * 2 * MAX_ANGLES));
     {   // counters, histograms and the cell bitmap start every pass at zero: one block, one fill per pass
         size_t nb_cnt = G * C_COUNT * sizeof(int), nb_hist = G * 256 * sizeof(int), nb_bm = G * ctx->bm_bands * CELLBM_WORDS * sizeof(u64);
         uint8_t *blk = nullptr;
@@ -272,7 +329,7 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     }
     RET(dmalloc(ctx, &ctx->need_dim, G));
     RET(dmalloc(ctx, &ctx->pass_flags, G));
-    RET(dmalloc(ctx, &ctx->res_dev, G));
+    RET(dmalloc(ctx, &ctx->res_dev, G * LFDMI_MAX_SCALES));
     HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
@@ -291,12 +348,42 @@ extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflig
     return 0;
 }
 
+extern "C" int lfdmi_ctx_create(int device, int max_h, int max_w, int max_inflight, lfdmi_ctx **out) {
+    return create_impl(device, max_h, max_w, max_inflight, nullptr, out);
+}
+extern "C" int lfdmi_ctx_create_sized(int device, int max_h, int max_w, int max_inflight, const lfdmi_caps *caps, lfdmi_ctx **out) {
+    return create_impl(device, max_h, max_w, max_inflight, caps, out);
+}
+extern "C" int64_t lfdmi_ctx_bytes(lfdmi_ctx *ctx) { return ctx ? (int64_t)(ctx->bytes + (ctx->spill ? ctx->spill->bytes : 0)) : 0; }
+extern "C" int64_t lfdmi_spill_count(lfdmi_ctx *ctx) { return ctx ? ctx->n_spilled : 0; }
+
+// the worst-case single-frame workspace behind a compact context (nullptr: ctx is worst-case itself, or no memory)
+static lfdmi_ctx *get_spill(lfdmi_ctx *ctx) {
+    if (ctx->worst) return nullptr;
+    if (!ctx->spill) {
+        lfdmi_caps wc;
+        worst_caps(ctx->H, ctx->W, &wc);
+        lfdmi_ctx *sp = nullptr;
+        int rc = create_impl(ctx->device, ctx->H, ctx->W, 1, &wc, &sp);
+        if (rc) {
+            ctx->err = "worst-case workspace: " + (sp ? sp->err : std::string("creation failed"));
+            if (sp) lfdmi_ctx_destroy(sp);
+            return nullptr;
+        }
+        sp->timing = false;
+        ctx->spill = sp;
+    }
+    return ctx->spill;
+}
+
 extern "C" void lfdmi_ctx_destroy(lfdmi_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->spill) lfdmi_ctx_destroy(ctx->spill);
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (void *p : ctx->allocs) hipFree(p);
     if (ctx->stage) hipFree(ctx->stage);
+    if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->rs_boxes) hipFree(ctx->rs_boxes);
     if (ctx->cat_dev) hipFree(ctx->cat_dev);
     for (auto e : ctx->ev_pool) hipEventDestroy(e);
@@ -356,6 +443,15 @@ static int check_shape(lfdmi_ctx *ctx, int n, int h, int w) {
         return fail(ctx, LFDMI_ERR_CAPACITY, "frame larger than the context was created for");
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, LFDMI_ERR_HIP, "hipSetDevice");
     (void)hipGetLastError(); // a failed earlier call must not poison this one
+    ctx->last_h = h; ctx->last_w = w;
+    return 0;
+}
+
+static int ensure_scratch(lfdmi_ctx *ctx, size_t bytes) {
+    if (ctx->scratch_bytes >= bytes) return 0;
+    if (ctx->scratch) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+    HIPCHK(hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
     return 0;
 }
 
@@ -619,7 +715,7 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
         minLen, lwTresh, active);
     KCHK("k_rects_big");
     HIPCHK(hipEventRecord(ctx->ev_join[1], ctx->side[1]));
-    k_rects<<<dim3(32, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, ctx->hullbuf, ctx->quads, ctx->counters, h, w,
+    k_rects<<<dim3(32, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, nullptr, ctx->quads, ctx->counters, h, w,
                                                     ctx->key_cap, ctx->slot_cap, minLen, lwTresh, active);
     KCHK("k_rects");
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
@@ -631,26 +727,44 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     return 0;
 }
 
+// does this context's accumulator / peak storage hold HoughLines(rho, theta) on an h x w image?
+static bool hough_fits(const lfdmi_ctx *ctx, int h, int w, double rho_d, double theta_d) {
+    int na, nr;
+    lfdmi_hough_dims(h, w, rho_d, theta_d, &na, &nr);
+    return na > 0 && nr > 0 && na <= MAX_ANGLES && (size_t)(na + 2) * (nr + 2) <= ctx->acc_cap && (ctx->worst ? (size_t)na * nr <= ctx->peak_cap : true);
+}
+
 static int ensure_tables(lfdmi_ctx *ctx, int h, int w, double rho_d, double theta_d) {
-    if (ctx->tab_rho == rho_d && ctx->tab_theta == theta_d && ctx->tab_h == h && ctx->tab_w == w) return 0;
+    for (int i = 0; i < LFDMI_MAX_SCALES; i++) {
+        auto &t = ctx->tabs[i];
+        if (t.rho == rho_d && t.theta == theta_d && t.h == h && t.w == w) {
+            t.stamp = ++ctx->tab_clock;
+            ctx->tab_cur = i; ctx->numangle = t.numangle; ctx->numrho = t.numrho;
+            return 0;
+        }
+    }
     float rho = (float)rho_d, theta = (float)theta_d;
     if (!(rho > 0) || !(theta > 0)) return fail(ctx, LFDMI_ERR_ARG, "rho and theta must be positive");
     int na, nr;
     lfdmi_hough_dims(h, w, rho_d, theta_d, &na, &nr);
-    if (na <= 0 || nr <= 0 || na > MAX_ANGLES || (size_t)(na + 2) * (nr + 2) > ctx->acc_cap || (size_t)na * nr > ctx->peak_cap)
+    if (na <= 0 || nr <= 0 || na > MAX_ANGLES || (size_t)(na + 2) * (nr + 2) > ctx->acc_cap)
         return fail(ctx, LFDMI_ERR_CAPACITY, "Hough accumulator larger than the workspace (rho < 1 px or theta < 1 deg)");
-    std::vector<float> t((size_t)2 * na);
+    int slot = 0;
+    for (int i = 1; i < LFDMI_MAX_SCALES; i++) if (ctx->tabs[i].stamp < ctx->tabs[slot].stamp) slot = i; // least recently used
+    auto &t = ctx->tabs[slot];
+    // the upload below reads t.host asynchronously (pageable memory: staged before the call returns) and is ordered on
+    // the launch stream behind every kernel that still reads the entry's old table
+    t.host.assign((size_t)2 * na, 0.f);
     float irho = 1 / rho;
     float ang = 0.f;
     for (int n = 0; n < na; ang += theta, n++) { // createTrigTable: float accumulation of the angle
-        t[n] = (float)(cos((double)ang) * irho);
-        t[na + n] = (float)(sin((double)ang) * irho);
+        t.host[n] = (float)(cos((double)ang) * irho);
+        t.host[na + n] = (float)(sin((double)ang) * irho);
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemcpy(ctx->tab, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
-    ctx->tab_host = t;
-    ctx->tab_rho = rho_d; ctx->tab_theta = theta_d; ctx->tab_h = h; ctx->tab_w = w;
-    ctx->numangle = na; ctx->numrho = nr;
+    HIPCHK(hipMemcpyAsync(ctx->tab + (size_t)slot * 2 * MAX_ANGLES, t.host.data(), t.host.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    t.rho = rho_d; t.theta = theta_d; t.h = h; t.w = w; t.numangle = na; t.numrho = nr;
+    t.stamp = ++ctx->tab_clock;
+    ctx->tab_cur = slot; ctx->numangle = na; ctx->numrho = nr;
     return 0;
 }
 
@@ -660,12 +774,40 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
                      int need_detect, const int *active) {
     RET(ensure_tables(ctx, h, w, rho, theta));
     int na = ctx->numangle, nr = ctx->numrho;
-    // angles per workgroup: the largest power of two whose bin-major slab fits in LDS
-    int aw_log2 = 6;
-    while (aw_log2 > 0 && ((size_t)nr << aw_log2) * 4 + 256 > 152 * 1024) aw_log2--;
-    if (((size_t)nr << aw_log2) * 4 + 256 > 152 * 1024) return fail(ctx, LFDMI_ERR_CAPACITY, "numrho too large for LDS");
-    int AW = 1 << aw_log2;
-    int nslabs = (na + AW - 1) / AW;
+    // Angles per workgroup (AW, a power of two <= 64) and the accumulator rows each angle slab can reach:
+    // r = x c + y s over the image rectangle (+- 2 bins of slack).  The LDS slab of a workgroup holds only those rows,
+    // AW votes wide; the largest AW whose widest slab fits in LDS is used (SDSS, rho 20: 64 angles x <= 128 rows;
+    // 4096 x 4096, rho 5: 16 angles x ~1 160 rows).
+    const std::vector<float> &tab_host = ctx->tabs[ctx->tab_cur].host;
+    const int half = (nr - 1) / 2;
+    VoteRanges rng;
+    int aw_log2 = 6, nslabs = 1, nbmax = nr;
+    for (;; aw_log2--) {
+        int AW = 1 << aw_log2;
+        nslabs = (na + AW - 1) / AW;
+        nbmax = 1;
+        for (int sl = 0; sl < VOTE_MAX_SLABS; sl++) { rng.lo[sl] = -half; rng.hi[sl] = nr - 1 - half; }
+        if (nslabs <= VOTE_MAX_SLABS && (int)tab_host.size() == 2 * na) {
+            for (int sl = 0; sl < nslabs; sl++) {
+                double rmin = 0, rmax = 0;
+                for (int n = sl * AW; n < na && n < (sl + 1) * AW; n++) {
+                    double c = tab_host[n], sn = tab_host[na + n];
+                    for (int cx = 0; cx < 2; cx++)
+                        for (int cy = 0; cy < 2; cy++) {
+                            double r = (cx ? w : 0) * c + (cy ? h : 0) * sn;
+                            rmin = r < rmin ? r : rmin;
+                            rmax = r > rmax ? r : rmax;
+                        }
+                }
+                int lo = (int)floor(rmin) - 2, hi = (int)ceil(rmax) + 2;
+                rng.lo[sl] = lo < -half ? -half : lo;
+                rng.hi[sl] = hi > nr - 1 - half ? nr - 1 - half : hi;
+                nbmax = std::max(nbmax, rng.hi[sl] - rng.lo[sl] + 1);
+            }
+        } else nbmax = nr;
+        if (((size_t)nbmax << aw_log2) * 4 + 256 <= 152 * 1024 || aw_log2 == 0) break;
+    }
+    if (((size_t)nbmax << aw_log2) * 4 + 256 > 152 * 1024) return fail(ctx, LFDMI_ERR_CAPACITY, "numrho too large for LDS");
     dim3 wg = word_grid(h, w, nc);
     {
         // cut each pixel list into pieces so that a launch carries several workgroups per CU
@@ -682,33 +824,11 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         KCHK("k_pixlist"); }
         Span sp(ctx, KID_VOTE, need_detect);
         dim3 vgrid(nslabs * nsplit, n_img, nc);
-        // rows of the accumulator each angle slab can reach: r = x c + y s over the image rectangle (+- 2 bins of slack)
-        VoteRanges rng;
-        int half = (nr - 1) / 2, nbmax = 1;
-        for (int sl = 0; sl < VOTE_MAX_SLABS; sl++) { rng.lo[sl] = -half; rng.hi[sl] = nr - 1 - half; }
-        if (nslabs <= VOTE_MAX_SLABS && (int)ctx->tab_host.size() == 2 * na) {
-            for (int sl = 0; sl < nslabs; sl++) {
-                double rmin = 0, rmax = 0;
-                for (int n = sl * AW; n < na && n < (sl + 1) * AW; n++) {
-                    double c = ctx->tab_host[n], sn = ctx->tab_host[na + n];
-                    for (int cx = 0; cx < 2; cx++)
-                        for (int cy = 0; cy < 2; cy++) {
-                            double r = (cx ? w : 0) * c + (cy ? h : 0) * sn;
-                            rmin = r < rmin ? r : rmin;
-                            rmax = r > rmax ? r : rmax;
-                        }
-                }
-                int lo = (int)floor(rmin) - 2, hi = (int)ceil(rmax) + 2;
-                rng.lo[sl] = lo < -half ? -half : lo;
-                rng.hi[sl] = hi > nr - 1 - half ? nr - 1 - half : hi;
-            }
-        }
-        for (int sl = 0; sl < nslabs && sl < VOTE_MAX_SLABS; sl++) nbmax = std::max(nbmax, rng.hi[sl] - rng.lo[sl] + 1);
-        if (nslabs > VOTE_MAX_SLABS) nbmax = nr;
         size_t vlds = ((size_t)nbmax << aw_log2) * 4 + 256;
 #define LFD_LAUNCH_VOTE(L)                                                                                          \
     case L:                                                                                                         \
-        k_hough_vote<L><<<vgrid, VOTE_THREADS, vlds, ctx->stream>>>(ctx->pix_equ, ctx->pix_box, ctx->counters, ctx->tab, \
+        k_hough_vote<L><<<vgrid, VOTE_THREADS, vlds, ctx->stream>>>(ctx->pix_equ, ctx->pix_box, ctx->counters,           \
+                                                                   ctx->tab + (size_t)ctx->tab_cur * 2 * MAX_ANGLES, \
                                                                    ctx->accum, na, nr, nsplit, ctx->list_cap,       \
                                                                    ctx->acc_cap, active, need_detect, rng);         \
         break;
@@ -774,9 +894,10 @@ static int run_prep_erode(lfdmi_ctx *ctx, const void *src, int nc, int h, int w,
     return 0;
 }
 
-// one detection pass on nc images already resident at src (device): fills ctx->res_dev
-static int run_pass(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int prep_mode, bool dim,
-                    const lfdmi_params *p, const int *active, int *need_dim) {
+// One detection pass on nc images already resident at src (device).  Front end: mask .. fit_minAreaRect (counters,
+// bit rows, box image); tail: HoughLines on both images at one rho + check_theta -> res (device records of the slots).
+static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int prep_mode, bool dim,
+                     const lfdmi_params *p, const int *active) {
     HIPCHK(hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream)); // counters, histograms, cell bitmap
     const uint8_t *dil_src = ctx->gray;
     if (dim && can_fuse_prep_erode(ctx, dtype, w, p->erodeKernel, p->erode_kh, p->erode_kw)) {
@@ -797,15 +918,29 @@ static int run_pass(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, i
         RET(run_morph(ctx, dil_src, ctx->equ, ctx->equb, ctx->lut, p->dilateKernel, p->dilate_kh, p->dilate_kw, 0, nc, h, w, active));
         RET(run_canny(ctx, ctx->equ, nc, h, w, 0, 255, active));
     }
-    RET(run_rects(ctx, nc, h, w, p->contoursMode, p->contoursMethod, p->minAreaRectMinLen, p->lwTresh, active));
-    RET(run_hough(ctx, nc, h, w, p->houghMethod, LFD_PI / 180, 1, 2, p->nlinesInSet, 1, active));
+    return run_rects(ctx, nc, h, w, p->contoursMode, p->contoursMethod, p->minAreaRectMinLen, p->lwTresh, active);
+}
+
+static int run_tail(lfdmi_ctx *ctx, int nc, int h, int w, double rho, bool dim, const lfdmi_params *p, const int *active,
+                    int *need_dim, lfdmi_result *res, bool again) {
+    if (again) { // a further scale of the same front end
+        k_hough_reset<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->counters, nc);
+        KCHK("k_hough_reset");
+    }
+    RET(run_hough(ctx, nc, h, w, rho, LFD_PI / 180, 1, 2, p->nlinesInSet, 1, active));
     TailParams tp;
     tp.navg = p->nlinesInSet; tp.dro = p->dro; tp.thetaTresh = p->thetaTresh; tp.lineSetTresh = p->lineSetTresh;
     tp.which = dim ? 2 : 1;
     Span sp(ctx, KID_FINALIZE);
-    k_finalize<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->lines, ctx->counters, ctx->res_dev, need_dim, ctx->pass_flags, active, tp, nc);
+    k_finalize<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->lines, ctx->counters, res, need_dim, ctx->pass_flags, active, tp, nc);
     KCHK("k_finalize");
     return 0;
+}
+
+static int run_pass(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int prep_mode, bool dim,
+                    const lfdmi_params *p, const int *active, int *need_dim) {
+    RET(run_front(ctx, src, dtype, nc, h, w, flip, prep_mode, dim, p, active));
+    return run_tail(ctx, nc, h, w, p->houghMethod, dim, p, active, need_dim, ctx->res_dev, false);
 }
 
 static void dictify(int h, int w, lfdmi_result *r) { // processfield.py:266-288, float32 scalars
@@ -892,6 +1027,7 @@ extern "C" int lfdmi_canny(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int
     RET(check_shape(ctx, n, h, w));
     if (!src || !dst) return fail(ctx, LFDMI_ERR_ARG, "NULL image");
     size_t N = (size_t)h * w;
+    std::vector<int> cnt((size_t)ctx->G * C_COUNT);
     for (int c0 = 0; c0 < n; c0 += ctx->G) {
         int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
         const void *d;
@@ -900,7 +1036,16 @@ extern "C" int lfdmi_canny(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int
         RET(run_canny(ctx, (const uint8_t *)d, nc, h, w, low, high, nullptr));
         RET(expand_bits(ctx, ctx->edgeb, ctx->tmp, nc, h, w));
         RET(out_copy(ctx, dst, (size_t)c0 * N, ctx->tmp, (size_t)nc * N, loc));
+        HIPCHK(hipMemcpyAsync(cnt.data(), ctx->counters, (size_t)nc * C_COUNT * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         RET(sync(ctx, nc));
+        for (int i = 0; i < nc; i++)
+            if (cnt[(size_t)i * C_COUNT + C_OVERFLOW]) { // more runs than this workspace's tables hold: the worst-case one takes the image
+                lfdmi_ctx *sp = get_spill(ctx);
+                if (!sp) return fail(ctx, LFDMI_ERR_CAPACITY, "run tables too small for this image");
+                int rc = lfdmi_canny(sp, src + (size_t)(c0 + i) * N, 1, h, w, low, high, dst + (size_t)(c0 + i) * N, loc);
+                if (rc) { ctx->err = sp->err; return rc; }
+                ctx->n_spilled++;
+            }
     }
     return 0;
 }
@@ -926,7 +1071,16 @@ extern "C" int lfdmi_fit_min_area_rect(lfdmi_ctx *ctx, const uint8_t *img, int n
         HIPCHK(hipMemcpyAsync(cnt.data(), ctx->counters, (size_t)nc * C_COUNT * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         RET(sync(ctx, nc));
         for (int i = 0; i < nc; i++) {
-            if (cnt[(size_t)i * C_COUNT + C_OVERFLOW]) return fail(ctx, LFDMI_ERR_CAPACITY, "contour workspace overflow");
+            if (cnt[(size_t)i * C_COUNT + C_OVERFLOW]) { // a table of this workspace is too small for the image: the worst-case one takes it
+                lfdmi_ctx *sp = get_spill(ctx);
+                if (!sp) return fail(ctx, LFDMI_ERR_CAPACITY, "contour workspace overflow");
+                int rc = lfdmi_fit_min_area_rect(sp, img + (size_t)(c0 + i) * N, 1, h, w, contoursMode, contoursMethod, minAreaRectMinLen, lwTresh,
+                                                 box_img ? box_img + (size_t)(c0 + i) * N : nullptr, detection ? detection + c0 + i : nullptr,
+                                                 n_boxes ? n_boxes + c0 + i : nullptr, loc);
+                if (rc) { ctx->err = sp->err; return rc; }
+                ctx->n_spilled++;
+                continue;
+            }
             int det = cnt[(size_t)i * C_COUNT + C_DETECT], nb = cnt[(size_t)i * C_COUNT + C_NQUADS];
             if (loc == LFDMI_DEVICE) {
                 if (detection) HIPCHK(hipMemcpy(detection + c0 + i, &det, 4, hipMemcpyHostToDevice));
@@ -944,18 +1098,23 @@ static int hough_api(lfdmi_ctx *ctx, const uint8_t *img, int n, int h, int w, do
                      int max_lines, float *lines, int32_t *n_lines, int32_t *accum, int loc) {
     RET(check_shape(ctx, n, h, w));
     if (!img) return fail(ctx, LFDMI_ERR_ARG, "NULL image");
+    if (!hough_fits(ctx, h, w, rho, theta) && !ctx->worst) { // finer than this workspace's accumulators: the worst-case one takes the call
+        lfdmi_ctx *sp = get_spill(ctx);
+        if (!sp) return fail(ctx, LFDMI_ERR_CAPACITY, "Hough accumulator larger than the workspace");
+        int rc = hough_api(sp, img, n, h, w, rho, theta, threshold, max_lines, lines, n_lines, accum, loc);
+        if (rc) ctx->err = sp->err;
+        return rc;
+    }
     RET(ensure_tables(ctx, h, w, rho, theta));
     size_t N = (size_t)h * w;
     int na = ctx->numangle, nr = ctx->numrho;
     size_t acc_n = (size_t)(na + 2) * (nr + 2);
     std::vector<int> cnt((size_t)ctx->G * C_COUNT);
     float *lines_dev = nullptr;
-    if (lines && max_lines > 0) {
-        // device scratch for sorted lines: reuse the hull buffer (unused by this entry point)
-        if ((size_t)ctx->G * max_lines * 2 * sizeof(float) > (size_t)ctx->G * ctx->slot_cap * 2 * sizeof(int2))
-            return fail(ctx, LFDMI_ERR_CAPACITY, "max_lines too large");
-        lines_dev = (float *)ctx->hullbuf;
-    }
+    size_t lines_bytes = (lines && max_lines > 0) ? (size_t)ctx->G * max_lines * 2 * sizeof(float) : 0;
+    size_t acc_bytes = accum ? (size_t)ctx->G * acc_n * sizeof(int) : 0;
+    if (lines_bytes + acc_bytes) RET(ensure_scratch(ctx, lines_bytes + acc_bytes)); // sorted lines | untransposed accumulators
+    if (lines_bytes) lines_dev = (float *)ctx->scratch;
     for (int c0 = 0; c0 < n; c0 += ctx->G) {
         int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
         const void *d;
@@ -965,7 +1124,7 @@ static int hough_api(lfdmi_ctx *ctx, const uint8_t *img, int n, int h, int w, do
         KCHK("k_bits_from_u8");
         RET(run_hough(ctx, nc, h, w, rho, theta, threshold, 1, 0, 0, nullptr));
         if (accum) {
-            int *tmp_acc = (int *)ctx->hullbuf; // scratch unused by this entry point
+            int *tmp_acc = (int *)((char *)ctx->scratch + lines_bytes);
             k_accum_untranspose<<<dim3(64, nc), 256, 0, ctx->stream>>>(ctx->accum, tmp_acc, na, nr, ctx->acc_cap);
             KCHK("k_accum_untranspose");
             RET(out_copy(ctx, accum, (size_t)c0 * acc_n * 4, tmp_acc, (size_t)nc * acc_n * 4, loc));
@@ -979,6 +1138,16 @@ static int hough_api(lfdmi_ctx *ctx, const uint8_t *img, int n, int h, int w, do
         HIPCHK(hipMemcpyAsync(cnt.data(), ctx->counters, (size_t)nc * C_COUNT * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         RET(sync(ctx, nc));
         for (int i = 0; i < nc; i++) {
+            if (cnt[(size_t)i * C_COUNT + C_OVERFLOW]) { // chunk list or peak list too small for this image: the worst-case workspace takes it
+                lfdmi_ctx *sp = get_spill(ctx);
+                if (!sp) return fail(ctx, LFDMI_ERR_CAPACITY, "Hough lists too small for this image");
+                int rc = hough_api(sp, img + (size_t)(c0 + i) * N, 1, h, w, rho, theta, threshold, max_lines,
+                                   lines ? lines + (size_t)(c0 + i) * max_lines * 2 : nullptr, n_lines ? n_lines + c0 + i : nullptr,
+                                   accum ? accum + (size_t)(c0 + i) * acc_n : nullptr, loc);
+                if (rc) { ctx->err = sp->err; return rc; }
+                ctx->n_spilled++;
+                continue;
+            }
             int total = cnt[(size_t)i * C_COUNT + C_NPEAK_EQU];
             if (n_lines) {
                 if (loc == LFDMI_DEVICE) HIPCHK(hipMemcpy(n_lines + c0 + i, &total, 4, hipMemcpyHostToDevice));
@@ -1111,32 +1280,53 @@ extern "C" int lfdmi_remove_stars(lfdmi_ctx *ctx, float *img, int n, int h, int 
 // ---- C-ABI: whole passes ------------------------------------------------------------------
 // Whole-pass entry points launch the general run kernels only once the context has met a frame the per-frame
 // LDS kernels could not take; a chunk that meets the first such frame is run again with them.
+#define GENERAL_QUIET_CHUNKS 8
 struct GeneralGuard {
     lfdmi_ctx *c;
     explicit GeneralGuard(lfdmi_ctx *ctx) : c(ctx) { c->general_on = !c->frame_ccl || c->general_seen; }
     ~GeneralGuard() { c->general_on = true; }
     bool again(const int *flags, int n) {
-        if (c->general_on) return false;
         bool need = false;
         for (int i = 0; i < n; i++) need = need || (flags[i] & PASS_FLAG_GENERAL);
+        if (c->general_on) {
+            // the ~22 extra launches per pass are dropped again once GENERAL_QUIET_CHUNKS chunks in a row did without them
+            if (need) c->quiet_chunks = 0;
+            else if (c->frame_ccl && ++c->quiet_chunks >= GENERAL_QUIET_CHUNKS) { c->general_seen = false; c->quiet_chunks = 0; }
+            return false;
+        }
         if (!need) return false;
         c->general_seen = true;
         c->general_on = true;
+        c->quiet_chunks = 0;
         return true;
     }
 };
 
+// results[s * rstride + i]: frame i at Hough scale s (rhos == nullptr: one scale, p->houghMethod)
 static int pass_api(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, int w, int flip, int prep_mode, bool dim,
-                    const lfdmi_params *p, lfdmi_result *results, float *lines_equ, float *lines_box, int loc) {
+                    const lfdmi_params *p, int n_scales, const double *rhos, lfdmi_result *results, size_t rstride, float *lines_equ,
+                    float *lines_box, int loc) {
     RET(check_shape(ctx, n, h, w));
     RET(check_params(ctx, p, dim));
     if (!img || !results || dtype < 0 || dtype > 2) return fail(ctx, LFDMI_ERR_ARG, "bad argument");
+    if (n_scales < 1 || n_scales > LFDMI_MAX_SCALES) return fail(ctx, LFDMI_ERR_ARG, "n_scales out of range");
     if (dtype == LFDMI_U8 && dim) return fail(ctx, LFDMI_ERR_DTYPE, "dim pass needs a float image (numpy refuses uint8 += float)");
+    const double rho1 = p->houghMethod;
+    if (!rhos) rhos = &rho1;
+    for (int s = 0; s < n_scales; s++)
+        if (!hough_fits(ctx, h, w, rhos[s], LFD_PI / 180)) { // finer than this workspace's accumulators: the worst-case one takes the call
+            lfdmi_ctx *sp = get_spill(ctx);
+            if (!sp || !hough_fits(sp, h, w, rhos[s], LFD_PI / 180)) return fail(ctx, LFDMI_ERR_CAPACITY, "Hough accumulator larger than the workspace (rho < 1 px)");
+            int rc = pass_api(sp, img, dtype, n, h, w, flip, prep_mode, dim, p, n_scales, rhos, results, rstride, lines_equ, lines_box, loc);
+            if (rc) ctx->err = sp->err;
+            return rc;
+        }
     size_t N = (size_t)h * w, es = dtype_size(dtype);
     int K = p->nlinesInSet;
-    std::vector<lfdmi_result> host((size_t)ctx->G);
-    std::vector<float> hl((size_t)ctx->G * 2 * K * 2);
-    std::vector<int> flags((size_t)ctx->G);
+    const size_t G = (size_t)ctx->G;
+    std::vector<lfdmi_result> host(G * n_scales);
+    std::vector<float> hl(G * 2 * K * 2);
+    std::vector<int> flags(G);
     ctx->cur_pass = 0;
     for (int c0 = 0; c0 < n; c0 += ctx->G) {
         int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
@@ -1144,10 +1334,15 @@ static int pass_api(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, in
         RET(in_ptr(ctx, img, (size_t)c0 * N * es, (size_t)nc * N * es, loc, &d));
         GeneralGuard gg(ctx);
         for (;;) { // (again, with the general run kernels, if a frame turned out to need them)
-            k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, ctx->pass_flags, nc);
-            KCHK("k_init_results");
-            RET(run_pass(ctx, d, dtype, nc, h, w, flip, prep_mode, dim, p, nullptr, nullptr));
-            HIPCHK(hipMemcpyAsync(host.data(), ctx->res_dev, (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
+            for (int s = 0; s < n_scales; s++) {
+                k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev + s * G, ctx->pass_flags, nc);
+                KCHK("k_init_results");
+            }
+            RET(run_front(ctx, d, dtype, nc, h, w, flip, prep_mode, dim, p, nullptr));
+            for (int s = 0; s < n_scales; s++) {
+                RET(run_tail(ctx, nc, h, w, rhos[s], dim, p, nullptr, nullptr, ctx->res_dev + s * G, s > 0));
+                HIPCHK(hipMemcpyAsync(host.data() + s * G, ctx->res_dev + s * G, (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
+            }
             HIPCHK(hipMemcpyAsync(hl.data(), ctx->lines, (size_t)nc * 2 * K * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipMemcpyAsync(flags.data(), ctx->pass_flags, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1159,9 +1354,27 @@ static int pass_api(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, in
             RET(sync(ctx, nc, na, nd));
         }
         for (int i = 0; i < nc; i++) {
-            dictify(h, w, &host[i]);
-            results[c0 + i] = host[i];
-            bool have = host[i].detection && host[i].status == 0;
+            bool spill = false;
+            for (int s = 0; s < n_scales; s++) spill = spill || host[s * G + i].status == LFDMI_ERR_CAPACITY;
+            if (spill) { // a table of this workspace was too small for the frame: once more, alone, in the worst-case workspace
+                lfdmi_ctx *sp = get_spill(ctx);
+                if (sp) {
+                    lfdmi_result one[LFDMI_MAX_SCALES];
+                    int rc = pass_api(sp, (const char *)img + (size_t)(c0 + i) * N * es, dtype, 1, h, w, flip, prep_mode, dim, p, n_scales, rhos,
+                                      one, 1, lines_equ ? lines_equ + (size_t)(c0 + i) * 2 * K : nullptr,
+                                      lines_box ? lines_box + (size_t)(c0 + i) * 2 * K : nullptr, loc);
+                    if (rc) { ctx->err = sp->err; return rc; }
+                    for (int s = 0; s < n_scales; s++) results[s * rstride + c0 + i] = one[s];
+                    ctx->n_spilled++;
+                    continue;
+                }
+            }
+            for (int s = 0; s < n_scales; s++) {
+                dictify(h, w, &host[s * G + i]);
+                results[s * rstride + c0 + i] = host[s * G + i];
+            }
+            const lfdmi_result &last = host[(size_t)(n_scales - 1) * G + i]; // (the lines of the last scale are the ones still in the workspace)
+            bool have = last.detection && last.status == 0;
             for (int s = 0; s < 2; s++) {
                 float *dst = s ? lines_box : lines_equ;
                 if (!dst) continue;
@@ -1174,13 +1387,20 @@ static int pass_api(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, in
 
 extern "C" int lfdmi_process_bright(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, int w, int flip,
                                     const lfdmi_params *p, lfdmi_result *results, float *lines_equ, float *lines_box, int loc) {
-    return pass_api(ctx, img, dtype, n, h, w, flip, LFDMI_PREP_BRIGHT, false, p, results, lines_equ, lines_box, loc);
+    return pass_api(ctx, img, dtype, n, h, w, flip, LFDMI_PREP_BRIGHT, false, p, 1, nullptr, results, (size_t)n, lines_equ, lines_box, loc);
 }
 
 extern "C" int lfdmi_process_dim(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, int w, int flip, int after_bright,
                                  const lfdmi_params *p, lfdmi_result *results, float *lines_equ, float *lines_box, int loc) {
-    return pass_api(ctx, img, dtype, n, h, w, flip, after_bright ? LFDMI_PREP_BRIGHT_THEN_DIM : LFDMI_PREP_DIM, true, p, results,
-                    lines_equ, lines_box, loc);
+    return pass_api(ctx, img, dtype, n, h, w, flip, after_bright ? LFDMI_PREP_BRIGHT_THEN_DIM : LFDMI_PREP_DIM, true, p, 1, nullptr, results,
+                    (size_t)n, lines_equ, lines_box, loc);
+}
+
+extern "C" int lfdmi_process_multiscale(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, int w, int flip, int dim, int after_bright,
+                                        const lfdmi_params *p, int n_scales, const double *rhos, lfdmi_result *results, int loc) {
+    if (!rhos) return fail(ctx, LFDMI_ERR_ARG, "rhos NULL");
+    int mode = dim ? (after_bright ? LFDMI_PREP_BRIGHT_THEN_DIM : LFDMI_PREP_DIM) : LFDMI_PREP_BRIGHT;
+    return pass_api(ctx, img, dtype, n, h, w, flip, mode, dim != 0, p, n_scales, rhos, results, (size_t)n, nullptr, nullptr, loc);
 }
 
 extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w, const lfdmi_catalog *cat,
@@ -1190,6 +1410,14 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
     RET(check_params(ctx, bright, false));
     RET(check_params(ctx, dim, true));
     if (!frames || !results) return fail(ctx, LFDMI_ERR_ARG, "NULL argument");
+    if (!hough_fits(ctx, h, w, bright->houghMethod, LFD_PI / 180) || !hough_fits(ctx, h, w, dim->houghMethod, LFD_PI / 180)) {
+        lfdmi_ctx *sp = get_spill(ctx); // rho finer than this workspace's accumulators: the worst-case one takes the call
+        if (!sp || !hough_fits(sp, h, w, bright->houghMethod, LFD_PI / 180) || !hough_fits(sp, h, w, dim->houghMethod, LFD_PI / 180))
+            return fail(ctx, LFDMI_ERR_CAPACITY, "Hough accumulator larger than the workspace (rho < 1 px)");
+        int rc = lfdmi_detect_batch(sp, frames, n, h, w, cat, rs, bright, dim, results, loc);
+        if (rc) ctx->err = sp->err;
+        return rc;
+    }
     size_t N = (size_t)h * w;
     std::vector<lfdmi_result> host((size_t)ctx->G);
     std::vector<int> flags((size_t)ctx->G);
@@ -1231,6 +1459,17 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
             RET(sync(ctx, nc, na, nd));
         }
         for (int i = 0; i < nc; i++) {
+            if (host[i].status == LFDMI_ERR_CAPACITY) {
+                // a table of this workspace was too small for the frame: once more, alone, in the worst-case workspace.
+                // remove_stars has already blotted the frame (device copy and, by now, the caller's array): no catalogue.
+                lfdmi_ctx *sp = get_spill(ctx);
+                if (sp) {
+                    int rc = lfdmi_detect_batch(sp, frames + (size_t)(c0 + i) * N, 1, h, w, nullptr, nullptr, bright, dim, &results[c0 + i], loc);
+                    if (rc) { ctx->err = sp->err; return rc; }
+                    ctx->n_spilled++;
+                    continue;
+                }
+            }
             dictify(h, w, &host[i]);
             results[c0 + i] = host[i];
         }
@@ -1255,19 +1494,21 @@ extern "C" int lfdmi_debug_frame_profile(lfdmi_ctx *ctx, int n, long long *dst) 
     return 0;
 }
 
-extern "C" int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, uint8_t *dst, int loc) {
+extern "C" int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, int h, int w, uint8_t *dst, int loc) {
     if (!ctx || !dst || slot < 0 || slot >= ctx->G) return LFDMI_ERR_ARG;
-    if (ctx->tab_h <= 0) return fail(ctx, LFDMI_ERR_ARG, "no pass has run yet");
-    int h = ctx->tab_h, w = ctx->tab_w;
+    if (ctx->last_h <= 0) return fail(ctx, LFDMI_ERR_ARG, "no call has run yet");
+    if (h != ctx->last_h || w != ctx->last_w) return fail(ctx, LFDMI_ERR_ARG, "lfdmi_get_stage: the last call worked on a different shape");
     size_t N = (size_t)h * w, BW = (size_t)h * LFD_WQ(w);
     HIPCHK(hipSetDevice(ctx->device));
     const uint8_t *src = nullptr;
     if (which == LFDMI_STAGE_GRAY) src = ctx->gray + slot * N;
     else if (which == LFDMI_STAGE_EQU) src = ctx->equ + slot * N;
+    else if (which == LFDMI_STAGE_ERODED) src = ctx->tmp + slot * N;
     else if (which == LFDMI_STAGE_CANNY || which == LFDMI_STAGE_BOX) {
         const u64 *bits = (which == LFDMI_STAGE_CANNY ? ctx->edgeb : ctx->boxb) + slot * BW;
-        RET(expand_bits(ctx, bits, ctx->tmp, 1, h, w));
-        src = ctx->tmp;
+        RET(ensure_scratch(ctx, N));
+        RET(expand_bits(ctx, bits, (uint8_t *)ctx->scratch, 1, h, w));
+        src = (const uint8_t *)ctx->scratch;
     } else return fail(ctx, LFDMI_ERR_ARG, "unknown stage");
     RET(out_copy(ctx, dst, 0, src, N, loc));
     return sync(ctx, 1);

@@ -169,3 +169,90 @@ def make_portable_frame(k, shape=(512, 768), n_star=40, with_catalog=True):
         mag[::9, int(k) % 5] = -9999.0
         cat = {"ROWC": rowc, "COLC": colc, "PSFMAG": mag, "PETROTH90": pet, "NOBSERVE": nob, "NDETECT": nde}
     return img, cat, truth
+
+
+# ---- many frames at once (bench.py, tools/) -------------------------------------------------------
+_TOOL_ENV = ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_LIBRARY")
+
+
+def _worker_main(argv):
+    """``python -m lfd_amd.synth <shared file> <n> <h> <w> <i0> <k_first> <count> <with_catalog>``: fills rows
+    i0 .. i0+count-1 of the shared [n, h, w] float32 array with frames k_first .., pickles the catalogues to stdout."""
+    import pickle
+    import sys
+    name, n, h, w, i0, k_first, count, with_cat = argv[0], *[int(x) for x in argv[1:8]]
+    out = np.memmap(name, np.float32, "r+", shape=(n, h, w))
+    cats = []
+    for j in range(count):
+        img, cat, _ = make_frame(k_first + j, (h, w), with_catalog=bool(with_cat))
+        out[i0 + j] = img
+        cats.append(cat)
+    out.flush()
+    del out
+    sys.stdout.buffer.write(pickle.dumps(cats))
+    sys.stdout.buffer.flush()
+
+
+def make_frames(k0, n, shape=SDSS_SHAPE, workers=None, with_catalog=True):
+    """Frames k0 .. k0+n-1 as one float32 array [n, h, w] plus their catalogues, generated by ``workers`` child
+    processes that write into shared memory.
+
+    The workers are separate ``python -m lfd_amd.synth`` programs started as child processes, never forked copies of
+    the caller: the caller may already have initialised the GPU -- under rocprofv3 the profiler's preloaded tool
+    library does that before ``main`` runs -- and a forked copy of such a process can hang.  The tool-library
+    variables are removed from the children's environment and the GPU is hidden from them, so they neither load the
+    profiler nor touch the card.
+    """
+    import os
+    import pickle
+    import subprocess
+    import sys
+    h, w = shape
+    workers = workers or min(16, os.cpu_count() or 1)
+    workers = max(1, min(workers, n // 2))
+    if workers <= 1:
+        out = np.empty((n, h, w), np.float32)
+        cats = []
+        for i in range(n):
+            img, cat, _ = make_frame(k0 + i, shape, with_catalog=with_catalog)
+            out[i] = img
+            cats.append(cat)
+        return out, cats
+    import tempfile
+    env = {k: v for k, v in os.environ.items()
+           if k not in _TOOL_ENV and not k.startswith("ROCPROF") and not k.startswith("ROCTX")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["ROCR_VISIBLE_DEVICES"] = ""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    # a file in /dev/shm (memory backed) that parent and children map; removed before returning
+    shm_dir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    fd, path = tempfile.mkstemp(prefix="lfd_synth_", suffix=".f32", dir=shm_dir)
+    procs = []
+    try:
+        os.ftruncate(fd, n * h * w * 4)
+        os.close(fd)
+        for r in range(workers):
+            a, b = n * r // workers, n * (r + 1) // workers
+            if b > a:
+                cmd = [sys.executable, "-m", "lfd_amd.synth", path, str(n), str(h), str(w), str(a), str(k0 + a),
+                       str(b - a), str(int(with_catalog))]
+                procs.append((a, b, subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, cwd=root)))
+        cats = [None] * n
+        for a, b, p in procs:
+            blob, _ = p.communicate()
+            if p.returncode:
+                raise RuntimeError(f"frame generator worker failed with exit code {p.returncode}")
+            cats[a:b] = pickle.loads(blob)
+        out = np.fromfile(path, np.float32).reshape(n, h, w)
+    finally:
+        for _, _, p in procs:
+            if p.poll() is None:
+                p.kill()
+        os.unlink(path)
+    return out, cats
+
+
+if __name__ == "__main__":
+    import sys
+    _worker_main(sys.argv[1:])

@@ -744,7 +744,7 @@ int lfo_hough_accum(const uint8_t *img, int h, int w, double rho_d, double theta
     return 0;
 }
 
-static const int32_t *g_sort_accum;
+static __thread const int32_t *g_sort_accum; /* thread-local: bench.py and the tests call the oracle from several threads */
 static int cmp_hough(const void *a, const void *b) {
     int l1 = *(const int32_t *)a, l2 = *(const int32_t *)b;
     if (g_sort_accum[l1] != g_sort_accum[l2]) return g_sort_accum[l1] > g_sort_accum[l2] ? -1 : 1;

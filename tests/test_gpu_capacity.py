@@ -1,0 +1,144 @@
+"""Workspace sizing (include/lfdmi.h: lfdmi_caps), the worst-case spill path, and BASELINE configs[4] at batch:
+4096x4096 float32 frames through the dim pass with a 9x9 erosion and HoughLines at rho 20 / 10 / 5, against the oracle."""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def params():
+    from lfd_amd.detecttrails import default_params
+    return default_params()
+
+
+def same(rec_gpu, rec_oracle):
+    return all(rec_gpu[k].item() == v for k, v in rec_oracle.items())
+
+
+def test_lsst_batch_multiscale_vs_oracle(oracle):
+    """configs[4]: 8 LSST-size frames in ONE launch sequence of a compact 8-slot workspace; every record at every
+    Hough scale equals the oracle's process_dim with houghMethod = rho (reference call sites: processfield.py:453-506;
+    the reference always uses one rho, so the multi-scale part is GPU == oracle self-consistency)."""
+    import torch
+    from lfd_amd import _native, synth
+    _, pd, _ = params()
+    pd = dict(pd, erodeKernel=np.ones((9, 9), np.uint8))
+    rhos = [20.0, 10.0, 5.0]
+    n = 8
+    frames, _ = synth.make_frames(0, n, synth.LSST_SHAPE, with_catalog=False)
+
+    def cpu(job):
+        i, rho = job
+        return oracle.process_dim(frames[i].copy(), dict(pd, houghMethod=rho), flip=True)
+
+    jobs = [(i, r) for i in range(n) for r in rhos]
+    with ThreadPoolExecutor(12) as ex:
+        want = dict(zip(jobs, ex.map(cpu, jobs)))
+    with _native.Context(0, 4096, 4096, n) as ctx:
+        assert ctx.workspace_bytes() < n * 260e6                    # ~7.9 B/px of tables + fixed Hough storage per slot
+        res = ctx.process_multiscale(frames, pd, rhos, dim=True, flip=True)          # host frames, staged by the library
+        d = torch.from_numpy(frames).cuda()
+        torch.cuda.synchronize()
+        res_d = ctx.process_multiscale(d, pd, rhos, dim=True, flip=True)             # device-resident, used in place
+        assert res.tobytes() == res_d.tobytes()
+        assert ctx.spill_count() == 0                               # sky frames stay inside the default capacities
+        runs = ctx.get_counters(0, n)[:, 12]
+        assert runs.max() <= 32768, runs                            # ... and on the per-frame LDS kernels
+        one = ctx.process_dim(frames[:2], dict(pd, houghMethod=10.0), flip=True)[0]   # the single-scale entry point agrees
+        assert one.tobytes() == res[1, :2].tobytes()
+    found = set()
+    for s, rho in enumerate(rhos):
+        for i in range(n):
+            assert same(res[s, i], want[(i, rho)]), (rho, i, want[(i, rho)], res[s, i])
+            found.add(want[(i, rho)]["found"])
+    assert found == {0, 2}                                          # bright streaks survive a 9x9 erosion, dim ones do not
+
+
+def test_tiny_capacities_spill_to_the_worst_case_workspace(oracle):
+    """A workspace whose tables are far too small for the frames: every overflow (run tables, contour keys, row slots,
+    Hough chunk lists, peak lists) is flagged on the device before any table is indexed past its end, and the frame is
+    run again through the worst-case workspace: records equal those of a default context and of the oracle."""
+    from lfd_amd import _native, synth
+    pb, pd, prs = params()
+    kw = {k: v for k, v in prs.items() if k != "debug"}
+    rs_g, rs_o = _native.make_rs_params("r", **kw), oracle.rs_params("r", **kw)
+    frames, cats = zip(*[synth.make_frame(k)[:2] for k in range(6)])
+    batch = np.stack(frames)
+    packed = synth.pack_catalogs(list(cats))
+    with _native.Context(0, 1489, 2048, 6) as ref_ctx:
+        ref = ref_ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g)
+        assert ref_ctx.spill_count() == 0
+    for caps in ({"run_cap": 3000}, {"key_cap": 64}, {"slot_cap": 2000}, {"list_cap": 1500}, {"peak_cap": 256},
+                 {"run_cap": 3000, "key_cap": 64, "slot_cap": 2000, "list_cap": 1500, "peak_cap": 256}):
+        with _native.Context(0, 1489, 2048, 6, caps=caps) as ctx:
+            res = ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g)
+            assert res.tobytes() == ref.tobytes(), caps
+            assert ctx.spill_count() > 0, caps
+            # per-pass entry points and the host-frame path take the same route
+            rb, _, _ = ctx.process_bright(np.ascontiguousarray(batch[:2, ::-1]), pb)
+            for i in range(2):
+                assert same(rb[i], oracle.process_bright(np.ascontiguousarray(batch[i, ::-1]), pb)), caps
+    for i in (0, 1):
+        assert same(ref[i], oracle.detect_frame(frames[i].copy(), pb, pd, cats[i], rs_o))
+    with _native.Context(0, 1489, 2048, 2, caps="worst") as ctx:        # every table at its theoretical maximum: never spills
+        res = ctx.detect_batch(batch[:2].copy(), pb, pd, {k: v[:2] for k, v in packed.items()}, rs_g)
+        assert res.tobytes() == ref[:2].tobytes() and ctx.spill_count() == 0
+
+
+def test_operator_entry_points_spill_too(oracle):
+    """Canny / fit_minAreaRect / HoughLines on a dense random image through a workspace with tiny tables."""
+    from lfd_amd import _native
+    rng = np.random.default_rng(5)
+    img = (rng.random((300, 400)) < 0.5).astype(np.uint8) * 255
+    smooth = rng.integers(0, 256, (300, 400), dtype=np.uint8)
+    with _native.Context(0, 300, 400, 2, caps={"run_cap": 500, "key_cap": 50, "slot_cap": 500, "list_cap": 300, "peak_cap": 64}) as ctx:
+        assert np.array_equal(ctx.canny(smooth, 50, 150), oracle.canny(smooth, 50, 150))
+        det, box, nb = ctx.fit_min_area_rect(smooth)
+        det_o, box_o, nb_o = oracle.fit_min_area_rect(smooth)
+        assert det == det_o and nb == nb_o and np.array_equal(box, box_o)
+        lines, n = ctx.hough_lines(img, 20, max_lines=50)
+        lines_o, n_o = oracle.hough_lines(img, 20, max_lines=50)
+        assert n == n_o and np.array_equal(lines, lines_o)
+        assert np.array_equal(ctx.hough_accum(img, 7.5), oracle.hough_accum(img, 7.5))
+        assert ctx.spill_count() >= 4
+
+
+def test_rho_finer_than_the_workspace_was_sized_for(oracle):
+    """houghMethod = 2 with accumulators sized for rho >= 5 (the default): the call runs through the worst-case workspace."""
+    from lfd_amd import _native, synth
+    pb, pd, _ = params()
+    img = synth.make_frame(0, with_catalog=False)[0][::-1].copy()
+    with _native.Context(0, 1489, 2048, 2) as ctx:
+        p = dict(pb, houghMethod=2, dro=40)
+        res, _, _ = ctx.process_bright(img, p)
+        assert same(res, oracle.process_bright(img, p))
+        both = ctx.detect_batch(img[::-1].copy()[None], p, dict(pd, houghMethod=3))[0]
+        assert same(both, oracle.detect_frame(img[::-1].copy(), p, dict(pd, houghMethod=3)))
+
+
+def test_get_stage_checks_the_shape_of_the_last_call():
+    from lfd_amd import _native
+    with _native.Context(0, 256, 256, 1) as ctx:
+        with pytest.raises(_native.NativeError):
+            ctx.get_stage(0, _native.STAGE_EQU, 256, 256)            # nothing has run yet
+        a = np.zeros((64, 128), np.uint8)
+        a[20:30, 40:90] = 200
+        ctx.dilate(a, np.ones((3, 3), np.uint8))
+        with pytest.raises(_native.NativeError):
+            ctx.get_stage(0, _native.STAGE_EQU, 256, 256)            # the last call worked on 64 x 128
+        out = ctx.get_stage(0, _native.STAGE_EQU, 64, 128)
+        assert out.shape == (64, 128) and out[25, 60] == 200
+
+
+def test_default_workspace_sizes_for_the_baseline_batches():
+    """Bytes per in-flight frame of the default capacities: 256 SDSS frames and 256 LSST-size frames
+    both fit one GPU with room to spare (the theoretical-maximum layout took ~95 GB and ~470 GB)."""
+    from lfd_amd import _native
+    with _native.Context(0, 1489, 2048, 256) as ctx:
+        b = ctx.workspace_bytes()
+        assert b < 256 * 32e6, b
+    with _native.Context(0, 4096, 4096, 256) as ctx:
+        b = ctx.workspace_bytes()
+        assert b < 256 * 170e6, b

@@ -266,10 +266,12 @@ def test_cell_bitmap_and_general_run_kernels_do_not_change_results(monkeypatch):
             assert np.array_equal(a, b)
 
 
-def test_dense_noise_frames_take_the_general_kernels_and_match_the_oracle(oracle):
+@pytest.mark.parametrize("caps", ["worst", None])
+def test_dense_noise_frames_take_the_general_kernels_and_match_the_oracle(oracle, caps):
     """Frames the per-frame LDS kernels cannot hold (noise everywhere: far more than 32 768 runs) are
     flagged on the device, the chunk is run again with the general multi-workgroup kernels, and the records
-    still equal the oracle's; later chunks of the same context launch the general kernels right away."""
+    still equal the oracle's; later chunks of the same context launch the general kernels right away.  With the default
+    (compact) capacities such frames exceed the run tables first and take the worst-case workspace instead."""
     from lfd_amd import _native
     pb, pd, prs = params()
     rng = np.random.default_rng(7)
@@ -281,10 +283,14 @@ def test_dense_noise_frames_take_the_general_kernels_and_match_the_oracle(oracle
         frames.append(f)
     frames.append(np.zeros((h, w), np.float32))           # and an empty frame in the same chunk
     batch = np.stack(frames)
-    ctx = _native.Context(0, h, w, 4)
+    ctx = _native.Context(0, h, w, 4, caps=caps)
     res = ctx.detect_batch(batch.copy(), pb, pd)
-    runs = ctx.get_counters(0, 4)[:, 12]
-    assert runs[:3].min() > 32768, runs                   # really beyond the LDS tables
+    if caps == "worst":
+        runs = ctx.get_counters(0, 4)[:, 12]
+        assert runs[:3].min() > 32768, runs               # really beyond the LDS tables
+        assert ctx.spill_count() == 0
+    else:
+        assert ctx.spill_count() == 3                     # beyond the default run tables (N / 16): worst-case workspace
     for i in range(4):
         want = oracle.detect_frame(frames[i].copy(), pb, pd)
         assert same(res[i], want), (i, want, res[i])

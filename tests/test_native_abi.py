@@ -25,7 +25,12 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(_native.SYMBOLS) == declared
-    assert lib.lfdmi_version() == 100
+    assert lib.lfdmi_version() == 200
+    # nothing is exported that the header does not declare
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("lfdmi_")})
+    assert exported == declared, sorted(set(exported) ^ set(declared))
 
 
 def test_struct_layouts():
@@ -34,6 +39,11 @@ def test_struct_layouts():
     assert [n for n, _ in _native.Result._fields_] == list(_native.RESULT_DTYPE.names)
     assert C.sizeof(_native.Params) == 6 * 8 + 3 * 4 + 2 * 4 + 8 + 2 * 4 + 8 + 2 * 8 + 4  # with padding
     assert C.sizeof(_native.RsParams) == 48 and C.sizeof(_native.Catalog) == 72
+    assert C.sizeof(_native.Caps) == 32
+    c = _native.Caps()
+    _native.lib().lfdmi_default_caps(1489, 2048, C.byref(c))
+    n = 1489 * 2048
+    assert (c.run_cap, c.key_cap, c.slot_cap, c.list_cap, c.peak_cap, c.min_rho) == (n // 16, n // 256, n // 16, n // 16, 65536, 5.0)
 
 
 def test_hough_dims_without_gpu():
