@@ -126,39 +126,42 @@ def process_field(results, errors, run, camcol, filter, field, params_bright, pa
         _log_error(errors, (run, camcol, filter, field), e, params_bright.get("debug") or params_dim.get("debug"))
 
 
-def process_fields_batched(results, errors, ids, params_bright, params_dim, params_removestars):
-    """Same outcome as calling process_field for every (run, camcol, filter, field) in ``ids``, in order,
-    but all frames that load go through ONE lfdmi_detect_batch call (frames with different
-    filters use different magnitude caps, so the batch is grouped by filter)."""
-    loaded = []
-    for key in ids:
-        try:
-            loaded.append((key,) + _load_frame(*key))
-        except Exception as e:  # noqa: BLE001
-            loaded.append((key, e))
+def process_fields_batched(results, errors, ids, params_bright, params_dim, params_removestars, loaded=None):
+    """Same outcome as calling process_field for every (run, camcol, filter, field) in ``ids``, in order -- the same
+    results rows, the same errors entries, a bad frame costs only itself (detecttrails.py:119-139) -- but all frames
+    that load go through ONE lfdmi_detect_batch call per (filter, shape) group (frames with different filters use
+    different magnitude caps).  ``loaded``: what ``_load_many(ids)`` returned, if the caller read the files already."""
+    from .removestars import _check_finite
+    if loaded is None:
+        loaded = _load_many(ids)
     rows = {}
     debug = params_bright.get("debug") or params_dim.get("debug")
-    by_filter = {}
+    groups = {}
     for item in loaded:
-        if len(item) == 4:
-            by_filter.setdefault(item[0][2], []).append(item)
+        if len(item) != 4:
+            continue                                  # did not load: its exception is logged below
+        key, img, _, cat = item
+        try:
+            if cat is not None and len(cat["NOBSERVE"]):
+                _check_finite(cat)                    # math.ceil(nan) in the reference: this frame's error alone
+        except Exception as e:  # noqa: BLE001
+            rows[key] = e
+            continue
+        groups.setdefault((key[2], img.shape), []).append(item)
     from .. import synth
-    for flt, items in by_filter.items():
-        shapes = {it[1].shape for it in items}
-        for shape in shapes:
-            group = [it for it in items if it[1].shape == shape]
-            try:
-                for it in group:
-                    from .removestars import _check_finite
-                    _check_finite(it[3])
-                frames = _np.stack([it[1] for it in group])
-                packed = synth.pack_catalogs([it[3] for it in group])
-                ctx = get_context(*shape, inflight=min(32, len(group)))
-                recs = ctx.detect_batch(frames, params_bright, params_dim, packed, _rs_struct(flt, params_removestars))
-                for it, rec in zip(group, recs):
-                    rows[it[0]] = rec
-            except Exception as e:  # noqa: BLE001 - fall back to per-frame handling of this group
-                for it in group:
+    for (flt, shape), group in groups.items():
+        try:
+            frames = _np.stack([it[1] for it in group])
+            packed = synth.pack_catalogs([it[3] for it in group])
+            ctx = get_context(*shape, inflight=min(32, len(group)))
+            recs = ctx.detect_batch(frames, params_bright, params_dim, packed, _rs_struct(flt, params_removestars))
+            for it, rec in zip(group, recs):
+                rows[it[0]] = rec
+        except Exception:  # noqa: BLE001 - a call-level failure: every frame of the group on its own, under its own try
+            for it in group:
+                try:
+                    rows[it[0]] = process_frame_arrays(it[1], it[3], flt, params_bright, params_dim, params_removestars)[2]
+                except Exception as e:  # noqa: BLE001
                     rows[it[0]] = e
     for item in loaded:
         key = item[0]
@@ -178,6 +181,18 @@ def process_fields_batched(results, errors, ids, params_bright, params_dim, para
                 results.write(f"{item[2]} {res['x1']} {res['y1']} {res['x2']} {res['y2']}\n")
         except Exception as e:  # noqa: BLE001
             _log_error(errors, key, e, debug)
+
+
+def _load_many(ids):
+    """[(key, img, head, cat) or (key, exception)] for every key, in order (FITS / bz2 decoding: host work that
+    DetectTrails.process overlaps with the GPU passes of the previous chunk)."""
+    out = []
+    for key in ids:
+        try:
+            out.append((key,) + _load_frame(*key))
+        except Exception as e:  # noqa: BLE001
+            out.append((key, e))
+    return out
 
 
 class DetectTrails:
@@ -288,31 +303,35 @@ class DetectTrails:
         elif pick == "field":
             yield self._run, self._camcol, self._filter, self._field
 
-    def process(self, batch=1, rank=None, world_size=None):
+    def process(self, batch=32, rank=None, world_size=None):
         """Run the selection; results and errors files are opened in append mode.
 
-        ``batch`` > 1 sends that many frames to the GPU per call (same rows, same order).
-        With ``world_size`` > 1 (default: $RANK / $WORLD_SIZE, i.e. one process per GPU under
-        torchrun) every rank processes frames ``rank, rank + world_size, ...`` of the selection and
-        appends to ``<results>.rank<r>`` / ``<errors>.rank<r>`` -- the replacement for splitting runs
-        into PBS jobs (lfd/createjobs)."""
+        ``batch`` frames go to the GPU per call (same rows, same order as frame by frame; ``batch=1`` is the
+        reference's frame-at-a-time loop); while the GPU works on one chunk a reader thread already decodes the
+        FITS / bz2 files of the next one.  With ``world_size`` > 1 (default: $RANK / $WORLD_SIZE, i.e. one process
+        per GPU under torchrun) every rank processes one contiguous block of the selection
+        (``lfd_amd.batch.shard_bounds``: ceil(n / world_size) frames each, the same rule the batch detector and
+        bench.py use) and appends to ``<results>.rank<r>`` / ``<errors>.rank<r>`` -- the replacement for splitting
+        runs into PBS jobs (lfd/createjobs/createjobs.py:173-202)."""
+        from concurrent.futures import ThreadPoolExecutor
+        from ..batch import shard_range
         rank = int(os.environ.get("RANK", 0)) if rank is None else rank
         world_size = int(os.environ.get("WORLD_SIZE", 1)) if world_size is None else world_size
         suffix = f".rank{rank}" if world_size > 1 else ""
+        keys = list(self._frames())
+        if world_size > 1:
+            a, b = shard_range(len(keys), rank, world_size)
+            keys = keys[a:b]
         with open(self.results + suffix, "a") as results, open(self.errors + suffix, "a") as errors:
-            pending = []
-            for i, key in enumerate(self._frames()):
-                if i % world_size != rank:
-                    continue
-                if batch <= 1:
-                    process_field(results, errors, *key, self.params_bright, self.params_dim,
-                                  self.params_removestars)
-                    continue
-                pending.append(key)
-                if len(pending) == batch:
-                    process_fields_batched(results, errors, pending, self.params_bright, self.params_dim,
-                                           self.params_removestars)
-                    pending = []
-            if pending:
-                process_fields_batched(results, errors, pending, self.params_bright, self.params_dim,
-                                       self.params_removestars)
+            if batch <= 1:
+                for key in keys:
+                    process_field(results, errors, *key, self.params_bright, self.params_dim, self.params_removestars)
+                return
+            chunks = [keys[i:i + batch] for i in range(0, len(keys), batch)]
+            with ThreadPoolExecutor(1) as reader:
+                nxt = reader.submit(_load_many, chunks[0]) if chunks else None
+                for i, chunk in enumerate(chunks):
+                    loaded = nxt.result()
+                    nxt = reader.submit(_load_many, chunks[i + 1]) if i + 1 < len(chunks) else None
+                    process_fields_batched(results, errors, chunk, self.params_bright, self.params_dim,
+                                           self.params_removestars, loaded=loaded)

@@ -13,24 +13,31 @@ import numpy as np
 BLOCK = 2880
 
 
+def _quoted(text):
+    """Contents of the quoted string that starts ``text`` ('' is an escaped quote; trailing blanks are not significant)."""
+    s = text.lstrip()[1:]
+    out, i = [], 0
+    while i < len(s):
+        if s[i] == "'":
+            if i + 1 < len(s) and s[i + 1] == "'":
+                out.append("'")
+                i += 2
+                continue
+            break
+        out.append(s[i])
+        i += 1
+    return "".join(out).rstrip()
+
+
 def _parse_card(card):
     key = card[:8].strip()
+    if key == "CONTINUE" and card[8:].lstrip().startswith("'"):
+        return key, _quoted(card[8:])          # long-string convention: continues the previous card's value
     if card[8:10] != "= ":
         return key, None
     val = card[10:]
     if val.lstrip().startswith("'"):
-        s = val.lstrip()[1:]
-        out, i = [], 0
-        while i < len(s):
-            if s[i] == "'":
-                if i + 1 < len(s) and s[i + 1] == "'":
-                    out.append("'")
-                    i += 2
-                    continue
-                break
-            out.append(s[i])
-            i += 1
-        return key, "".join(out).rstrip()
+        return key, _quoted(val)
     val = val.split("/")[0].strip()
     if val in ("T", "F"):
         return key, val == "T"
@@ -45,6 +52,7 @@ def _parse_card(card):
 
 def _read_header(buf, off):
     hdr = {}
+    last_str = None
     while True:
         block = buf[off:off + BLOCK]
         if len(block) < BLOCK:
@@ -58,9 +66,18 @@ def _read_header(buf, off):
             if key == "END":
                 done = True
                 break
+            if key == "CONTINUE":
+                # a string value ending in '&' goes on in the following CONTINUE card(s)
+                if last_str is not None and isinstance(hdr.get(last_str), str) and hdr[last_str].endswith("&") and val is not None:
+                    hdr[last_str] = hdr[last_str][:-1] + val
+                continue
             if key and val is not None and key not in hdr:
                 hdr[key] = val
+                last_str = key if isinstance(val, str) else None
         if done:
+            for k, v in hdr.items():           # (a final '&' with nothing after it is dropped, as cfitsio does)
+                if isinstance(v, str) and v.endswith("&") and k == last_str:
+                    hdr[k] = v[:-1]
             return hdr, off
 
 
@@ -99,7 +116,11 @@ def read_image(path, with_header=True):
     arr = arr.astype(dt.newbyteorder("="))
     bscale, bzero = hdr.get("BSCALE", 1), hdr.get("BZERO", 0)
     if bscale != 1 or bzero != 0:
-        arr = arr * bscale + bzero
+        unsigned = {(16, 32768): np.uint16, (32, 2147483648): np.uint32, (8, -128): np.int8}
+        if bscale == 1 and float(bzero).is_integer() and (hdr["BITPIX"], int(bzero)) in unsigned:
+            arr = (arr.astype(np.int64) + int(bzero)).astype(unsigned[(hdr["BITPIX"], int(bzero))])  # the FITS unsigned convention
+        else:
+            arr = arr.astype(np.float64) * float(bscale) + float(bzero)
     return (arr, hdr) if with_header else arr
 
 
@@ -154,6 +175,14 @@ def read_table(path, columns, ext=1):
                 raise ValueError(f"column {name}: TFORM {form} not supported")
             col = np.ndarray((nrows, rep), dt, buf, data_off + pos, (row_bytes, np.dtype(dt).itemsize))
             col = col.astype(np.dtype(dt).newbyteorder("=")) if code != "A" else col.copy()
+            if code == "L":
+                col = (col == ord("T"))
+            tscal, tzero = hdr.get(f"TSCAL{i}", 1), hdr.get(f"TZERO{i}", 0)
+            if (tscal != 1 or tzero != 0) and code in "BIJKED":
+                if tscal == 1 and float(tzero).is_integer() and code in "BIJK":
+                    col = col.astype(np.int64) + int(tzero)      # unsigned integers stored with an offset
+                else:
+                    col = col * tscal + tzero
             out[name] = col[:, 0] if rep == 1 else col
         pos += width
     missing = want - set(out)

@@ -80,14 +80,50 @@ def test_detecttrails_process(tmp_path, oracle, batch):
 
 
 def test_rank_sharding_of_the_driver(tmp_path, oracle):
-    """world_size = 2 in one process: the two ranks' files together hold the single-process rows."""
+    """world_size = 2 in one process: rank r takes the r-th contiguous block of the selection (batch.shard_bounds, the
+    rule the batch detector and bench.py use); the two ranks' files, concatenated, are the single-process rows in order."""
     from lfd_amd.detecttrails import DetectTrails
-    fields = list(range(0, 6))
+    fields = list(range(0, 7))
     truth = build_tree(tmp_path, fields)
     want = expected_rows(oracle, truth, skip={fields[2]})
     for r in (0, 1):
         DetectTrails(run=94, camcol=1, filter="r", savepath=str(tmp_path)).process(batch=2, rank=r, world_size=2)
     got = []
     for r in (0, 1):
-        got += [l.strip() for l in open(tmp_path / f"results.txt.rank{r}") if l.strip()]
-    assert sorted(got) == sorted(want)
+        rows = [l.strip() for l in open(tmp_path / f"results.txt.rank{r}") if l.strip()]
+        lo, hi = (0, 4) if r == 0 else (4, 7)                  # ceil(7 / 2) = 4 frames for rank 0
+        assert all(lo <= int(row.split()[3]) < hi for row in rows), (r, rows)
+        got += rows
+    assert got == want
+
+
+def test_one_bad_frame_costs_only_itself_in_a_batch(tmp_path, oracle):
+    """A NaN in one photoObj catalogue (math.ceil raises in the reference: that frame's error, detecttrails.py:133-139)
+    inside a batch of good frames: rows and errors entries equal the frame-at-a-time run."""
+    from lfd_amd.detecttrails import DetectTrails, fitslite, sdssfiles
+    fields = list(range(0, 6))
+    truth = build_tree(tmp_path, fields)
+    bad = fields[4]
+    ppath = sdssfiles.filename("photoObj", 94, 1, bad)
+    cols = dict(truth[bad][1])
+    cols["ROWC"] = cols["ROWC"].copy()
+    cols["ROWC"][3, 2] = np.nan
+    cols["OBJC_TYPE"] = np.zeros(len(cols["NOBSERVE"]), np.int32)
+    cols["TYPE"] = np.zeros((len(cols["NOBSERVE"]), 5), np.int32)
+    fitslite.write_table(ppath, cols)
+    want = expected_rows(oracle, truth, skip={fields[2], bad})
+    outs = {}
+    for batch in (1, 6):
+        sub = tmp_path / f"b{batch}"
+        sub.mkdir()
+        dt = DetectTrails(run=94, camcol=1, filter="r", savepath=str(sub))
+        dt.process(batch=batch)
+        rows = [l.strip() for l in open(dt.results) if l.strip()]
+        err = open(dt.errors).read()
+        heads = [blk.splitlines()[0] for blk in err.split("\n\n") if blk.strip()]
+        tails = [blk.strip().splitlines()[-1] for blk in err.split("\n\n") if blk.strip()]
+        outs[batch] = (rows, heads, tails)
+    assert outs[1] == outs[6]
+    assert outs[6][0] == want
+    assert outs[6][1] == [f"94 1 r {fields[2]}", f"94 1 r {bad}"]
+    assert outs[6][2][1] == "cannot convert float NaN to integer"

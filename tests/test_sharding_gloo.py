@@ -31,7 +31,15 @@ def _worker(rank, world, n_frames, port, q):
     dist.destroy_process_group()
 
 
-def _run(world, n_frames, port):
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, n_frames, port=None):
+    port = port or _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, n_frames, port, q)) for r in range(world)]
@@ -45,14 +53,14 @@ def _run(world, n_frames, port):
 
 
 def test_two_ranks_even_split():
-    out = _run(2, 64, 29611)
+    out = _run(2, 64)
     assert [(r, a, b) for r, a, b, _ in out] == [(0, 0, 32), (1, 32, 64)]
     want = _fake_records(0, 64).tobytes()
     assert all(buf == want for *_, buf in out)
 
 
 def test_two_ranks_ragged_split():
-    out = _run(2, 7, 29612)
+    out = _run(2, 7)
     assert [(a, b) for _, a, b, _ in out] == [(0, 4), (4, 7)]
     want = _fake_records(0, 7).tobytes()
     assert all(buf == want for *_, buf in out)
