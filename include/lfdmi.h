@@ -49,7 +49,11 @@ enum { LFDMI_RETR_EXTERNAL = 0, LFDMI_RETR_LIST = 1, LFDMI_RETR_CCOMP = 2, LFDMI
 enum { LFDMI_CHAIN_APPROX_NONE = 1, LFDMI_CHAIN_APPROX_SIMPLE = 2, LFDMI_CHAIN_APPROX_TC89_L1 = 3,
        LFDMI_CHAIN_APPROX_TC89_KCOS = 4 };
 /* lfdmi_get_stage selectors (device images of the last process/detect call, per slot) */
-enum { LFDMI_STAGE_GRAY = 0, LFDMI_STAGE_EQU = 1, LFDMI_STAGE_CANNY = 2, LFDMI_STAGE_BOX = 3, LFDMI_STAGE_ERODED = 4 };
+/* GRAY: convertScaleAbs output; EQUALIZED: equalizeHist(gray) (1equBRIGHT / 6equDIM); ERODED: erode(equalized)
+ * (7erodedDIM); EQU: the dilated image Canny and HoughLines see (2dilateBRIGHT / 8openedDIM); CANNY: the edge map;
+ * BOX: box_img (3contoursBRIGHT / 9contoursDIM) -- debug dump names of processfield.py:349-378, :459-496 */
+enum { LFDMI_STAGE_GRAY = 0, LFDMI_STAGE_EQU = 1, LFDMI_STAGE_CANNY = 2, LFDMI_STAGE_BOX = 3, LFDMI_STAGE_ERODED = 4,
+       LFDMI_STAGE_EQUALIZED = 5 };
 
 typedef struct lfdmi_ctx lfdmi_ctx;
 

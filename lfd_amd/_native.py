@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblfdmi.so")
 HOST, DEVICE = 0, 1
 U8, F32, F64 = 0, 1, 2
 PREP_NONE, PREP_BRIGHT, PREP_DIM, PREP_BRIGHT_THEN_DIM = 0, 1, 2, 3
-STAGE_GRAY, STAGE_EQU, STAGE_CANNY, STAGE_BOX, STAGE_ERODED = 0, 1, 2, 3, 4
+STAGE_GRAY, STAGE_EQU, STAGE_CANNY, STAGE_BOX, STAGE_ERODED, STAGE_EQUALIZED = 0, 1, 2, 3, 4, 5
 MAX_SCALES = 4
 MAX_SET_LINES = 64
 MAX_MORPH_K = 31

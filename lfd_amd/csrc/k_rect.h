@@ -146,6 +146,37 @@ k_extremes(RunTabs t, int2 *rowext, int h, int w, int slot_cap, const int *wlist
     }
 }
 
+// cv2.RETR_EXTERNAL (processfield.py:226-230 lets any retrieval mode through): only the outer borders of components that
+// no other component encloses.  Suzuki-Abe decides that while scanning ("the last border pixel met on this row is
+// positive": lfd_oracle.c, lfo_find_contours); the same set is: edge components whose raster-first pixel has the OUTSIDE
+// background (the 4-connected 0-component that touches the frame) as its left neighbour, or sits in column 0
+// (tests/test_contour_equivalence.py checks the two rules against each other).  A key's first row slot holds that
+// pixel's column, so this runs after the row extremes: hole keys and enclosed components get extent 0 and the
+// rectangle kernels skip them.
+__global__ void __launch_bounds__(256)
+k_filter_external(RunTabs t, int4 *keys, const int2 *rowext, const int *counters, int h, int w, int key_cap, int slot_cap,
+                  const int *active) {
+    int g = blockIdx.y;
+    if (slot_off(active, counters, g)) return;
+    const int wq = LFD_WQ(w);
+    const size_t fo = (size_t)g * h * wq, ro = (size_t)g * t.run_cap;
+    int nkeys = min(counters[g * C_COUNT + C_NKEYS], key_cap);
+    int4 *kg = keys + (size_t)g * key_cap;
+    const int2 *re = rowext + (size_t)g * slot_cap;
+    for (int ki = blockIdx.x * 256 + threadIdx.x; ki < nkeys; ki += gridDim.x * 256) {
+        int4 key = kg[ki];
+        bool keep = !(key.y & KEY_HOLE_BIT);
+        if (keep) {
+            int y0 = key.z, x0 = re[key.w].x;
+            if (x0 > 0 && x0 < w) {
+                int bid = run_id(t.scanb + fo, t.edge + fo, y0, x0 - 1, 0, wq, w);
+                keep = bid >= 0 && bid < t.run_cap && t.FLb[ro + t.Lb[ro + bid]] != 0;
+            }
+        }
+        if (!keep) kg[ki].y = key.y & KEY_HOLE_BIT; // extent 0
+    }
+}
+
 // ---- minAreaRect on a hull given through an accessor -------------------------------------
 struct HullView {
     const int2 *c1; // chain 1 (left side, rows increasing)

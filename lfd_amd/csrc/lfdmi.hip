@@ -653,8 +653,8 @@ static int zero_counters(lfdmi_ctx *ctx, int nc) {
 static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method, double minLen, double lwTresh, const int *active) {
     if (method != LFDMI_CHAIN_APPROX_NONE && method != LFDMI_CHAIN_APPROX_SIMPLE)
         return fail(ctx, LFDMI_ERR_UNSUPPORTED, "contoursMethod: only CHAIN_APPROX_NONE / CHAIN_APPROX_SIMPLE");
-    if (mode != LFDMI_RETR_LIST && mode != LFDMI_RETR_CCOMP && mode != LFDMI_RETR_TREE)
-        return fail(ctx, LFDMI_ERR_UNSUPPORTED, "contoursMode: only RETR_LIST / RETR_CCOMP / RETR_TREE");
+    if (mode != LFDMI_RETR_EXTERNAL && mode != LFDMI_RETR_LIST && mode != LFDMI_RETR_CCOMP && mode != LFDMI_RETR_TREE)
+        return fail(ctx, LFDMI_ERR_UNSUPPORTED, "contoursMode: RETR_EXTERNAL / RETR_LIST / RETR_CCOMP / RETR_TREE");
     dim3 lg(WORDLIST_BLOCKS, nc);
     int rc = ctx->run_cap;
     { Span sp(ctx, KID_RUNS_INIT_BG);
@@ -696,6 +696,11 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     { Span sp(ctx, KID_EXTREMES);
     k_extremes<<<lg, 256, 0, ctx->stream>>>(rt, ctx->rowext, h, w, ctx->slot_cap, ctx->wl_fg, ctx->counters, gen);
     KCHK("k_extremes"); }
+    }
+    if (mode == LFDMI_RETR_EXTERNAL) { // hole borders and enclosed components drop out before the rectangles
+        Span sp(ctx, KID_KEYS);
+        k_filter_external<<<dim3(8, nc), 256, 0, ctx->stream>>>(rt, ctx->keys, ctx->rowext, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, active);
+        KCHK("k_filter_external");
     }
     { Span sp(ctx, KID_RECTS);
     // Three independent kernels by key height (short: a lane per key; medium / tall: a wave per key).
@@ -1503,8 +1508,15 @@ extern "C" int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, int h, int w
     const uint8_t *src = nullptr;
     if (which == LFDMI_STAGE_GRAY) src = ctx->gray + slot * N;
     else if (which == LFDMI_STAGE_EQU) src = ctx->equ + slot * N;
-    else if (which == LFDMI_STAGE_ERODED) src = ctx->tmp + slot * N;
-    else if (which == LFDMI_STAGE_CANNY || which == LFDMI_STAGE_BOX) {
+    else if (which == LFDMI_STAGE_EQUALIZED || which == LFDMI_STAGE_ERODED) {
+        // equalizeHist output (before the morphology) and the eroded, equalised image of the dim pass: the workspace
+        // keeps the un-equalised planes (the monotone LUT commutes with min / max and is applied by their consumers)
+        RET(ensure_scratch(ctx, N));
+        const uint8_t *plane = (which == LFDMI_STAGE_EQUALIZED ? ctx->gray : ctx->tmp) + slot * N;
+        k_apply_lut<<<dim3(512, 1), 256, 0, ctx->stream>>>(plane, ctx->lut + slot * 256, (uint8_t *)ctx->scratch, N);
+        KCHK("k_apply_lut");
+        src = (const uint8_t *)ctx->scratch;
+    } else if (which == LFDMI_STAGE_CANNY || which == LFDMI_STAGE_BOX) {
         const u64 *bits = (which == LFDMI_STAGE_CANNY ? ctx->edgeb : ctx->boxb) + slot * BW;
         RET(ensure_scratch(ctx, N));
         RET(expand_bits(ctx, bits, (uint8_t *)ctx->scratch, 1, h, w));

@@ -135,14 +135,14 @@ def _finish(ctx, res, lines_equ, lines_box, shape, nlinesInSet, dro, thetaTresh,
     status = int(res["status"])
     if status not in (0, _native.ERR_NOLINES):
         raise _native.NativeError(status, "frame failed on the device")
+    equhough = _lines_as_cv(lines_equ, res["n_lines_equ"]) if res["detection"] else None
+    boxhough = _lines_as_cv(lines_box, res["n_lines_box"]) if res["detection"] else None
     if debug:
-        _dump_debug(ctx, shape, tag, path)
+        _dump_debug(ctx, shape, tag, path, bool(res["detection"]), equhough, boxhough, nlinesInSet)
     if not res["detection"]:
         if debug:
             print(f"{tag}: no boxes found")
         return (False, None)
-    equhough = _lines_as_cv(lines_equ, res["n_lines_equ"])
-    boxhough = _lines_as_cv(lines_box, res["n_lines_box"])
     if equhough is None or boxhough is None:
         # cv2.HoughLines returned None: the reference dies inside check_theta with this error
         raise TypeError("'NoneType' object is not subscriptable")
@@ -151,16 +151,33 @@ def _finish(ctx, res, lines_equ, lines_box, shape, nlinesInSet, dro, thetaTresh,
     return (True, dictify_hough(shape, equhough[0][0]))
 
 
-def _dump_debug(ctx, shape, tag, path):
-    """Stage images of slot 0 as PNGs (names after docs/source/detecttrails/detparams.rst:39-54)."""
+def _dump_debug(ctx, shape, tag, path, detection, equhough, boxhough, nlines):
+    """The reference's debug images (processfield.py:349-378 bright, :459-496 dim; list in
+    docs/source/detecttrails/detparams.rst:39-54), fetched from the device buffers of slot 0:
+    bright 1equ, 2dilate, 3contours and -- when a rectangle was found -- 4boxhough, 5equhough;
+    dim 6equ, 7eroded, 8opened, 9contours, 10equhough, 11boxhough."""
     from . import debugio
     if path is None:
         raise TypeError("expected str, bytes or os.PathLike object, not NoneType")  # os.path.join(None, ..)
-    names = {"BRIGHT": ("2dilateBRIGHT.png", "3contoursBRIGHT.png"),
-             "DIM": ("8openedDIM.png", "9contoursDIM.png")}[tag]
     h, w = shape
-    debugio.write_png(os.path.join(path, names[0]), ctx.get_stage(0, _native.STAGE_EQU, h, w))
-    debugio.write_png(os.path.join(path, names[1]), ctx.get_stage(0, _native.STAGE_BOX, h, w))
+    equalized = ctx.get_stage(0, _native.STAGE_EQUALIZED, h, w)
+    equ = ctx.get_stage(0, _native.STAGE_EQU, h, w)
+    box = ctx.get_stage(0, _native.STAGE_BOX, h, w)
+    if tag == "BRIGHT":
+        debugio.write_png(os.path.join(path, "1equBRIGHT.png"), equalized, 3)
+        debugio.write_png(os.path.join(path, "2dilateBRIGHT.png"), equ, 3)
+        debugio.write_png(os.path.join(path, "3contoursBRIGHT.png"), box, 3)
+        if detection:
+            debugio.draw_lines(equhough, equ, nlines, "5equhoughBRIGHT", path)
+            debugio.draw_lines(boxhough, box, nlines, "4boxhoughBRIGHT", path)
+    else:
+        debugio.write_png(os.path.join(path, "6equDIM.png"), equalized, 0)
+        debugio.write_png(os.path.join(path, "7erodedDIM.png"), ctx.get_stage(0, _native.STAGE_ERODED, h, w), 0)
+        debugio.write_png(os.path.join(path, "8openedDIM.png"), equ, 0)
+        debugio.write_png(os.path.join(path, "9contoursDIM.png"), box, 0)
+        if detection:
+            debugio.draw_lines(equhough, equ, nlines, "10equhoughDIM", path, compression=4)
+            debugio.draw_lines(boxhough, box, nlines, "11boxhoughDIM", path, compression=4, color=(0, 0, 255))
 
 
 def process_field_bright(img, lwTresh, thetaTresh, dilateKernel, contoursMode, contoursMethod,

@@ -61,3 +61,50 @@ def test_hulls_equal_on_nested_structures(oracle):
     E[7, 7] = 1                                      # dot inside the inner hole
     assert ccl_hulls(oracle, E) == suzuki_hulls(oracle, E)
     assert len(suzuki_hulls(oracle, E)) == 5
+
+
+def external_by_topology(E):
+    """RETR_EXTERNAL without border following (k_rect.h: k_filter_external): 8-connected components whose raster-first
+    pixel has the frame-connected 4-background as its left neighbour (or sits in column 0) -> their first pixels."""
+    fg, n = ndi.label(E != 0, structure=np.ones((3, 3), int))
+    pad = np.pad(E != 0, 1)
+    bg, _ = ndi.label(~pad)                      # 4-connectivity, the 1-px zero frame included
+    outside = bg[0, 0]
+    ext = set()
+    for c in range(1, n + 1):
+        ys, xs = np.nonzero(fg == c)
+        y0 = int(ys.min())
+        x0 = int(xs[ys == y0].min())
+        if bg[y0 + 1, x0] == outside:            # padded coordinates of (y0, x0 - 1)
+            ext.add((x0, y0))
+    return ext
+
+
+def test_retr_external_is_the_outside_background_rule(oracle):
+    """Suzuki-Abe's RETR_EXTERNAL test ("the last border pixel met on this row is positive", lfo_find_contours) against
+    the topological rule the GPU uses: random noise, nested rectangles / rings, thinned blobs, Canny edge maps."""
+    rng = np.random.default_rng(1)
+    total = 0
+    for trial in range(600):
+        h, w = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+        kind = trial % 4
+        if kind == 0:
+            img = (rng.random((h, w)) < rng.uniform(0.2, 0.8)).astype(np.uint8)
+        elif kind == 1:
+            img = np.zeros((h, w), np.uint8)
+            for _ in range(int(rng.integers(1, 6))):
+                y0, x0 = int(rng.integers(0, h)), int(rng.integers(0, w))
+                y1, x1 = int(rng.integers(y0, h)) + 1, int(rng.integers(x0, w)) + 1
+                img[y0:y1, x0:x1] = 1
+                if y1 - y0 > 2 and x1 - x0 > 2:
+                    img[y0 + 1:y1 - 1, x0 + 1:x1 - 1] = 0
+        elif kind == 2:
+            img = ndi.binary_dilation(rng.random((h, w)) < 0.5).astype(np.uint8) & (rng.random((h, w)) < 0.9)
+        else:
+            img = oracle.canny((ndi.gaussian_filter(rng.random((h, w)), 1.5) * 255).astype(np.uint8), 0, 255)
+        img = np.ascontiguousarray((img != 0) * 255, np.uint8)
+        cs, holes = oracle.find_contours(img, oracle.RETR_EXTERNAL)
+        assert not any(holes)
+        assert {tuple(int(v) for v in c[0]) for c in cs} == external_by_topology(img), (trial, kind)
+        total += len(cs)
+    assert total > 1500
