@@ -71,6 +71,11 @@ typedef struct {
     int32_t erode_kh, erode_kw;   /* dim only */
     const uint8_t *erodeKernel;
     double minFlux, addFlux;      /* dim only */
+    /* Optional smoothing of Canny's input.  BASELINE's north_star lists a Gaussian stage inside Canny; cv2.Canny
+     * (processfield.py:236) has none, so it is OFF unless gaussKernel > 0 and has no reference call site.  Odd size
+     * 1..31; gaussSigma <= 0: cv2.getGaussianKernel's default for that size.  Semantics: lfdmi_gaussian_blur. */
+    int32_t gaussKernel;
+    double gaussSigma;
 } lfdmi_params;
 
 #define LFDMI_MAX_SET_LINES 64
@@ -152,6 +157,12 @@ int lfdmi_dilate(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, const 
                  int kh, int kw, uint8_t *dst, int loc);
 int lfdmi_erode(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, const uint8_t *kernel,
                 int kh, int kw, uint8_t *dst, int loc);
+/* Optional Gaussian stage (no reference call site, see lfdmi_params.gaussKernel): cv2.getGaussianKernel(ksize, sigma,
+ * CV_32F) applied separably in float32 (rows, then columns; BORDER_REFLECT_101; taps accumulated in order without FMA),
+ * one final round-half-even + saturation.  OpenCV's own 8-bit path uses fixed-point taps since 3.4.1, so this is the
+ * build's definition (oracle: lfo_gaussian_blur), not a cv2 parity claim. */
+int lfdmi_gaussian_blur(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, int ksize, double sigma,
+                        uint8_t *dst, int loc);
 /* cv2.Canny(img, low, high) with aperture 3, L1 gradient (processfield.py:236) */
 int lfdmi_canny(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, double low, double high,
                 uint8_t *dst, int loc);

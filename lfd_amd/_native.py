@@ -29,7 +29,7 @@ SYMBOLS = (
     "lfdmi_version", "lfdmi_default_caps", "lfdmi_ctx_create", "lfdmi_ctx_create_sized", "lfdmi_ctx_bytes", "lfdmi_spill_count",
     "lfdmi_ctx_destroy", "lfdmi_last_error", "lfdmi_set_stream", "lfdmi_process_multiscale", "lfdmi_debug_frame_profile",
     "lfdmi_max_inflight", "lfdmi_prep_u8", "lfdmi_equalize_hist", "lfdmi_dilate", "lfdmi_erode",
-    "lfdmi_canny", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
+    "lfdmi_canny", "lfdmi_gaussian_blur", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
     "lfdmi_hough_dims", "lfdmi_remove_stars", "lfdmi_process_bright", "lfdmi_process_dim",
     "lfdmi_detect_batch", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_timing_select", "lfdmi_get_timing",
     "lfdmi_timing_slots", "lfdmi_timing_name",
@@ -48,7 +48,8 @@ class Params(C.Structure):
                 ("nlinesInSet", C.c_int32), ("contoursMode", C.c_int32), ("contoursMethod", C.c_int32),
                 ("dilate_kh", C.c_int32), ("dilate_kw", C.c_int32), ("dilateKernel", C.c_void_p),
                 ("erode_kh", C.c_int32), ("erode_kw", C.c_int32), ("erodeKernel", C.c_void_p),
-                ("minFlux", C.c_double), ("addFlux", C.c_double)]
+                ("minFlux", C.c_double), ("addFlux", C.c_double),
+                ("gaussKernel", C.c_int32), ("gaussSigma", C.c_double)]
 
 
 class Caps(C.Structure):
@@ -156,6 +157,8 @@ def make_params(d, dim=False):
         p.erodeKernel = ek.ctypes.data
         p.minFlux = float(d["minFlux"])
         p.addFlux = float(d["addFlux"])
+    p.gaussKernel = int(d.get("gaussKernel", 0) or 0)       # optional smoothing of Canny's input; off in the reference
+    p.gaussSigma = float(d.get("gaussSigma", 0.0) or 0.0)
     return p, keep
 
 
@@ -312,6 +315,13 @@ class Context:
 
     def erode(self, img, kernel):
         return self._morph(self._lib.lfdmi_erode, img, kernel)
+
+    def gaussian_blur(self, img, ksize, sigma=0.0):
+        img, n, h, w, sq = self._batch(img)
+        loc = DEVICE if _is_dev(img) else HOST
+        out = self._out_like(img, n, h, w, sq)
+        self._chk(self._lib.lfdmi_gaussian_blur(self._h, _ptr(img), n, h, w, int(ksize), C.c_double(sigma), _ptr(out), loc))
+        return out[0] if sq else out
 
     def canny(self, img, low=0.0, high=255.0):
         img, n, h, w, sq = self._batch(img)

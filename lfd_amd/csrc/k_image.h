@@ -578,6 +578,55 @@ k_morph_generic(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Optional Gaussian smoothing of Canny's input (off by default: cv2.Canny has no such stage; see include/lfdmi.h).
+// Separable float32 filter, taps from the host (cv2.getGaussianKernel's formula), BORDER_REFLECT_101, accumulation
+// in tap order without FMA, one rounding to 8 bit at the end.  64 x 16 tile per workgroup: the u8 tile with its
+// halo and the horizontal float result live in LDS.
+// ------------------------------------------------------------------------------------------
+#define GAUSS_TW 64
+#define GAUSS_TH 16
+struct GaussTaps { float k[32]; int n; };
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+__global__ void __launch_bounds__(256)
+k_gauss(const uint8_t *src, uint8_t *dst, int h, int w, GaussTaps taps, const int *active) {
+    int g = blockIdx.z;
+    if (active && !active[g]) return;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smg[];
+    const int n = taps.n, r = n / 2;
+    const int IW = GAUSS_TW + 2 * r, IH = GAUSS_TH + 2 * r;
+    uint8_t *tin = smg;                                              // IH x IW bytes
+    float *hor = (float *)(smg + ((IH * IW + 15) & ~15));            // IH x GAUSS_TW floats
+    const int x0 = blockIdx.x * GAUSS_TW, y0 = blockIdx.y * GAUSS_TH;
+    const uint8_t *s = src + (size_t)g * h * w;
+    for (int idx = threadIdx.x; idx < IH * IW; idx += 256) {
+        int iy = idx / IW, ix = idx - iy * IW;
+        tin[idx] = s[(size_t)reflect101(y0 + iy - r, h) * w + reflect101(x0 + ix - r, w)];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < IH * GAUSS_TW; idx += 256) {
+        int iy = idx / GAUSS_TW, ix = idx - iy * GAUSS_TW;
+        float acc = 0.f;
+        for (int k = 0; k < n; k++) acc = __fadd_rn(acc, __fmul_rn((float)tin[iy * IW + ix + k], taps.k[k]));
+        hor[idx] = acc;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < GAUSS_TH * GAUSS_TW; idx += 256) {
+        int oy = idx / GAUSS_TW, ox = idx - oy * GAUSS_TW;
+        int gy = y0 + oy, gx = x0 + ox;
+        if (gy >= h || gx >= w) continue;
+        float acc = 0.f;
+        for (int k = 0; k < n; k++) acc = __fadd_rn(acc, __fmul_rn(hor[(oy + k) * GAUSS_TW + ox], taps.k[k]));
+        dst[(size_t)g * h * w + (size_t)gy * w + gx] = (uint8_t)sat_u8_f32(acc);
+    }
+}
+
 // u8 image -> "!= 0" bit rows (standalone HoughLines entry point)
 __global__ void __launch_bounds__(256)
 k_bits_from_u8(const uint8_t *src, u64 *bits, int h, int w) {

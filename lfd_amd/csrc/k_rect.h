@@ -148,7 +148,7 @@ k_extremes(RunTabs t, int2 *rowext, int h, int w, int slot_cap, const int *wlist
 
 // cv2.RETR_EXTERNAL (processfield.py:226-230 lets any retrieval mode through): only the outer borders of components that
 // no other component encloses.  Suzuki-Abe decides that while scanning ("the last border pixel met on this row is
-// positive": lfd_oracle.c, lfo_find_contours); the same set is: edge components whose raster-first pixel has the OUTSIDE
+// positive"); the same set is: edge components whose raster-first pixel has the OUTSIDE
 // background (the 4-connected 0-component that touches the frame) as its left neighbour, or sits in column 0
 // (tests/test_contour_equivalence.py checks the two rules against each other).  A key's first row slot holds that
 // pixel's column, so this runs after the row extremes: hole keys and enclosed components get extent 0 and the

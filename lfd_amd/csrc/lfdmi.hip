@@ -91,6 +91,15 @@ struct lfdmi_ctx {
     size_t scratch_bytes = 0;
     int last_h = 0, last_w = 0;        // shape of the last call (lfdmi_get_stage)
     int quiet_chunks = 0;              // chunks since a frame last needed the general run kernels (general_seen decays)
+    // host-frame feed of lfdmi_detect_batch: two pinned staging buffers filled by host threads, two device buffers, a copy
+    // stream; chunk k+1 crosses PCIe while chunk k is being processed
+    void *feed_pin[2] = {nullptr, nullptr}, *feed_dev[2] = {nullptr, nullptr};
+    size_t feed_bytes = 0;
+    hipStream_t feed_copy = nullptr;
+    hipEvent_t feed_up[2] = {nullptr, nullptr};
+    std::thread feed_thread[2];
+    int feed_threads = 8;              // host threads copying a chunk into the pinned buffer (LFDMI_FEED_THREADS)
+    size_t feed_chunk_bytes = 800u << 20; // largest feed chunk (LFDMI_FEED_MB): 64 SDSS frames, 11 frames of 4096 x 4096
     int4 *rs_boxes = nullptr;          // remove_stars squares of the chunk (host-frame path)
     size_t rs_boxes_cap = 0;
     void *stage = nullptr;
@@ -253,6 +262,8 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_FRAME_RUNCAP")) { int v = atoi(e); if (v >= 0 && v < FRAME_RUNCAP) ctx->frame_runcap = v; }
     if (const char *e = getenv("LFDMI_DC_SUBSTRIPS")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->dc_substrips = v; }
     if (const char *e = getenv("LFDMI_DC_STRIP")) { int v = atoi(e); if (v >= 1 && v <= DCW_MAXS) ctx->dc_strip = v; } // tuning knob
+    if (const char *e = getenv("LFDMI_FEED_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->feed_threads = v; }
+    if (const char *e = getenv("LFDMI_FEED_MB")) { int v = atoi(e); if (v >= 0 && v <= 8192) ctx->feed_chunk_bytes = (size_t)v << 20; } // 0: plain staging
     ctx->N = (size_t)max_h * max_w;
     ctx->wq = LFD_WQ(max_w);
     size_t N = ctx->N, G = (size_t)max_inflight, BW = (size_t)max_h * ctx->wq;
@@ -383,6 +394,13 @@ extern "C" void lfdmi_ctx_destroy(lfdmi_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (void *p : ctx->allocs) hipFree(p);
     if (ctx->stage) hipFree(ctx->stage);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->feed_thread[i].joinable()) ctx->feed_thread[i].join();
+        if (ctx->feed_pin[i]) hipHostFree(ctx->feed_pin[i]);
+        if (ctx->feed_dev[i]) hipFree(ctx->feed_dev[i]);
+        if (ctx->feed_up[i]) hipEventDestroy(ctx->feed_up[i]);
+    }
+    if (ctx->feed_copy) hipStreamDestroy(ctx->feed_copy);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->rs_boxes) hipFree(ctx->rs_boxes);
     if (ctx->cat_dev) hipFree(ctx->cat_dev);
@@ -644,6 +662,37 @@ static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, i
     return 0;
 }
 
+// cv2.getGaussianKernel(n, sigma, CV_32F)
+static int gauss_taps(lfdmi_ctx *ctx, int n, double sigma, GaussTaps *t) {
+    static const float small_tab[4][7] = {{1.f}, {0.25f, 0.5f, 0.25f}, {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
+                                          {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f}};
+    if (n <= 0 || n > 31 || (n & 1) == 0) return fail(ctx, LFDMI_ERR_ARG, "gaussKernel must be odd, 1..31");
+    const float *fixed = (n <= 7 && sigma <= 0) ? small_tab[n >> 1] : nullptr;
+    double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    double scale2X = -0.5 / (sigmaX * sigmaX), sum = 0;
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        double v = fixed ? (double)fixed[i] : exp(scale2X * x * x);
+        t->k[i] = (float)v;
+        sum += t->k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) t->k[i] = (float)(t->k[i] * sum);
+    t->n = n;
+    return 0;
+}
+
+static int run_gauss(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, int nc, int h, int w, int ksize, double sigma, const int *active) {
+    GaussTaps t;
+    RET(gauss_taps(ctx, ksize, sigma, &t));
+    int r = ksize / 2, IW = GAUSS_TW + 2 * r, IH = GAUSS_TH + 2 * r;
+    size_t lds = (size_t)((IH * IW + 15) & ~15) + (size_t)IH * GAUSS_TW * sizeof(float);
+    Span sp(ctx, KID_MISC);
+    k_gauss<<<dim3((w + GAUSS_TW - 1) / GAUSS_TW, (h + GAUSS_TH - 1) / GAUSS_TH, nc), 256, lds, ctx->stream>>>(src, dst, h, w, t, active);
+    KCHK("k_gauss");
+    return 0;
+}
+
 static int zero_counters(lfdmi_ctx *ctx, int nc) {
     HIPCHK(hipMemsetAsync(ctx->counters, 0, (size_t)nc * C_COUNT * sizeof(int), ctx->stream));
     return 0;
@@ -859,6 +908,8 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
 
 static int check_params(lfdmi_ctx *ctx, const lfdmi_params *p, bool dim) {
     if (!p) return fail(ctx, LFDMI_ERR_ARG, "params NULL");
+    if (p->gaussKernel < 0 || p->gaussKernel > 31 || (p->gaussKernel > 0 && (p->gaussKernel & 1) == 0))
+        return fail(ctx, LFDMI_ERR_ARG, "gaussKernel must be 0 (off) or odd, 1..31");
     if (p->nlinesInSet < 1 || p->nlinesInSet > LFDMI_MAX_SET_LINES) return fail(ctx, LFDMI_ERR_ARG, "nlinesInSet out of range");
     if (!p->dilateKernel) return fail(ctx, LFDMI_ERR_ARG, "dilateKernel NULL");
     if (dim && !p->erodeKernel) return fail(ctx, LFDMI_ERR_ARG, "erodeKernel NULL");
@@ -915,7 +966,12 @@ static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, 
             dil_src = ctx->tmp;
         }
     }
-    if (can_fuse_dilate_canny(p->dilateKernel, p->dilate_kh, p->dilate_kw, w)) {
+    if (p->gaussKernel > 0) { // optional smoothing of Canny's input (off in the reference): separate dilate, blur, Canny
+        RET(run_morph(ctx, dil_src, ctx->equ, ctx->equb, ctx->lut, p->dilateKernel, p->dilate_kh, p->dilate_kw, 0, nc, h, w, active));
+        RET(ensure_scratch(ctx, (size_t)ctx->G * ctx->N));
+        RET(run_gauss(ctx, ctx->equ, (uint8_t *)ctx->scratch, nc, h, w, p->gaussKernel, p->gaussSigma, active));
+        RET(run_canny(ctx, (const uint8_t *)ctx->scratch, nc, h, w, 0, 255, active));
+    } else if (can_fuse_dilate_canny(p->dilateKernel, p->dilate_kh, p->dilate_kw, w)) {
         // the prep kernel of this pass left the cell occupancy of its output (a superset of the eroded image's)
         RET(run_dilate_canny(ctx, dil_src, nc, h, w, ctx->lut, p->dilate_kh, p->dilate_kw, active, ctx->use_cellbm));
         RET(run_canny(ctx, ctx->equ, nc, h, w, 0, 255, active, true));
@@ -1021,6 +1077,21 @@ extern "C" int lfdmi_dilate(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, in
                             uint8_t *dst, int loc) { return morph_api(ctx, src, n, h, w, kernel, kh, kw, dst, loc, 0); }
 extern "C" int lfdmi_erode(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, const uint8_t *kernel, int kh, int kw,
                            uint8_t *dst, int loc) { return morph_api(ctx, src, n, h, w, kernel, kh, kw, dst, loc, 1); }
+
+extern "C" int lfdmi_gaussian_blur(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int w, int ksize, double sigma, uint8_t *dst, int loc) {
+    RET(check_shape(ctx, n, h, w));
+    if (!src || !dst) return fail(ctx, LFDMI_ERR_ARG, "NULL image");
+    size_t N = (size_t)h * w;
+    for (int c0 = 0; c0 < n; c0 += ctx->G) {
+        int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
+        const void *d;
+        RET(in_ptr(ctx, src, (size_t)c0 * N, (size_t)nc * N, loc, &d));
+        RET(run_gauss(ctx, (const uint8_t *)d, ctx->equ, nc, h, w, ksize, sigma, nullptr));
+        RET(out_copy(ctx, dst, (size_t)c0 * N, ctx->equ, (size_t)nc * N, loc));
+        RET(sync(ctx, nc));
+    }
+    return 0;
+}
 
 static int expand_bits(lfdmi_ctx *ctx, const u64 *bits, uint8_t *dev_dst, int nc, int h, int w) {
     k_u8_from_bits<<<dim3((w + 63) / 64, (h + 3) / 4, nc), 256, 0, ctx->stream>>>(bits, dev_dst, h, w);
@@ -1259,7 +1330,7 @@ static void blot_host_frames(float *frames, int nc, int h, int w, const lfdmi_ca
             }
         }
     };
-    int nt = nc >= 32 ? 4 : 1;
+    int nt = nc >= 32 ? 8 : (nc >= 8 ? 4 : 1);
     if (nt == 1) { work(0, nc); return; }
     std::vector<std::thread> th;
     for (int t = 0; t < nt; t++) th.emplace_back(work, nc * t / nt, nc * (t + 1) / nt);
@@ -1408,6 +1479,66 @@ extern "C" int lfdmi_process_multiscale(lfdmi_ctx *ctx, const void *img, int dty
     return pass_api(ctx, img, dtype, n, h, w, flip, mode, dim != 0, p, n_scales, rhos, results, (size_t)n, nullptr, nullptr, loc);
 }
 
+// ---- host-frame feed -------------------------------------------------------------------------------------------------
+// A pageable hipMemcpyAsync reaches ~30-45 GB/s on this platform and cannot overlap with anything (the runtime stages it
+// synchronously); pinning the caller's array costs 40 ms per GB.  So the library stages itself: `feed_threads` host
+// threads copy chunk k+1 of the caller's frames into a pinned buffer (~100 GB/s with 8 threads) while the DMA engine
+// moves chunk k (57 GB/s, the link's rate) and the GPU processes chunk k-1: the frames cross PCIe once, back to back.
+static int feed_prepare(lfdmi_ctx *ctx, size_t bytes) {
+    if (!ctx->feed_copy) {
+        HIPCHK(hipStreamCreateWithFlags(&ctx->feed_copy, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&ctx->feed_up[i], hipEventDisableTiming));
+    }
+    if (ctx->feed_bytes >= bytes) return 0;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->feed_copy));
+    for (int i = 0; i < 2; i++) {
+        if (ctx->feed_pin[i]) { HIPCHK(hipHostFree(ctx->feed_pin[i])); ctx->feed_pin[i] = nullptr; }
+        if (ctx->feed_dev[i]) { HIPCHK(hipFree(ctx->feed_dev[i])); ctx->feed_dev[i] = nullptr; }
+    }
+    ctx->feed_bytes = 0;
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipHostMalloc(&ctx->feed_pin[i], bytes, hipHostMallocDefault));
+        HIPCHK(hipMalloc(&ctx->feed_dev[i], bytes));
+    }
+    ctx->feed_bytes = bytes;
+    return 0;
+}
+
+// Chunk `slot`: host threads copy the caller's bytes into the pinned buffer piece by piece, and every piece is sent on
+// its way (copy stream) as soon as it is staged, so the DMA engine starts after the first piece (32 MB, < 1 ms), not
+// after the whole chunk.  Runs on its own thread; feed_wait joins it and makes the launch stream wait for the upload.
+#define FEED_PIECE (32u << 20)
+static void feed_chunk_async(lfdmi_ctx *ctx, int slot, const char *src, size_t bytes) {
+    char *pin = (char *)ctx->feed_pin[slot], *dev = (char *)ctx->feed_dev[slot];
+    const int T = ctx->feed_threads, device = ctx->device;
+    hipStream_t copy = ctx->feed_copy;
+    hipEvent_t up = ctx->feed_up[slot];
+    ctx->feed_thread[slot] = std::thread([=] {
+        hipSetDevice(device);
+        for (size_t o = 0; o < bytes; o += FEED_PIECE) {
+            size_t pb = std::min<size_t>(FEED_PIECE, bytes - o);
+            int t_n = pb >= (size_t)T * (1u << 20) ? T : 1;
+            std::vector<std::thread> th;
+            for (int t = 1; t < t_n; t++) {
+                size_t a = pb / t_n * t, b = (t == t_n - 1) ? pb : pb / t_n * (t + 1);
+                th.emplace_back([=] { memcpy(pin + o + a, src + o + a, b - a); });
+            }
+            memcpy(pin + o, src + o, t_n > 1 ? pb / t_n : pb);
+            for (auto &x : th) x.join();
+            hipMemcpyAsync(dev + o, pin + o, pb, hipMemcpyHostToDevice, copy);
+        }
+        hipEventRecord(up, copy);
+    });
+}
+
+static int feed_wait(lfdmi_ctx *ctx, int slot) {
+    if (ctx->feed_thread[slot].joinable()) ctx->feed_thread[slot].join();
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->feed_up[slot], 0));
+    return 0;
+}
+
 extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w, const lfdmi_catalog *cat,
                                   const lfdmi_rs_params *rs, const lfdmi_params *bright, const lfdmi_params *dim,
                                   lfdmi_result *results, int loc) {
@@ -1429,10 +1560,28 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
     std::vector<int4> boxes;
     struct KeepEqu { lfdmi_ctx *c; bool old; KeepEqu(lfdmi_ctx *c_, bool v) : c(c_), old(c_->keep_equ) { c->keep_equ = v; } ~KeepEqu() { c->keep_equ = old; } }
         keep_guard(ctx, ctx->want_stage_images);
-    for (int c0 = 0; c0 < n; c0 += ctx->G) {
-        int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
+    // Host frames: chunks of up to ~feed_chunk_bytes (and at most G frames) go through the pinned double buffer
+    // (feed_* above), chunk k+1 uploading while chunk k is processed.  Device frames (LFDMI_FEED_MB=0, tiny batches):
+    // chunks of G frames, used in place / staged by the runtime.
+    int per = ctx->G;
+    const bool feed = loc == LFDMI_HOST && ctx->feed_chunk_bytes > 0 && (size_t)n * N * 4 >= (64u << 20);
+    if (feed) {
+        size_t fpc = ctx->feed_chunk_bytes / (N * 4);
+        per = (int)std::min<size_t>((size_t)ctx->G, std::max<size_t>(1, fpc));
+        RET(feed_prepare(ctx, (size_t)std::min(per, n) * N * 4));
+        feed_chunk_async(ctx, 0, (const char *)frames, (size_t)std::min(per, n) * N * 4);
+        if (per < n) feed_chunk_async(ctx, 1, (const char *)frames + (size_t)per * N * 4, (size_t)std::min(per, n - per) * N * 4);
+    }
+    std::thread blotter; // remove_stars on the caller's host array (see blot_host_frames)
+    struct FeedJoin { lfdmi_ctx *c; std::thread *b; ~FeedJoin() { for (auto &t : c->feed_thread) if (t.joinable()) t.join(); if (b->joinable()) b->join(); } }
+        feed_join{ctx, &blotter}; // (every exit path)
+    for (int c0 = 0, kc = 0; c0 < n; c0 += per, kc++) {
+        int nc = n - c0 < per ? n - c0 : per;
         const void *d;
-        RET(in_ptr(ctx, frames, (size_t)c0 * N * 4, (size_t)nc * N * 4, loc, &d));
+        if (feed) {
+            d = ctx->feed_dev[kc & 1];
+            RET(feed_wait(ctx, kc & 1)); // the launch stream waits for chunk kc's upload (chunk kc + 1 follows it back to back)
+        } else RET(in_ptr(ctx, frames, (size_t)c0 * N * 4, (size_t)nc * N * 4, loc, &d));
         const bool host_blot = cat && loc == LFDMI_HOST && cat->loc == LFDMI_HOST;
         if (cat) {
             RET(run_removestars(ctx, (float *)d, c0, nc, h, w, cat, rs, host_blot ? &boxes : nullptr));
@@ -1449,8 +1598,9 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
         ctx->cur_pass = 1;
         RET(run_pass(ctx, d, LFDMI_F32, nc, h, w, 1, LFDMI_PREP_BRIGHT_THEN_DIM, true, dim, ctx->need_dim, nullptr));
         ctx->cur_pass = 0;
-        if (host_blot && !blotted) { // host threads zero-fill the caller's frames while the GPU works through the passes
-            blot_host_frames(frames + (size_t)c0 * N, nc, h, w, cat, c0, boxes);
+        if (host_blot && !blotted) { // host threads zero-fill the caller's frames in the background (joined below / at the end)
+            if (blotter.joinable()) blotter.join();
+            blotter = std::thread([=, bx = boxes] { blot_host_frames(frames + (size_t)c0 * N, nc, h, w, cat, c0, bx); });
             blotted = true;
         }
         HIPCHK(hipMemcpyAsync(host.data(), ctx->res_dev, (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
@@ -1463,12 +1613,17 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
             for (int i = 0; i < nc; i++) { nd[0] += flags[i] & 1; na[1] += (flags[i] >> 1) & 1; nd[1] += (flags[i] >> 2) & 1; }
             RET(sync(ctx, nc, na, nd));
         }
+        if (feed && c0 + 2 * per < n) { // this chunk's two buffers are free again (its upload and passes are done): chunk kc + 2 starts
+            int nn = std::min(per, n - (c0 + 2 * per));
+            feed_chunk_async(ctx, kc & 1, (const char *)frames + (size_t)(c0 + 2 * per) * N * 4, (size_t)nn * N * 4);
+        }
         for (int i = 0; i < nc; i++) {
             if (host[i].status == LFDMI_ERR_CAPACITY) {
                 // a table of this workspace was too small for the frame: once more, alone, in the worst-case workspace.
                 // remove_stars has already blotted the frame (device copy and, by now, the caller's array): no catalogue.
                 lfdmi_ctx *sp = get_spill(ctx);
                 if (sp) {
+                    if (blotter.joinable()) blotter.join(); // (a host frame is read again below: its blotting must be complete)
                     int rc = lfdmi_detect_batch(sp, frames + (size_t)(c0 + i) * N, 1, h, w, nullptr, nullptr, bright, dim, &results[c0 + i], loc);
                     if (rc) { ctx->err = sp->err; return rc; }
                     ctx->n_spilled++;

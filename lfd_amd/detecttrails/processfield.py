@@ -181,13 +181,17 @@ def _dump_debug(ctx, shape, tag, path, detection, equhough, boxhough, nlines):
 
 
 def process_field_bright(img, lwTresh, thetaTresh, dilateKernel, contoursMode, contoursMethod,
-                         minAreaRectMinLen, houghMethod, nlinesInSet, lineSetTresh, dro, debug):
+                         minAreaRectMinLen, houghMethod, nlinesInSet, lineSetTresh, dro, debug,
+                         gaussKernel=0, gaussSigma=0.0):
     """Bright-trail pass (reference: processfield.py:291-388).
 
     ``img`` is clamped at zero IN PLACE (``img[img < 0] = 0``), converted to 8 bit, equalised,
     dilated, screened with minimum-area rectangles and, if any rectangle qualifies, fitted with
     Hough lines on the dilated image and on the rectangle image; colinear line sets give
     ``(True, {"x1":..,"y1":..,"x2":..,"y2":..})``, anything else ``(False, None)``.
+
+    ``gaussKernel`` / ``gaussSigma`` are not reference parameters: an optional Gaussian smoothing of Canny's input
+    (odd kernel size, 0 = off = the reference's behaviour; cv2.Canny has no smoothing stage).
     """
     img[img < 0] = 0
     dev_img = _as_native_image(img)
@@ -195,7 +199,8 @@ def process_field_bright(img, lwTresh, thetaTresh, dilateKernel, contoursMode, c
     params = dict(lwTresh=lwTresh, thetaTresh=thetaTresh, dilateKernel=dilateKernel,
                   contoursMode=contoursMode, contoursMethod=contoursMethod,
                   minAreaRectMinLen=minAreaRectMinLen, houghMethod=houghMethod,
-                  nlinesInSet=nlinesInSet, lineSetTresh=lineSetTresh, dro=dro)
+                  nlinesInSet=nlinesInSet, lineSetTresh=lineSetTresh, dro=dro,
+                  gaussKernel=gaussKernel, gaussSigma=gaussSigma)
     res, le, lb = ctx.process_bright(dev_img, params)
     return _finish(ctx, res, le, lb, tuple(dev_img.shape), nlinesInSet, dro, thetaTresh, lineSetTresh, debug,
                    "BRIGHT", pathBright)
@@ -203,7 +208,7 @@ def process_field_bright(img, lwTresh, thetaTresh, dilateKernel, contoursMode, c
 
 def process_field_dim(img, minFlux, addFlux, lwTresh, thetaTresh, erodeKernel, dilateKernel,
                       contoursMode, contoursMethod, minAreaRectMinLen, houghMethod, nlinesInSet,
-                      dro, lineSetTresh, debug):
+                      dro, lineSetTresh, debug, gaussKernel=0, gaussSigma=0.0):
     """Dim-trail pass (reference: processfield.py:391-506).
 
     IN PLACE: ``img[img < minFlux] = 0; img[img > 0] += addFlux``.  Then 8-bit conversion,
@@ -224,7 +229,8 @@ def process_field_dim(img, minFlux, addFlux, lwTresh, thetaTresh, erodeKernel, d
     params = dict(minFlux=minFlux, addFlux=addFlux, lwTresh=lwTresh, thetaTresh=thetaTresh,
                   erodeKernel=erodeKernel, dilateKernel=dilateKernel, contoursMode=contoursMode,
                   contoursMethod=contoursMethod, minAreaRectMinLen=minAreaRectMinLen,
-                  houghMethod=houghMethod, nlinesInSet=nlinesInSet, lineSetTresh=lineSetTresh, dro=dro)
+                  houghMethod=houghMethod, nlinesInSet=nlinesInSet, lineSetTresh=lineSetTresh, dro=dro,
+                  gaussKernel=gaussKernel, gaussSigma=gaussSigma)
     # the device applies the same masking to the untouched copy (PREP_DIM)
     res, le, lb = ctx.process_dim(gpu_src, params, after_bright=False)
     return _finish(ctx, res, le, lb, tuple(gpu_src.shape), nlinesInSet, dro, thetaTresh, lineSetTresh, debug,

@@ -663,21 +663,82 @@ int lfo_fill_poly(uint8_t *img, int h, int w, const int32_t *v, int npts, uint8_
     return 0;
 }
 
-/* processfield.py:201-263 */
+/* Optional Gaussian smoothing of Canny's input (off by default; no reference call site: see lfd_oracle.h) */
+int lfo_gaussian_kernel(int n, double sigma, float *cf) {
+    static const float small_tab[4][7] = {{1.f}, {0.25f, 0.5f, 0.25f}, {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
+                                          {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f}};
+    if (n <= 0 || n > 31 || (n & 1) == 0) return -1;
+    const float *fixed = (n <= 7 && sigma <= 0) ? small_tab[n >> 1] : 0;
+    double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    double scale2X = -0.5 / (sigmaX * sigmaX), sum = 0;
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        double t = fixed ? (double)fixed[i] : exp(scale2X * x * x);
+        cf[i] = (float)t;
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) cf[i] = (float)(cf[i] * sum);
+    return 0;
+}
+
+static int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+int lfo_gaussian_blur(const uint8_t *src, int h, int w, int ksize, double sigma, uint8_t *dst) {
+    float cf[32];
+    if (lfo_gaussian_kernel(ksize, sigma, cf)) return -1;
+    int r = ksize / 2;
+    float *tmp = (float *)malloc((size_t)h * w * sizeof(float));
+    if (!tmp) return -1;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float acc = 0.f;
+            for (int k = 0; k < ksize; k++) acc = acc + (float)src[(size_t)y * w + reflect101(x + k - r, w)] * cf[k];
+            tmp[(size_t)y * w + x] = acc;
+        }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float acc = 0.f;
+            for (int k = 0; k < ksize; k++) acc = acc + tmp[(size_t)reflect101(y + k - r, h) * w + x] * cf[k];
+            dst[(size_t)y * w + x] = sat_u8_from_f32(acc);
+        }
+    free(tmp);
+    return 0;
+}
+
 int lfo_fit_min_area_rect(const uint8_t *img, int h, int w, int contoursMode, int contoursMethod,
                           double minAreaRectMinLen, double lwTresh, uint8_t *box_img,
                           int32_t *detection, int32_t *n_boxes) {
+    return lfo_fit_min_area_rect_g(img, h, w, contoursMode, contoursMethod, minAreaRectMinLen, lwTresh, 0, 0., box_img, detection,
+                                   n_boxes);
+}
+
+/* processfield.py:201-263 (gaussKernel > 0: Canny sees the smoothed image; the reference never smooths) */
+int lfo_fit_min_area_rect_g(const uint8_t *img, int h, int w, int contoursMode, int contoursMethod,
+                            double minAreaRectMinLen, double lwTresh, int gaussKernel, double gaussSigma,
+                            uint8_t *box_img, int32_t *detection, int32_t *n_boxes) {
     size_t n = (size_t)h * w;
     uint8_t *canny = (uint8_t *)malloc(n);
+    uint8_t *smooth = 0;
+    if (gaussKernel > 0) {
+        smooth = (uint8_t *)malloc(n);
+        if (!smooth || !canny || lfo_gaussian_blur(img, h, w, gaussKernel, gaussSigma, smooth)) { free(smooth); free(canny); return -1; }
+        img = smooth;
+    }
     int32_t *pts = 0, *offs = 0, nc = 0;
     int det = 0, nb = 0;
     if (!canny) return -1;
     if (contoursMethod != LFO_CHAIN_APPROX_NONE && contoursMethod != LFO_CHAIN_APPROX_SIMPLE) {
-        free(canny);
+        free(canny); free(smooth);
         return -4; /* TC89 approximations change the point set: not restated */
     }
     memset(box_img, 0, n);
-    if (lfo_canny(img, h, w, 0, 255, canny)) { free(canny); return -1; }
+    if (lfo_canny(img, h, w, 0, 255, canny)) { free(canny); free(smooth); return -1; }
+    free(smooth);
     if (lfo_find_contours(canny, h, w, contoursMode, &pts, &offs, 0, &nc)) { free(canny); return -1; }
     for (int c = 0; c < nc; c++) {
         float rect[5];
@@ -909,8 +970,8 @@ int lfo_remove_stars(float *img, int h, int w, int n_obj, const float *rowc, con
 static int detect_tail(const uint8_t *equ, int h, int w, const lfo_params *p, lfo_result *res,
                        uint8_t *box_img, int which) {
     int32_t det = 0, nb = 0;
-    int rc = lfo_fit_min_area_rect(equ, h, w, p->contoursMode, p->contoursMethod,
-                                   p->minAreaRectMinLen, p->lwTresh, box_img, &det, &nb);
+    int rc = lfo_fit_min_area_rect_g(equ, h, w, p->contoursMode, p->contoursMethod, p->minAreaRectMinLen, p->lwTresh,
+                                     p->gaussKernel, p->gaussSigma, box_img, &det, &nb);
     if (rc) return rc;
     res->detection = det;
     res->rejected_by_theta = 0;

@@ -60,6 +60,9 @@ typedef struct {
     int erode_kh, erode_kw;      /* dim only; erodeKernel NULL for bright */
     const uint8_t *erodeKernel;
     double minFlux, addFlux;     /* dim only */
+    int gaussKernel;             /* optional smoothing of Canny's input: odd size of a cv2.GaussianBlur-like kernel, 0 = off
+                                    (the reference never smooths: cv2.Canny has no Gaussian stage, processfield.py:236) */
+    double gaussSigma;           /* <= 0: 0.3*((ksize-1)*0.5 - 1) + 0.8 */
 } lfo_params;
 
 typedef struct {
@@ -92,6 +95,15 @@ int lfo_morph(const uint8_t *src, int h, int w, const uint8_t *kernel, int kh, i
 int lfo_canny(const uint8_t *src, int h, int w, double low_thresh, double high_thresh,
               uint8_t *dst);
 int lfo_sobel_mag(const uint8_t *src, int h, int w, int16_t *dx, int16_t *dy, int32_t *mag);
+/* Optional Gaussian stage (BASELINE north_star lists one inside Canny; cv2.Canny has none, so it is OFF by default and has
+ * no reference call site).  Defined here as cv2.getGaussianKernel(ksize, sigma, CV_32F) applied separably (rows, then
+ * columns) in float32 with BORDER_REFLECT_101, accumulation in tap order without FMA, one final round-half-even +
+ * saturation.  OpenCV's own 8-bit path uses fixed-point taps since 3.4.1, so this is NOT claimed bit-equal to cv2. */
+int lfo_gaussian_kernel(int ksize, double sigma, float *taps);
+int lfo_gaussian_blur(const uint8_t *src, int h, int w, int ksize, double sigma, uint8_t *dst);
+int lfo_fit_min_area_rect_g(const uint8_t *img, int h, int w, int contoursMode, int contoursMethod,
+                            double minAreaRectMinLen, double lwTresh, int gaussKernel, double gaussSigma,
+                            uint8_t *box_img, int32_t *detection, int32_t *n_boxes);
 /* A.5: returns contours as a flat (x,y) int32 list + offsets[n+1]; caller frees with lfo_free */
 int lfo_find_contours(const uint8_t *img, int h, int w, int mode, int32_t **points,
                       int32_t **offsets, int32_t **is_hole, int32_t *n_contours);

@@ -33,7 +33,8 @@ class Params(C.Structure):
                 ("nlinesInSet", C.c_int), ("contoursMode", C.c_int), ("contoursMethod", C.c_int),
                 ("dilate_kh", C.c_int), ("dilate_kw", C.c_int), ("dilateKernel", C.c_void_p),
                 ("erode_kh", C.c_int), ("erode_kw", C.c_int), ("erodeKernel", C.c_void_p),
-                ("minFlux", C.c_double), ("addFlux", C.c_double)]
+                ("minFlux", C.c_double), ("addFlux", C.c_double),
+                ("gaussKernel", C.c_int), ("gaussSigma", C.c_double)]
 
 
 class Result(C.Structure):
@@ -152,6 +153,23 @@ def canny(src, low=0.0, high=255.0):
     if rc:
         raise RuntimeError(f"lfo_canny rc={rc}")
     return out
+
+
+def gaussian_blur(src, ksize, sigma=0.0):
+    """The optional smoothing stage as this build defines it (see lfd_oracle.h; not a cv2 parity claim)."""
+    src = _u8(src)
+    out = np.empty_like(src)
+    rc = lib().lfo_gaussian_blur(_p(src), src.shape[0], src.shape[1], int(ksize), C.c_double(sigma), _p(out))
+    if rc:
+        raise RuntimeError(f"lfo_gaussian_blur rc={rc}")
+    return out
+
+
+def gaussian_kernel(ksize, sigma=0.0):
+    taps = np.zeros(32, np.float32)
+    if lib().lfo_gaussian_kernel(int(ksize), C.c_double(sigma), _p(taps)):
+        raise ValueError("ksize must be odd, 1..31")
+    return taps[:ksize].copy()
 
 
 def find_contours(img, mode=RETR_LIST):
@@ -324,6 +342,8 @@ def make_params(d, dim=False):
         p.erodeKernel = ek.ctypes.data
         p.minFlux = d["minFlux"]
         p.addFlux = d["addFlux"]
+    p.gaussKernel = int(d.get("gaussKernel", 0) or 0)
+    p.gaussSigma = float(d.get("gaussSigma", 0.0) or 0.0)
     return _Keep(p, keep)
 
 

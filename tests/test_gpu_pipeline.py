@@ -334,3 +334,35 @@ def test_host_frames_are_blotted_in_place_without_a_copy_back(oracle):
         assert same(res[i], want)
         assert np.array_equal(batch[i], ref)
     ctx.close()
+
+
+def test_host_feed_ring_keeps_rows_order_and_blotting(oracle, monkeypatch):
+    """Host frames go through the pinned double buffer of lfdmi_detect_batch (chunk k+1 uploads while chunk k is
+    processed).  With LFDMI_FEED_MB=30 a chunk is two SDSS frames, so nine frames take five chunks and every buffer is
+    reused: records, their order and the in-place blotting equal the device-resident run and the oracle."""
+    import torch
+    from lfd_amd import _native, synth
+    pb, pd, prs = params()
+    rs_g, rs_o = rs_pair(oracle, prs)
+    ks = list(range(60, 69))
+    frames, cats = zip(*[synth.make_frame(k)[:2] for k in ks])
+    packed = synth.pack_catalogs(list(cats))
+    d = torch.from_numpy(np.stack(frames)).cuda()
+    dcat = {k: torch.from_numpy(v).cuda() for k, v in packed.items()}
+    torch.cuda.synchronize()
+    with _native.Context(0, 1489, 2048, 9) as ctx:
+        ref = ctx.detect_batch(d, pb, pd, dcat, rs_g)
+    blotted = d.cpu().numpy()
+    for feed_mb in ("30", "0", None):
+        if feed_mb is None:
+            monkeypatch.delenv("LFDMI_FEED_MB", raising=False)
+        else:
+            monkeypatch.setenv("LFDMI_FEED_MB", feed_mb)
+        batch = np.stack(frames)
+        with _native.Context(0, 1489, 2048, 4) as ctx:
+            res = ctx.detect_batch(batch, pb, pd, packed, rs_g)
+            res2 = ctx.detect_batch(np.stack(frames), pb, pd, packed, rs_g)      # buffers reused by a second call
+        assert res.tobytes() == ref.tobytes() == res2.tobytes(), feed_mb
+        assert np.array_equal(batch, blotted), feed_mb
+    for i in (0, 4, 8):
+        assert same(ref[i], oracle.detect_frame(frames[i].copy(), pb, pd, cats[i], rs_o))

@@ -135,7 +135,7 @@ def test_fit_min_area_rect_dense_nested_contours(gpu_ctx, oracle):
 def test_unsupported_contour_knobs_raise(gpu_ctx):
     from lfd_amd import _native
     img = np.zeros((32, 32), np.uint8)
-    for mode, method in ((0, 1), (1, 3), (1, 4)):
+    for mode, method in ((7, 1), (1, 3), (1, 4)):          # the TC89 approximations change the point set: not restated
         with pytest.raises(_native.NativeError) as e:
             gpu_ctx.fit_min_area_rect(img, mode, method)
         assert e.value.code == _native.ERR_UNSUPPORTED
@@ -208,3 +208,28 @@ def test_remove_stars(gpu_ctx, oracle):
         again = batch.copy()
         gpu_ctx.remove_stars(again, synth.pack_catalogs(cats), _native.make_rs_params(flt, **kw))
         assert np.array_equal(again, batch)                  # idempotent
+
+
+def test_optional_gaussian_stage(gpu_ctx, oracle):
+    """The Gaussian smoothing north_star lists inside Canny -- off by default, because cv2.Canny has none
+    (processfield.py:236): the operator against the oracle's definition, and a pass with gaussKernel set."""
+    rng = np.random.default_rng(11)
+    for shape in ((40, 50), (97, 131), (64, 256), (5, 3)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        for ksize, sigma in ((1, 0), (3, 0), (5, 0), (7, 0), (9, 0), (5, 1.7), (15, 3.0), (31, 0)):
+            assert np.array_equal(gpu_ctx.gaussian_blur(img, ksize, sigma), oracle.gaussian_blur(img, ksize, sigma)), (shape, ksize, sigma)
+    batch = rng.integers(0, 256, (3, 33, 70), dtype=np.uint8)
+    out = gpu_ctx.gaussian_blur(batch, 5)
+    for i in range(3):
+        assert np.array_equal(out[i], oracle.gaussian_blur(batch[i], 5))
+    from lfd_amd import synth
+    from lfd_amd.detecttrails import default_params
+    pb, pd, _ = default_params()
+    img = synth.make_frame(0, with_catalog=False)[0][::-1].copy()
+    for p, fn_g, fn_o in ((dict(pb, gaussKernel=5), gpu_ctx.process_bright, oracle.process_bright),
+                          (dict(pd, gaussKernel=3, gaussSigma=1.0), gpu_ctx.process_dim, oracle.process_dim)):
+        res = fn_g(img, p)[0]
+        want = fn_o(img, p)
+        assert all(res[k].item() == v for k, v in want.items()), (want, res)
+    off = gpu_ctx.process_bright(img, pb)[0]
+    assert off.tobytes() == gpu_ctx.process_bright(img, dict(pb, gaussKernel=0))[0].tobytes()

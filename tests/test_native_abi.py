@@ -37,7 +37,7 @@ def test_struct_layouts():
     from lfd_amd import _native
     assert C.sizeof(_native.Result) == 48 == _native.RESULT_DTYPE.itemsize
     assert [n for n, _ in _native.Result._fields_] == list(_native.RESULT_DTYPE.names)
-    assert C.sizeof(_native.Params) == 6 * 8 + 3 * 4 + 2 * 4 + 8 + 2 * 4 + 8 + 2 * 8 + 4  # with padding
+    assert C.sizeof(_native.Params) == 6 * 8 + 3 * 4 + 2 * 4 + 8 + 2 * 4 + 8 + 2 * 8 + 4 + 4 + 4 + 8  # with padding
     assert C.sizeof(_native.RsParams) == 48 and C.sizeof(_native.Catalog) == 72
     assert C.sizeof(_native.Caps) == 32
     c = _native.Caps()
