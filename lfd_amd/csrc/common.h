@@ -24,6 +24,7 @@ enum {
     C_NMED = 14,     // keys of medium height (one wave each, small LDS footprint)
     C_NNZ_EQU = 15,  // non-zero pixels of equ (180 Hough votes each)
     C_NNZ_BOX = 16,  // non-zero pixels of box_img
+    C_NTILES = 17,   // 64 x 16 tiles of the pass image with anything in reach (work list of k_dilate_canny_t)
     C_COUNT = 20
 };
 

@@ -950,6 +950,61 @@ k_dilate_canny_v(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
 #define DCW_MAXS 8            // tiles per strip (one wave walks a strip left to right)
 static_assert(DCW_TH == CELLBM_ROWS && CANNY_TW == 4 * CELLBM_COLS, "a tile is one band high and four cells wide");
 
+// ---- SWAR helpers of the wave kernels: four pixels as two packed-u16 pairs (E = bytes 0, 2; O = bytes 1, 3) ----
+typedef unsigned short dcw_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dcw_pkmax(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(dcw_us2, a), __builtin_bit_cast(dcw_us2, b)));
+}
+// (E, O)[i] <- max((E, O)[i], the same bytes S positions further right), for words 0 .. nw-1 of a split byte row.
+// Byte x + S of a split row: S = 4k: word i + k; S = 4k + 1: E' = O[i+k], O' = (E[i+k] >> 16 | E[i+k+1] << 16); ...
+template <int S, int NWT>
+__device__ __forceinline__ void dcw_shift_max(uint32_t (&E)[NWT], uint32_t (&O)[NWT], int nw) {
+    constexpr int K = S / 4, R = S % 4;
+#pragma unroll
+    for (int i = 0; i < NWT; i++) {
+        if (i >= nw || i + K + 1 >= NWT) continue;
+        uint32_t e2, o2;
+        if constexpr (R == 0) { e2 = E[i + K]; o2 = O[i + K]; }
+        else if constexpr (R == 1) { e2 = O[i + K]; o2 = __builtin_amdgcn_alignbyte(E[i + K + 1], E[i + K], 2); }
+        else if constexpr (R == 2) { e2 = __builtin_amdgcn_alignbyte(E[i + K + 1], E[i + K], 2); o2 = __builtin_amdgcn_alignbyte(O[i + K + 1], O[i + K], 2); }
+        else { e2 = __builtin_amdgcn_alignbyte(O[i + K + 1], O[i + K], 2); o2 = E[i + K + 1]; }
+        E[i] = dcw_pkmax(E[i], e2);
+        O[i] = dcw_pkmax(O[i], o2);
+    }
+}
+// max over the KW bytes starting at each of the four pixels of output word jj of a staged row (the window of pixel q
+// starts at staged byte CANNY_MOFF - KW/2 + 4 jj + q): running maxima over windows of 1, 2, 4, ... bytes, then
+// max(m_p[x], m_p[x + KW - p]) for the largest power of two p <= KW -- ~3 packed instructions per doubling step and
+// word instead of ~6 per tap.
+template <int KW>
+__device__ __forceinline__ uint32_t dcw_hmax(const uint32_t *rw, int jj) {
+    constexpr int AX = KW / 2, R0 = (CANNY_MOFF - AX) & 3, Q0 = (CANNY_MOFF - AX) >> 2;
+    constexpr int NB = KW + 3, NW = (NB + 3) / 4, NR = (R0 + NB + 3) / 4, NWT = NW + 9;
+    uint32_t raw[NR + 1];
+#pragma unroll
+    for (int i = 0; i < NR; i++) raw[i] = rw[Q0 + jj + i];
+    raw[NR] = 0;
+    uint32_t E[NWT], O[NWT];
+#pragma unroll
+    for (int i = 0; i < NWT; i++) {
+        uint32_t a = 0;
+        if (i < NW) a = R0 ? __builtin_amdgcn_alignbyte(raw[i + 1 <= NR ? i + 1 : NR], raw[i], R0) : raw[i];
+        E[i] = a & 0x00FF00FFu;
+        O[i] = (a >> 8) & 0x00FF00FFu;
+    }
+    constexpr int P = KW >= 16 ? 16 : (KW >= 8 ? 8 : (KW >= 4 ? 4 : (KW >= 2 ? 2 : 1))), D = KW - P;
+    // words each step still has to produce (bytes needed by the steps after it)
+    constexpr int need1 = 4 + D + (P > 8 ? 8 : 0) + (P > 4 ? 4 : 0) + (P > 2 ? 2 : 0);
+    if constexpr (P >= 2) dcw_shift_max<1, NWT>(E, O, (need1 + 3) / 4);
+    constexpr int need2 = need1 - 2;
+    if constexpr (P >= 4) dcw_shift_max<2, NWT>(E, O, (need2 + 3) / 4);
+    constexpr int need4 = need2 - 4;
+    if constexpr (P >= 8) dcw_shift_max<4, NWT>(E, O, (need4 + 3) / 4);
+    if constexpr (P >= 16) dcw_shift_max<8, NWT>(E, O, (4 + D + 3) / 4);
+    if constexpr (D > 0) dcw_shift_max<D, NWT>(E, O, 1);
+    return E[0] | (O[0] << 8);
+}
+
 template <class F>
 __device__ __forceinline__ void dcw_for_live(u64 live, uint32_t colmask, int lane, F f) {
     int r = lane & 31;
@@ -1085,210 +1140,220 @@ k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
             }
             continue;
         }
-        __syncthreads();
-        // ---- background fill of px, activity masks
-#pragma unroll
-        for (int p = 0; p < 3; p++)
-            if (lane + 64 * p < PH * (TS / 16)) ((uint4 *)px)[lane + 64 * p] = make_uint4(zw, zw, zw, zw);
-        if (lane < DCW_TH) { rowc[lane] = 0ull; rows[lane] = 0ull; }
-        uint32_t hp = 0, vm = 0, A = 0;
-        if (lane < NWD) {
-            int o = CANNY_MOFF - ax + 4 * lane;           // window bytes o .. o + kw + 2 of the staged row
-            uint32_t h0 = 0;
-            for (int p = o >> 4; p <= (o + kw + 2) >> 4; p++) h0 |= Pm[p];
-            for (int dy = 0; dy < kh; dy++) vm |= h0 >> dy; // dilated row dr reads input rows dr .. dr+kh-1
-            vm &= mPH;
-            for (int dy = 0; dy < kh; dy++) hp |= vm << dy; // rows of the horizontal pass the live outputs read
-            hp &= mIH;
-            A = vm;
-            // rows outside the image replicate the first / last image row
-            if (y0 == 0 && ((A >> 2) & 1)) A |= 3u;
-            int drl = h - 1 - y0 + 2;
-            if (drl < PH - 1 && ((A >> drl) & 1)) A |= (~0u << (drl + 1)) & mPH;
-        }
-        // columns outside the image replicate the first / last image column
-        {
-            uint32_t A1 = (uint32_t)__shfl((int)A, 1);
-            if (x0 == 0 && lane == 0) A |= A1;
-            bool right = x0 + CANNY_TW >= w;
-            int jlast = (w - x0) >> 2; // word column of the last image column (<= 16 when `right`)
-            uint32_t Al = (uint32_t)__shfl((int)A, right ? jlast : 0);
-            if (right && lane > jlast && lane < NWD) A |= Al;
-        }
-        // the Sobel magnitude can be non-zero where a 3x3 word neighbourhood holds a non-background word
-        uint32_t M;
-        {
-            uint32_t Au = (uint32_t)__shfl((int)A, lane > 0 ? lane - 1 : 0), Ad = (uint32_t)__shfl((int)A, lane + 1);
-            uint32_t Ax = A | (lane > 0 ? Au : 0u) | (lane + 1 < NWD ? Ad : 0u);
-            M = (Ax | (Ax >> 1) | (Ax >> 2)) & mMH;      // magnitude row my reads px rows my .. my+2
-            if (lane >= NWD) M = 0;
-        }
-        uint32_t Mn = (lane >= 1 && lane <= 16) ? (M & 0x1FFFEu) : 0u; // NMS items: the tile's own rows and columns
-        uint32_t rowA = (lane >= 1 && lane <= 16) ? A : 0u;
-        for (int off = 16; off > 0; off >>= 1) rowA |= (uint32_t)__shfl_xor((int)rowA, off);
-        const u64 LH = __ballot(hp != 0), LV = __ballot(vm != 0), LM = __ballot(M != 0), LN = __ballot(Mn != 0);
-        __syncthreads();
-        // ---- horizontal max of the live words
-        dcw_for_live(LH, hp, lane, [&](int ry, int jj) {
-            uint32_t aE = 0, aO = 0;
-            int o = CANNY_MOFF - ax + 4 * jj; // byte offset of the window's first column
-            const uint32_t *rw = (const uint32_t *)(tin + ry * TS);
-            int qi = o >> 2;
-            uint32_t lo = rw[qi], hi = rw[qi + 1];
-            for (int dx = 0; dx < kw; dx++, o++) {
-                if ((o >> 2) != qi) { qi = o >> 2; lo = hi; hi = rw[qi + 1]; }
-                uint32_t sft = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o & 3));
-                us2 e = __builtin_bit_cast(us2, sft & 0x00FF00FFu), od = __builtin_bit_cast(us2, (sft >> 8) & 0x00FF00FFu);
-                aE = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aE), e));
-                aO = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aO), od));
-            }
-            tmp[ry * NWD + jj] = aE | (aO << 8);
-        });
-        __syncthreads();
-        // tin is dead: clear the masks of the next tile and the magnitude plane that aliases tin
-        if (lane < 8) Pm[lane] = 0u;
-#pragma unroll
-        for (int p = 0; p < 3; p++)
-            if (lane + 64 * p < MGB / 16) ((uint4 *)mg)[lane + 64 * p] = make_uint4(0, 0, 0, 0);
-        // ---- vertical max + LUT of the live words
-        dcw_for_live(LV, vm, lane, [&](int dr, int jj) {
-            uint32_t aE = 0, aO = 0;
-            for (int dy = 0; dy < kh; dy++) {
-                uint32_t t = tmp[(dr + dy) * NWD + jj];
-                aE = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aE), __builtin_bit_cast(us2, t & 0x00FF00FFu)));
-                aO = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, aO), __builtin_bit_cast(us2, (t >> 8) & 0x00FF00FFu)));
-            }
-            uint32_t word = aE | (aO << 8);
-            word = (uint32_t)slut[word & 0xff] | ((uint32_t)slut[(word >> 8) & 0xff] << 8) |
-                   ((uint32_t)slut[(word >> 16) & 0xff] << 16) | ((uint32_t)slut[word >> 24] << 24);
-            ((uint32_t *)px)[dr * TSW + 3 + jj] = word;
-        });
-        __syncthreads();
-        // ---- ring positions outside the image replicate the dilated image's border: columns, then rows
-        {
-            bool left = x0 == 0, right = x0 + CANNY_TW >= w;
-            if (left || right) {
-                if (lane < PH) {
-                    uint32_t *pr = (uint32_t *)(px + lane * TS);
-                    if (left) pr[3] = 0x01010101u * px[lane * TS + CANNY_HALO];
-                    if (right) {
-                        int cl = CANNY_HALO + (w - x0) - 1; // staged byte of the last image column
-                        uint32_t e = 0x01010101u * px[lane * TS + cl];
-                        for (int wd = (cl + 1) >> 2; wd <= 20; wd++) pr[wd] = e;
-                    }
-                }
-                __syncthreads();
-            }
-            int drl = h - 1 - y0 + 2; // dilated row of the last image row
-            bool top = y0 == 0, bot = drl < PH - 1;
-            if (top || bot) {
-                uint32_t *pw32 = (uint32_t *)px;
-                if (top && lane < 2 * NWD) {
-                    int r = lane / NWD, jj = lane - r * NWD;
-                    pw32[r * TSW + 3 + jj] = pw32[2 * TSW + 3 + jj];
-                }
-                if (bot)
-                    for (int idx = lane; idx < (PH - 1 - drl) * NWD; idx += 64) {
-                        int r = idx / NWD, jj = idx - r * NWD;
-                        pw32[(drl + 1 + r) * TSW + 3 + jj] = pw32[drl * TSW + 3 + jj];
-                    }
-                __syncthreads();
-            }
-        }
-        // ---- the tile proper: equ (optional) and its != 0 bit row
-        if (d) {
-            int row = lane >> 2, c16 = lane & 3;
-            int gy = y0 + row, gx = x0 + 16 * c16;
-            if (gy < h && gx < w) *(uint4 *)(d + (size_t)gy * w + gx) = *(const uint4 *)(px + (row + 2) * TS + CANNY_HALO + 16 * c16);
-        }
-        {
-            u64 mine = 0ull;
-            uint32_t live = zw ? 0xFFFFu : ((rowA >> 2) & 0xFFFFu); // rows that can hold a non-zero pixel
-            live = __builtin_amdgcn_readfirstlane(live);
-            while (live) {
-                int oy = __ffs((int)live) - 1;
-                live &= live - 1;
-                u64 bal = __ballot(x0 + lane < w && px[(oy + 2) * TS + CANNY_HALO + lane] != 0);
-                if (lane == oy) mine = bal;
-            }
-            if (lane < DCW_TH && y0 + lane < h) equb[(size_t)g * h * wq + (size_t)(y0 + lane) * wq + tx] = mine;
-        }
-        // ---- Sobel + L1 magnitude + NMS sector of the live words -> (m << 2 | sector) as ushort
-        dcw_for_live(LM, M, lane, [&](int my, int k) {
-            int gy = y0 - 1 + my;
-            uint32_t o01 = 0, o23 = 0;
-            if (gy >= 0 && gy < h) {
-                int b[3][6]; // bytes -1..4 around the word, for the three rows
-#pragma unroll
-                for (int r = 0; r < 3; r++) {
-                    const uint32_t *rw = (const uint32_t *)(px + (my + r) * TS) + 3 + k;
-                    uint32_t wm = rw[-1], wc = rw[0], wp = rw[1];
-                    b[r][0] = wm >> 24; b[r][1] = wc & 0xff; b[r][2] = (wc >> 8) & 0xff;
-                    b[r][3] = (wc >> 16) & 0xff; b[r][4] = wc >> 24; b[r][5] = wp & 0xff;
-                }
-                int cs[6], rd[6]; // column sums r0 + 2 r1 + r2 and row differences r2 - r0
-#pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    cs[c] = b[0][c] + 2 * b[1][c] + b[2][c];
-                    rd[c] = b[2][c] - b[0][c];
-                }
-                uint32_t pk[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    int gx = x0 - 4 + 4 * k + q;
-                    int dx = cs[q + 2] - cs[q];
-                    int dy = rd[q] + 2 * rd[q + 1] + rd[q + 2];
-                    int adx = abs(dx), ady = abs(dy) << 15;
-                    int tg22x = adx * 13573;
-                    uint32_t sec = ady < tg22x ? 0u : (ady > tg22x + (adx << 16) ? 1u : (((dx ^ dy) < 0) ? 3u : 2u));
-                    uint32_t m = (uint32_t)(abs(dx) + abs(dy));
-                    pk[q] = (gx >= 0 && gx < w) ? ((m << 2) | sec) : 0u;
-                }
-                o01 = pk[0] | (pk[1] << 16);
-                o23 = pk[2] | (pk[3] << 16);
-            }
-            *(uint2 *)(mg + my * CANNY_MW + 4 * k) = make_uint2(o01, o23);
-        });
-        __syncthreads();
-        // ---- non-maximum suppression of the live words of the tile
-        dcw_for_live(LN, Mn, lane, [&](int my, int k) {
-            // ushorts 4k-2 .. 4k+5 of the three rows (pixel q of the word sits at index q + 2)
-            uint32_t u[3][4];
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const uint32_t *rp = (const uint32_t *)(mg + (my - 1 + r) * CANNY_MW + 4 * k - 2);
-                u[r][0] = rp[0]; u[r][1] = rp[1]; u[r][2] = rp[2]; u[r][3] = rp[3];
-            }
-            auto val = [&](int r, int i) -> int { uint32_t x = u[r][i >> 1]; return (int)((i & 1) ? (x >> 16) : (x & 0xffffu)); };
-            uint32_t cb = 0, sb = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                int vv = val(1, q + 2), m = vv >> 2, sec = vv & 3;
-                if (m > low) {
-                    int a, bb;
-                    bool strict_b;
-                    if (sec == 0) { a = val(1, q + 1) >> 2; bb = val(1, q + 3) >> 2; strict_b = false; }
-                    else if (sec == 1) { a = val(0, q + 2) >> 2; bb = val(2, q + 2) >> 2; strict_b = false; }
-                    else if (sec == 2) { a = val(0, q + 1) >> 2; bb = val(2, q + 3) >> 2; strict_b = true; }
-                    else { a = val(0, q + 3) >> 2; bb = val(2, q + 1) >> 2; strict_b = true; }
-                    bool keep = (m > a) && (strict_b ? (m > bb) : (m >= bb));
-                    if (keep) {
-                        cb |= 1u << q;
-                        if (m > high) sb |= 1u << q;
-                    }
-                }
-            }
-            if (cb) atomicOr((unsigned long long *)&rowc[my - 1], (u64)cb << (4 * (k - 1)));
-            if (sb) atomicOr((unsigned long long *)&rows[my - 1], (u64)sb << (4 * (k - 1)));
-        });
-        __syncthreads();
-        if (lane < DCW_TH && y0 + lane < h) {
-            size_t o = (size_t)g * h * wq + (size_t)(y0 + lane) * wq + tx;
-            cand[o] = rowc[lane];
-            strong[o] = rows[lane];
-        }
+#define DCW_STAMP(k)
+        constexpr int DCW_KHC = 0, DCW_KWC = 0; // (structuring element size only known at run time here)
+#include "k_dcw_tile.inc"
+#undef DCW_STAMP
     }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same fused stages driven by a list of ACTIVE tiles.
+//
+// On sky frames 55-65 % of the 64 x 16 tiles have nothing within reach (their 6 x 3 cells of the occupancy bitmap are
+// clear), and a wave that walks a strip spends most of its time on them: three scattered 8-byte stores per row of every
+// empty tile, loop overhead, and waves whose strips are empty sit next to waves whose strips are full.  So:
+//   k_dc_tiles        one workgroup per frame turns the cell bitmap into the frame's list of active tiles (raster
+//                     order) and writes the BACKGROUND of the three output bit planes (equ != 0, candidates, strong)
+//                     for the whole frame with coalesced 16-byte stores;
+//   k_dilate_canny_t  `parts` waves per frame each take a contiguous share of the list and run the tile stages on
+//                     it (input of the next tile in flight while the current one is processed), overwriting the
+//                     words of their tiles.  Every wave has real work on every step.
+// Results are identical to k_dilate_canny_w (same per-tile code, k_dcw_tile.inc).
+// ------------------------------------------------------------------------------------------
+#define DCT_THREADS 1024
+#define DCT_MAXBANDS 512 // 8191 rows / 16
+
+__device__ __forceinline__ unsigned dct_cells(const u64 *m, int b0) { // bits b0 .. b0 + 5 of a 512-bit row mask (b0 may be -1)
+    int st = b0 < 0 ? 0 : b0, wi = st >> 6, sh = st & 63;
+    u64 f = m[wi] >> sh;
+    if (sh > 58 && wi + 1 < CELLBM_WORDS) f |= m[wi + 1] << (64 - sh);
+    if (b0 < 0) f <<= 1;
+    return (unsigned)(f & 0x3Full);
+}
+
+__global__ void __launch_bounds__(DCT_THREADS)
+k_dc_tiles(const u64 *cellbm, int bm_bands, const uint8_t *lut, int *tile_list, int tile_cap, int *counters, u64 *equb, u64 *cand,
+           u64 *strong, uint8_t *equ, int h, int w, const int *active) {
+    const int g = blockIdx.x;
+    if (active && !active[g]) return;
+    const int tiles_x = (w + CANNY_TW - 1) / CANNY_TW, tiles_y = (h + DCW_TH - 1) / DCW_TH;
+    __shared__ int band_off[DCT_MAXBANDS + 1];
+    __shared__ u64 band_mask[DCT_MAXBANDS][2];
+    __shared__ u64 rowm[DCT_THREADS / 64][CELLBM_WORDS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = DCT_THREADS / 64;
+    // ---- which tiles have an occupied cell within reach: cells 4 tx - 1 .. 4 tx + 4 of bands ty - 1 .. ty + 1
+    for (int ty = wv; ty < tiles_y; ty += nwv) {
+        if (lane < CELLBM_WORDS) {
+            u64 m = cellbm ? 0ull : ~0ull;
+            if (cellbm)
+                for (int b = ty - 1; b <= ty + 1; b++)
+                    if (b >= 0 && b < bm_bands) m |= cellbm[((size_t)g * bm_bands + b) * CELLBM_WORDS + lane];
+            rowm[wv][lane] = m;
+        }
+        __builtin_amdgcn_wave_barrier();
+        int n = 0;
+        for (int half = 0; half < 2; half++) {
+            int tx = lane + 64 * half;
+            bool on = tx < tiles_x && dct_cells(rowm[wv], 4 * tx - 1) != 0;
+            u64 bal = __ballot(on);
+            if (lane == 0) band_mask[ty][half] = bal;
+            n += __popcll(bal);
+        }
+        if (lane == 0) band_off[ty] = n;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if (wv == 0) { // exclusive scan of the band counts: 8 bands per lane, then across the wave
+        int v[DCT_MAXBANDS / 64], loc = 0;
+        for (int k = 0; k < DCT_MAXBANDS / 64; k++) {
+            int b = lane * (DCT_MAXBANDS / 64) + k;
+            v[k] = b < tiles_y ? band_off[b] : 0;
+            loc += v[k];
+        }
+        int inc = loc;
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        int run = inc - loc;
+        for (int k = 0; k < DCT_MAXBANDS / 64; k++) {
+            int b = lane * (DCT_MAXBANDS / 64) + k;
+            if (b < tiles_y) band_off[b] = run;
+            run += v[k];
+        }
+        if (lane == 63) { band_off[DCT_MAXBANDS] = inc; counters[g * C_COUNT + C_NTILES] = inc < tile_cap ? inc : tile_cap; }
+    }
+    __syncthreads();
+    int *tl = tile_list + (size_t)g * tile_cap;
+    for (int ty = wv; ty < tiles_y; ty += nwv) {
+        int o = band_off[ty];
+        for (int half = 0; half < 2; half++) {
+            u64 bal = band_mask[ty][half];
+            if ((bal >> lane) & 1ull) {
+                int k = o + __popcll(bal & ((1ull << lane) - 1ull));
+                if (k < tile_cap) tl[k] = (ty << 16) | (lane + 64 * half);
+            }
+            o += __popcll(bal);
+        }
+    }
+    // ---- background of the outputs: the dilated, equalised image is lut[0] wherever nothing is within reach
+    const unsigned z = lut ? lut[g * 256] : 0u;
+    const int wq = LFD_WQ(w);
+    const size_t BW = (size_t)h * wq;
+    u64 *pe = equb + (size_t)g * BW, *pc = cand + (size_t)g * BW, *ps = strong + (size_t)g * BW;
+    if (z == 0 && (BW & 1) == 0) {
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+        for (size_t i = threadIdx.x; i < BW / 2; i += DCT_THREADS) {
+            ((uint4 *)pe)[i] = zero; ((uint4 *)pc)[i] = zero; ((uint4 *)ps)[i] = zero;
+        }
+    } else {
+        for (size_t i = threadIdx.x; i < BW; i += DCT_THREADS) {
+            pe[i] = z ? valid_mask((int)(i % wq), w) : 0ull;
+            pc[i] = 0ull; ps[i] = 0ull;
+        }
+    }
+    if (equ) { // stage image requested: its background too
+        const unsigned zz = z * 0x01010101u;
+        uint4 *pq = (uint4 *)(equ + (size_t)g * h * w);
+        for (size_t i = threadIdx.x; i < (size_t)h * w / 16; i += DCT_THREADS) pq[i] = make_uint4(zz, zz, zz, zz);
+    }
+}
+
+// PROF: developer build with s_memtime stamps at the stage boundaries (LFDMI_DC_PROFILE=1, tools/dc_profile.py): per frame the
+// cycles all waves spent in 0 input wait + staging, 1 masks, 2 horizontal max, 3 vertical max + LUT, 4 borders + equ bits,
+// 5 Sobel, 6 NMS + stores, and (slot 7) the number of tiles that ran the stages.  The shipped kernel is the PROF = false one.
+// KH, KW > 0: the structuring element's size as compile-time constants (the defaults of the two passes, 4 x 4 and 9 x 9, are
+// instantiated: unrolled running maxima by doubling); 0, 0: any size, run-time loops.
+template <bool PROF, int KH, int KW>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
+k_dilate_canny_t(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *strong, const uint8_t *lut, int h, int w,
+                 int kh, int kw, int low, int high, const int *active, int nc, int parts, const int *tile_list, int tile_cap,
+                 const int *counters, long long *prof) {
+    int L = blockIdx.x, xcd = L & 7, jb_ = L >> 3;
+    int g = (jb_ / parts) * 8 + xcd; // frame = 8 * (j / parts) + (block & 7): a frame's tiles behind one L2
+    if (g >= nc) return;
+    if (active && !active[g]) return;
+    const int part = jb_ - (jb_ / parts) * parts;
+    const int ntl = counters[g * C_COUNT + C_NTILES];
+    const int t_begin = (int)((long long)ntl * part / parts), t_end = (int)((long long)ntl * (part + 1) / parts);
+    if (t_begin >= t_end) return;
+    const int *tl = tile_list + (size_t)g * tile_cap;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smw[];
+    const int PH = DCW_PH, MH = DCW_MH, NWD = DCW_NWD, TS = DCW_TS, TSW = DCW_TS / 4;
+    const int IH = PH + kh - 1;
+    const int MGB = MH * CANNY_MW * 2;                 // magnitude plane: ushort (m << 2 | sector)
+    const int tin_bytes = IH * TS > MGB ? IH * TS : MGB;
+    uint8_t *tin = smw;                                // IH x 112; later the magnitude plane
+    uint32_t *tmp = (uint32_t *)(smw + tin_bytes);      // IH x 18 words of horizontal maxima
+    uint8_t *px = (uint8_t *)(tmp + IH * NWD);         // PH x 112
+    unsigned short *mg = (unsigned short *)smw;
+    __shared__ uint8_t slut[256];
+    __shared__ uint32_t Pm[8];                         // input piece column p: rows holding a non-zero byte
+    __shared__ u64 rowc[DCW_TH], rows[DCW_TH];         // NMS output bit rows of the tile
+    const int lane = threadIdx.x;
+    const int ay = kh / 2, ax = kw / 2;
+    const size_t N = (size_t)h * w;
+    const uint8_t *s = src + (size_t)g * N;
+    const int wq = LFD_WQ(w);
+    uint8_t *d = equ ? equ + (size_t)g * N : nullptr;
+    const int npieces = IH * 6;                        // <= 192: three 16-byte pieces per lane
+    int iy[3], wx[3];
+    bool has[3];
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        int idx = lane + 64 * p;
+        iy[p] = idx / 6;
+        wx[p] = idx - iy[p] * 6;
+        has[p] = idx < npieces;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) slut[lane + 64 * p] = lut ? lut[g * 256 + lane + 64 * p] : (uint8_t)(lane + 64 * p);
+    if (lane < 8) Pm[lane] = 0u;
+    __syncthreads();
+    uint32_t zw = slut[0]; // background of the dilated, equalised image
+    zw |= zw << 8; zw |= zw << 16;
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const uint32_t mPH = (1u << PH) - 1, mMH = (1u << MH) - 1, mIH = IH >= 32 ? ~0u : ((1u << IH) - 1);
+    auto load_tile = [&](int code, uint4 *v) {
+        const int ly0 = (code >> 16) * DCW_TH - 2 - ay, xl = (code & 0xffff) * CANNY_TW - CANNY_HALO;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            v[p] = make_uint4(0, 0, 0, 0); // out-of-image samples are ignored by a dilation
+            int gy = ly0 + iy[p], gx = xl + 16 * wx[p];
+            if (has[p] && gy >= 0 && gy < h && gx >= 0 && gx < w) v[p] = *(const uint4 *)(s + (size_t)gy * w + gx);
+        }
+    };
+    uint4 v[3];
+    int code = tl[t_begin];
+    load_tile(code, v);
+    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = 0;
+#define DCW_STAMP(k) do { if (PROF) { long long t_ = (long long)__builtin_amdgcn_s_memtime(); pacc[k] += t_ - pt0; pt0 = t_; } } while (0)
+    for (int ti = t_begin; ti < t_end; ti++) {
+        if (PROF) pt0 = (long long)__builtin_amdgcn_s_memtime();
+        const int tx = code & 0xffff, x0 = tx * CANNY_TW, y0 = (code >> 16) * DCW_TH;
+        uint32_t anyv = 0;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+            if (has[p]) {
+                uint32_t nzv = v[p].x | v[p].y | v[p].z | v[p].w;
+                if (nzv) atomicOr(&Pm[wx[p]], 1u << iy[p]);
+                anyv |= nzv;
+                *(uint4 *)(tin + iy[p] * TS + wx[p] * 16) = v[p];
+            }
+        if (ti + 1 < t_end) { // next tile's input: in flight while this one is processed
+            code = tl[ti + 1];
+            load_tile(code, v);
+        }
+        if (__ballot(anyv != 0) == 0ull) continue; // cells marked, bytes clear after all: the background is already in place
+        constexpr int DCW_KHC = KH, DCW_KWC = KW;
+#include "k_dcw_tile.inc"
+        if (PROF) pacc[7] += 1;
+    }
+#undef DCW_STAMP
+    if (PROF && prof && lane == 0)
+        for (int k = 0; k < 8; k++) atomicAdd((unsigned long long *)&prof[(size_t)g * 8 + k], (unsigned long long)pacc[k]);
 }
 
 // generic widths

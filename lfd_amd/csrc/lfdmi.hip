@@ -136,6 +136,12 @@ struct lfdmi_ctx {
     bool general_seen = false, general_on = true;
     bool frame_ccl = true;             // per-frame LDS connectivity kernels (k_frame.h)
     int frame_runcap = FRAME_RUNCAP;   // runs per frame they take (LFDMI_FRAME_RUNCAP lowers it: tests of the fallback path)
+    int *tile_list = nullptr;          // per slot: active 64 x 16 tiles of the pass image (k_dc_tiles -> k_dilate_canny_t)
+    int tile_cap = 0;
+    bool dc_specialize = true;         // LFDMI_DC_SPECIALIZE=0: the run-time-size instantiation of k_dilate_canny_t for every kernel size
+    bool dc_profile = false;           // LFDMI_DC_PROFILE=1: stage clocks of k_dilate_canny_t into `prof` (developer tool)
+    bool dc_tilelist = true;           // LFDMI_DC_TILELIST=0: the strip-walking kernel k_dilate_canny_w instead
+    int dc_parts = 0;                  // waves per frame of k_dilate_canny_t (0: tiles per frame / 64, LFDMI_DC_PARTS)
     int dc_substrips = 4;              // strips a wave of k_dilate_canny_w walks one after the other
     int dc_strip = 8;                  // tiles per wave strip in k_dilate_canny_w
     bool keep_equ = true;              // write the equalised+dilated stage image (off in lfdmi_detect_batch)
@@ -262,6 +268,8 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_FRAME_RUNCAP")) { int v = atoi(e); if (v >= 0 && v < FRAME_RUNCAP) ctx->frame_runcap = v; }
     if (const char *e = getenv("LFDMI_DC_SUBSTRIPS")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->dc_substrips = v; }
     if (const char *e = getenv("LFDMI_DC_STRIP")) { int v = atoi(e); if (v >= 1 && v <= DCW_MAXS) ctx->dc_strip = v; } // tuning knob
+    if (const char *e = getenv("LFDMI_DC_TILELIST")) ctx->dc_tilelist = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_DC_PARTS")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->dc_parts = v; }
     if (const char *e = getenv("LFDMI_FEED_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->feed_threads = v; }
     if (const char *e = getenv("LFDMI_FEED_MB")) { int v = atoi(e); if (v >= 0 && v <= 8192) ctx->feed_chunk_bytes = (size_t)v << 20; } // 0: plain staging
     ctx->N = (size_t)max_h * max_w;
@@ -306,10 +314,14 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     for (int **p : {&ctx->Lf, &ctx->YMf, &ctx->FLf, &ctx->Lb, &ctx->YMb, &ctx->FLb, &ctx->SBf, &ctx->SBb, &ctx->PAb,
                     &ctx->ROWf, &ctx->ROWb})
         RET(dmalloc(ctx, p, G * ctx->run_cap));
-    if (getenv("LFDMI_FRAME_PROFILE")) RET(dmalloc(ctx, &ctx->prof, G * 8));
+    if (const char *e = getenv("LFDMI_DC_PROFILE")) ctx->dc_profile = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_DC_SPECIALIZE")) ctx->dc_specialize = atoi(e) != 0;
+    if (getenv("LFDMI_FRAME_PROFILE") || ctx->dc_profile) RET(dmalloc(ctx, &ctx->prof, G * 8));
     RET(dmalloc(ctx, &ctx->rsa, G * FRAME_RUNCAP));
     ctx->bm_bands = (max_h + CELLBM_ROWS - 1) / CELLBM_ROWS;
     if (const char *e = getenv("LFDMI_CELLBM")) ctx->use_cellbm = atoi(e) != 0;
+    ctx->tile_cap = ((max_h + DCW_TH - 1) / DCW_TH) * ((max_w + CANNY_TW - 1) / CANNY_TW);
+    RET(dmalloc(ctx, &ctx->tile_list, G * ctx->tile_cap));
     RET(dmalloc(ctx, &ctx->segcnt, G * SCAN_MAX_SEG));
     RET(dmalloc(ctx, &ctx->fb_fg, G));
     RET(dmalloc(ctx, &ctx->fb_bg, G));
@@ -641,6 +653,38 @@ static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, i
         int IH = DCW_PH + kh - 1, MGB = DCW_MH * CANNY_MW * 2;
         size_t lds = (size_t)(IH * DCW_TS > MGB ? IH * DCW_TS : MGB) + (size_t)IH * DCW_NWD * 4 + (size_t)DCW_PH * DCW_TS;
         int tiles_x = (w + CANNY_TW - 1) / CANNY_TW, tiles_y = (h + DCW_TH - 1) / DCW_TH;
+        if (ctx->dc_tilelist && tiles_x <= 128 && tiles_y <= DCT_MAXBANDS) {
+            // active-tile list from the cell bitmap (or every tile), background of the bit planes, then the tile stages
+            Span sp(ctx, KID_DILATE_CANNY);
+            k_dc_tiles<<<nc, DCT_THREADS, 0, ctx->stream>>>(use_bm ? ctx->cellbm : nullptr, ctx->bm_bands, lut, ctx->tile_list, ctx->tile_cap,
+                                                             ctx->counters, ctx->equb, ctx->candb, ctx->strongb, ctx->keep_equ ? ctx->equ : nullptr,
+                                                             h, w, active);
+            KCHK("k_dc_tiles");
+            int parts = ctx->dc_parts > 0 ? ctx->dc_parts : std::max(8, std::min(256, tiles_x * tiles_y / 64));
+            unsigned grid = 8u * ((nc + 7) / 8) * parts;
+            long long *prof = nullptr;
+            if (ctx->dc_profile && ctx->prof) {
+                HIPCHK(hipMemsetAsync(ctx->prof, 0, (size_t)nc * 8 * sizeof(long long), ctx->stream));
+                prof = ctx->prof;
+            }
+#define LFD_DCT_LAUNCH(PROF_, KH_, KW_)                                                                                              \
+    k_dilate_canny_t<PROF_, KH_, KW_><<<grid, 64, lds, ctx->stream>>>(src, ctx->keep_equ ? ctx->equ : nullptr, ctx->equb, ctx->candb, \
+                                                                      ctx->strongb, lut, h, w, kh, kw, 0, 255, active, nc, parts,     \
+                                                                      ctx->tile_list, ctx->tile_cap, ctx->counters, prof)
+            const bool spec = ctx->dc_specialize;
+            if (prof) {
+                if (spec && kh == 4 && kw == 4) LFD_DCT_LAUNCH(true, 4, 4);
+                else if (spec && kh == 9 && kw == 9) LFD_DCT_LAUNCH(true, 9, 9);
+                else LFD_DCT_LAUNCH(true, 0, 0);
+            } else {
+                if (spec && kh == 4 && kw == 4) LFD_DCT_LAUNCH(false, 4, 4);
+                else if (spec && kh == 9 && kw == 9) LFD_DCT_LAUNCH(false, 9, 9);
+                else LFD_DCT_LAUNCH(false, 0, 0);
+            }
+#undef LFD_DCT_LAUNCH
+            KCHK("k_dilate_canny_t");
+            return 0;
+        }
         int S = ctx->dc_strip, SS = ctx->dc_substrips, nstripx = (tiles_x + S * SS - 1) / (S * SS);
         unsigned grid = 8u * ((nc + 7) / 8) * tiles_y * nstripx; // frame = 8 * (j / strips) + (block & 7): one XCD per frame
         Span sp(ctx, KID_DILATE_CANNY);
@@ -719,7 +763,7 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
         size_t lds = (size_t)(FRAME_RUNCAP + 4 * (FRAME_RUNCAP / 32)) * sizeof(int);
         k_frame_contours<<<nc, FRAME_THREADS, lds, ctx->stream>>>(rt, ctx->wl_fg, ctx->wl_bg, ctx->counters, ctx->keys, ctx->bigkeys,
                                                                   ctx->medkeys, ctx->rowext, ctx->rsa, h, w, ctx->key_cap, ctx->slot_cap,
-                                                                  ctx->frame_runcap, active, ctx->fb_bg, ctx->pass_flags, ctx->prof);
+                                                                  ctx->frame_runcap, active, ctx->fb_bg, ctx->pass_flags, ctx->dc_profile ? nullptr : ctx->prof);
         KCHK("k_frame_contours");
         gen = ctx->fb_bg;
     }
