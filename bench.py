@@ -41,6 +41,9 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 STAGES = {
     "prep": (5.0, {"k_prep_hist": 1.0, "k_lut": 1.0, "k_removestars": 1.0}),
     "prep+erode": (7.0, {"k_prep_erode": 1.0}),
+    # both passes' front ends in one sweep over the float frames: 5N for every frame (bright image) + 7N for the frames the dim
+    # pass then works on (priced in main(): the split depends on how many frames the bright pass accepts)
+    "prep(bright)+prep+erode(dim)": (None, {"k_prep_dual": 1.0}),
     "erode": (2.0, {"k_morph(erode)": 1.0}),
     "dilate": (2.0, {"k_morph(dilate)": 1.0, "k_dilate_canny": 0.55}),
     # Canny = NMS (the Sobel / NMS stages are ~45 % of the fused tile kernel: stage ablation in profiles/README.md)
@@ -56,7 +59,7 @@ STAGES = {
 # so that nothing is counted twice (the fused tile kernel: dilate 2N + the image read of the Canny stage, 1N; the other
 # 1N of Canny -- its edge-map output -- belongs to the hysteresis kernels)
 KERNEL_BYTES_PER_PX = {
-    "k_prep_hist": 5.0, "k_prep_erode": 7.0, "k_morph(erode)": 2.0, "k_morph(dilate)": 2.0, "k_dilate_canny": 3.0, "k_canny_nms": 1.0,
+    "k_prep_hist": 5.0, "k_prep_erode": 7.0, "k_prep_dual": None, "k_morph(erode)": 2.0, "k_morph(dilate)": 2.0, "k_dilate_canny": 3.0, "k_canny_nms": 1.0,
     "k_runs_init(fg)": 0.25, "k_frame_fg": 0.75, "k_runs_init(bg)": 0.25, "k_frame_bg": 1.0, "k_rects": 0.5, "k_fill_quads": 0.25,
     "k_pixlist": 0.5, "k_hough_vote": 1.25, "k_hough_peaks": 0.25,
 }
@@ -183,7 +186,7 @@ def main():
         res = step()
     torch.cuda.synchronize()
     warm = det.get_timing()
-    cands = sorted((k for k, v in warm.items() if v[1] and KERNEL_BYTES_PER_PX.get(k, 0.0) > 0), key=lambda k: -warm[k][0])[:4]
+    cands = sorted((k for k, v in warm.items() if v[1] and KERNEL_BYTES_PER_PX.get(k, 0.0) != 0.0), key=lambda k: -warm[k][0])[:4]
     det.timing_select(cands or ["k_dilate_canny", "k_prep_hist", "k_hough_vote", "k_prep_erode"])
     det.enable_timing(not args.no_kernel_timing)  # (re-arms and clears the sums)
     fence()
@@ -234,7 +237,12 @@ def main():
         if not any(v[1] for v in timing.values()):
             timing = {"misc": (1e-9, 1, 1)}
         name, (ms, launches, units) = max(timing.items(), key=lambda kv: kv[1][0])
-        bytes_per_frame = KERNEL_BYTES_PER_PX.get(name, 0.0) * N
+        dim_share = 1.0 - found_b / float(n) if not lsst else 1.0   # frames of a chunk the dim pass works on
+        dual_bpp = 5.0 + 7.0 * dim_share                            # k_prep_dual: 5N per frame + 7N per frame that goes on to the dim pass
+        bpp_dom = KERNEL_BYTES_PER_PX.get(name, 0.0)
+        if bpp_dom is None:
+            bpp_dom = dual_bpp
+        bytes_per_frame = bpp_dom * N
         achieved = (bytes_per_frame * units) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         avg_ms = ms / max(1, launches)
         traffic, traffic_src = load_traffic(name, (args.workload, n, inflight, args.lanes, [h, w]))
@@ -248,7 +256,7 @@ def main():
                 continue
             lead = max((k for k in ks if k in table and table[k][1]), key=lambda k: table[k][0] * ks[k])
             frames_st = table[lead][2]  # (Hough: frames with a rectangle, summed over the launches of every scale)
-            gb = bpp * N * frames_st / 1e9
+            gb = (dual_bpp if bpp is None else bpp) * N * frames_st / 1e9
             stages[sname] = {"ms_per_step": round(t_ms, 4), "algorithmic_GB": round(gb, 4), "GBps": round(gb / (t_ms * 1e-3), 1),
                              "frac_of_peak": round(gb / (t_ms * 1e-3) / HBM_PEAK_GBPS, 4)}
         ch = None
@@ -290,7 +298,7 @@ def main():
                          "avg_launch_ms": round(avg_ms, 4),
                          "frames_per_launch": round(units / max(1, launches), 2),
                          "algorithmic_bytes_per_frame": bytes_per_frame,
-                         "algorithmic_bytes_per_px": KERNEL_BYTES_PER_PX.get(name, 0.0),
+                         "algorithmic_bytes_per_px": round(bpp_dom, 3),
                          "canny_hough": ch,
                          "note": "algorithmic bytes as SURVEY 8(d) prescribes, each stage charged once across its kernels; "
                                  "measured_traffic_frac = PMC HBM bytes per launch / launch time / peak: a kernel whose measured "

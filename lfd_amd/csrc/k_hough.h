@@ -134,9 +134,13 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     const uint32_t *list = (im ? list1 : list0) + (size_t)g * list_cap;
     int lane = threadIdx.x & 63;
     int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    bool act = lane < na;
+    // lane = (chunk slot, angle): a slab of AW < 64 angles (large accumulators: the slab's rows x AW must fit in LDS) lets
+    // every wave work on 64 / AW chunks side by side instead of idling the lanes beyond AW
+    constexpr int SUBS = 64 >> aw_log2;
+    const int ang = lane & (AW - 1), sub = lane >> aw_log2;
+    bool act = ang < na;
     float c = 0.f, s = 0.f;
-    if (act) { c = tab[a0 + lane]; s = tab[numangle + a0 + lane]; }
+    if (act) { c = tab[a0 + ang]; s = tab[numangle + a0 + ang]; }
     const int nw = VOTE_THREADS / 64;
     // |r| <= (numrho-1)/2 by construction (numrho ~ 2(w+h)/rho, |j cos + i sin| < w+h), as in
     // OpenCV, which indexes its accumulator without a range check.
@@ -145,7 +149,7 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     // constant is folded into the base (address arithmetic is mod 2^32).  Lanes without an angle
     // have c = s = 0, hence rint = 0, and their base points at the spare words: no select.
     // (an inactive lane votes bin rint(0) = 0: its base is shifted so that lands in the spare words)
-    const unsigned cell = act ? (unsigned)((-lo) * AW + lane) : (unsigned)(nb * AW + lane);
+    const unsigned cell = act ? (unsigned)((-lo) * AW + ang) : (unsigned)(nb * AW + lane);
     const unsigned lanebase = (cell << 2) - (0x4B400000u << (aw_log2 + 2));
     char *accb = (char *)acc;
     // A list entry is a chunk of horizontal neighbours (y, x0 .. x0 + len - 1), len <= min(16, rho) (k_pixlist).
@@ -165,21 +169,35 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     for (int base = begin + wv * 64; base < end; base += nw * 64) {
         int m = min(64, end - base);
         uint32_t pv = (lane < m) ? list[base + lane] : 0u;
-        // every lane converts its own entry once; the wave then walks the entries with v_readlane
+        // every lane converts its own entry once; the wave then walks the entries with v_readlane (one chunk per step,
+        // SUBS == 1) or fetches its slot's entry with ds_bpermute (SUBS chunks per step)
         const int lenv = (int)(pv >> 26);                       // len - 1
         const float fx0v = (float)(pv & 0x1fffu), fyv = (float)((pv >> 13) & 0x1fffu);
         const float fxev = fx0v + (float)lenv;
-        for (int k = 0; k < m; k++) {
-            const float fx0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx0v), k));
-            const float fxe = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fxev), k));
-            const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyv), k));
-            const int L = __builtin_amdgcn_readlane(lenv, k) + 1;
+        for (int k = 0; k < m; k += SUBS) {
+            float fx0, fxe, fy;
+            int L;
+            bool on = true; // this lane's slot holds a chunk
+            if constexpr (SUBS == 1) {
+                fx0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx0v), k));
+                fxe = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fxev), k));
+                fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyv), k));
+                L = __builtin_amdgcn_readlane(lenv, k) + 1;
+            } else {
+                const int src = k + sub;
+                on = src < m;
+                const uint32_t pe = (uint32_t)__builtin_amdgcn_ds_bpermute((src & 63) << 2, (int)pv);
+                L = (int)(pe >> 26) + 1;
+                fx0 = (float)(pe & 0x1fffu);
+                fy = (float)((pe >> 13) & 0x1fffu);
+                fxe = fx0 + (float)(L - 1);
+            }
             const float ys = __fmul_rn(fy, s);
             const float w0 = __fadd_rn(__fmul_rn(fx0, c), ys);
             const float v0 = __fadd_rn(w0, 12582912.0f);
             const unsigned b0 = __builtin_bit_cast(unsigned, v0), be = LFD_BIN(fxe, ys);
-            if (__ballot(b0 != be) == 0ull) { // the whole chunk votes for one bin at every angle of this wave
-                atomicAdd((int *)(accb + ((b0 << sh) + lanebase)), L);
+            if (__ballot(on && b0 != be) == 0ull) { // every chunk of this step votes for one bin at every angle of this wave
+                if (on) atomicAdd((int *)(accb + ((b0 << sh) + lanebase)), L);
                 continue;
             }
             // boundary estimate (lanes whose ends agree get some t in [1, L-1]: both parts land in the same bin)
@@ -188,10 +206,12 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
             const int t = (int)ceilf(tf);
             const float fxb = __fadd_rn(fx0, (float)t), fxa = __fsub_rn(fxb, 1.0f);
             const unsigned ba = LFD_BIN(fxa, ys), bb = LFD_BIN(fxb, ys);
-            const bool ok = (ba == b0) && (bb == be);
+            const bool ok = !on || b0 == be || ((ba == b0) && (bb == be)); // (both ends in one bin: any split adds up to L there)
             if (__ballot(!ok) == 0ull) {
-                atomicAdd((int *)(accb + ((b0 << sh) + lanebase)), t);
-                atomicAdd((int *)(accb + ((be << sh) + lanebase)), L - t);
+                if (on) {
+                    atomicAdd((int *)(accb + ((b0 << sh) + lanebase)), t);
+                    atomicAdd((int *)(accb + ((be << sh) + lanebase)), L - t);
+                }
                 continue;
             }
             // One pixel off is common where bin borders sit on whole pixels (theta = 0: x cos / rho crosses
@@ -202,12 +222,18 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
             const int t2 = ok ? t : (high ? t - 1 : t + 1);
             const bool ok2 = ok || (high ? (bc == b0) : (ba == b0 && bb == b0 && bc == be));
             if (__ballot(!ok2) == 0ull) {
-                atomicAdd((int *)(accb + ((b0 << sh) + lanebase)), t2);
-                atomicAdd((int *)(accb + ((be << sh) + lanebase)), L - t2);
+                if (on) {
+                    atomicAdd((int *)(accb + ((b0 << sh) + lanebase)), t2);
+                    atomicAdd((int *)(accb + ((be << sh) + lanebase)), L - t2);
+                }
                 continue;
             }
-            for (int j = 0; j < L; j++) // rare: exact walk
-                atomicAdd((int *)(accb + ((LFD_BIN(__fadd_rn(fx0, (float)j), ys) << sh) + lanebase)), 1);
+            int Lmax = L; // rare: exact walk (the longest chunk of the step sets the trip count)
+            if constexpr (SUBS > 1) {
+                for (int off = 32; off > 0; off >>= 1) Lmax = max(Lmax, __shfl_xor(Lmax, off));
+            }
+            for (int j = 0; j < Lmax; j++)
+                if (on && j < L) atomicAdd((int *)(accb + ((LFD_BIN(__fadd_rn(fx0, (float)j), ys) << sh) + lanebase)), 1);
         }
     }
 #undef LFD_BIN

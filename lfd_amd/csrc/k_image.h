@@ -80,10 +80,12 @@ k_removestars(float *frames, int h, int w, int max_obj, const int *count, const 
 // mode bit 0: x<0 -> 0 (bright); bit 1: x<minFlux -> 0, x>0 -> x+addFlux (dim).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned sat_u8_f32(float x) {
-    float a = fabsf(x);
-    if (a != a) return 0u;
-    if (a >= 255.5f) return 255u;
-    return (unsigned)__float2int_rn(a);
+    // saturate_cast<uchar>(|x|) with round-half-even: v_rndne_f32, v_cvt_u32_f32, v_min_u32.  The conversion is written as
+    // the instruction itself: its hardware result for NaN (0) and for values beyond 32 bits (0xFFFFFFFF) is what is wanted
+    // here, whereas a C++ float -> unsigned cast of such values is undefined.
+    unsigned u;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(u) : "v"(__builtin_rintf(fabsf(x))));
+    return min(u, 255u);
 }
 __device__ __forceinline__ unsigned sat_u8_f64(double x) {
     double a = fabs(x);
@@ -114,7 +116,7 @@ static_assert(16 % PREP_ROWS == 0, "a workgroup's rows lie in one band");
 
 __global__ void __launch_bounds__(256)
 k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double minFlux,
-            double addFlux, uint8_t *gray, int *hist, u64 *cellbm, int bm_bands, const int *active) {
+            double addFlux, uint8_t *gray, int *hist, u64 *cellbm, int bm_bands, const int *active, u64 *fullbits) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     __shared__ int sh[4][256];
@@ -138,6 +140,13 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
                          c = prep_f32(v.z, mode, mf, af), e = prep_f32(v.w, mode, mf, af);
                 d[x4] = make_uchar4((unsigned char)a, (unsigned char)b, (unsigned char)c, (unsigned char)e);
                 if (a | b | c | e) nzpos |= 1u << i;
+                // one bit per aligned word of four pixels: "all four non-zero".  Only where such words line up can a wide
+                // erosion leave anything (k_morph_rect_v decides from these bits without loading the image); a wave's 64
+                // lanes are 64 consecutive words, so the ballot is one u64 of the plane
+                if (fullbits) {
+                    u64 fb = __ballot(a && b && c && e);
+                    if (lfd_lane() == 0) fullbits[((size_t)g * h + r) * ((w + 255) >> 8) + (x4 >> 6)] = fb;
+                }
                 if (a) atomicAdd(&sh[wv][a], 1); else zeros++;
                 if (b) atomicAdd(&sh[wv][b], 1); else zeros++;
                 if (c) atomicAdd(&sh[wv][c], 1); else zeros++;
@@ -192,72 +201,114 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
 // float32 input, all-ones kernel, w % 16 == 0, kw/2 <= 16 and kw - 1 - kw/2 <= 16.
 // ------------------------------------------------------------------------------------------
 #define PE_THREADS 1024
+#define PE_HISTS 16 // private LDS histograms (one per wave; the DUAL variant gives eight to each of its two outputs)
+// DUAL: the same pass over the float rows also produces the BRIGHT pass's 8-bit image (mode 1: x < 0 -> 0), its histogram
+// and its cell occupancy (gray_b / hist_b / cellbm_b) for the band's own rows: lfdmi_detect_batch runs both passes on the
+// same frames, so the 12.2 MB of a frame cross HBM once instead of twice (the dim outputs of frames the bright pass then
+// accepts are not used).
+template <bool DUAL>
 __global__ void __launch_bounds__(PE_THREADS)
 k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float af, uint8_t *dst, int *hist, int kh, int kw,
-             int BR, u64 *cellbm, int bm_bands, const int *active) {
+             int BR, u64 *cellbm, int bm_bands, const int *active, uint8_t *gray_b, int *hist_b, u64 *cellbm_b) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t smb[];
-    __shared__ int sh[PE_THREADS / 64][256];
+    __shared__ int sh[PE_HISTS][256];
+    constexpr int NH = DUAL ? PE_HISTS / 2 : PE_HISTS; // rows 0 .. NH-1: this kernel's own image; NH .. : the bright image
     const int R = BR + kh - 1, S = w + 32, SW = S >> 2, W4 = w >> 2;
     uint32_t *band = (uint32_t *)smb;            // R x S bytes
     uint32_t *vbuf = band + R * SW;              // BR x S bytes: vertical minimum
-    for (int k = threadIdx.x; k < (PE_THREADS / 64) * 256; k += PE_THREADS) ((int *)sh)[k] = 0;
+    for (int k = threadIdx.x; k < PE_HISTS * 256; k += PE_THREADS) ((int *)sh)[k] = 0;
     const int y0 = blockIdx.x * BR, ay = kh / 2, ax = kw / 2;
     const size_t N = (size_t)h * w;
     const float *s = src + (size_t)g * N;
-    const int wv = threadIdx.x >> 6;
+    const int wv = (threadIdx.x >> 6) & (NH - 1);
     // pads of every staged row
     for (int it = threadIdx.x; it < R * 8; it += PE_THREADS) {
         int r = it >> 3, k = it & 7;
         band[r * SW + (k < 4 ? k : W4 + k)] = 0xFFFFFFFFu;
     }
     __syncthreads();
-    int zeros = 0;
+    int zeros = 0, ones = 0, zeros_b = 0;
+    // piece `it` of the band is (row it / W4, 16-byte column it % W4); a lane's pieces are PE_THREADS apart, so it carries
+    // (row, column) along instead of dividing for every piece (an integer division is ~40 vector instructions)
+    const int dr1 = PE_THREADS / W4, dx1 = PE_THREADS - dr1 * W4;
+    int r_c = threadIdx.x / W4, x_c = threadIdx.x - r_c * W4;
     for (int it0 = threadIdx.x; it0 < R * W4; it0 += 4 * PE_THREADS) { // four row pieces in flight per lane
         float4 v[4];
-        int gyv[4];
+        int gyv[4], rr[4], xx[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            int it = it0 + u * PE_THREADS;
-            int r = it / W4, x4 = it - r * W4;
+            rr[u] = r_c; xx[u] = x_c;
+            x_c += dx1; r_c += dr1;
+            if (x_c >= W4) { x_c -= W4; r_c++; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int r = rr[u], x4 = xx[u];
             int gy = y0 - ay + r;
-            gyv[u] = (it < R * W4 && gy >= 0 && gy < h) ? gy : -1;
+            gyv[u] = (r < R && gy >= 0 && gy < h) ? gy : -1;
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gyv[u] >= 0) v[u] = ((const float4 *)(s + (size_t)(flip ? (h - 1 - gy) : gy) * w))[x4];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            int it = it0 + u * PE_THREADS;
-            if (it >= R * W4) continue;
-            int r = it / W4, x4 = it - r * W4;
+            const int r = rr[u], x4 = xx[u];
+            if (r >= R) continue;
             uint32_t word = 0xFFFFFFFFu;
             if (gyv[u] >= 0) {
                 unsigned a = prep_f32(v[u].x, mode, mf, af), b = prep_f32(v[u].y, mode, mf, af), c = prep_f32(v[u].z, mode, mf, af),
                          e = prep_f32(v[u].w, mode, mf, af);
                 word = a | (b << 8) | (c << 16) | (e << 24);
                 if (gyv[u] >= y0 && gyv[u] < y0 + BR) { // the band's own rows: every image row is counted once
-                    if (a) atomicAdd(&sh[wv][a], 1); else zeros++;
-                    if (b) atomicAdd(&sh[wv][b], 1); else zeros++;
-                    if (c) atomicAdd(&sh[wv][c], 1); else zeros++;
-                    if (e) atomicAdd(&sh[wv][e], 1); else zeros++;
+                    // (a dim-pass sky is zeros and ones: both are counted in registers, the rest goes to the LDS histogram)
+                    auto cnt = [&](unsigned q) { if (q == 0) zeros++; else if (q == 1) ones++; else atomicAdd(&sh[wv][q], 1); };
+                    cnt(a); cnt(b); cnt(c); cnt(e);
+                    if (DUAL) { // the bright pass's image of the same pixels
+                        unsigned a2 = prep_f32(v[u].x, 1, 0.f, 0.f), b2 = prep_f32(v[u].y, 1, 0.f, 0.f), c2 = prep_f32(v[u].z, 1, 0.f, 0.f),
+                                 e2 = prep_f32(v[u].w, 1, 0.f, 0.f);
+                        ((uchar4 *)(gray_b + (size_t)g * N + (size_t)gyv[u] * w))[x4] =
+                            make_uchar4((unsigned char)a2, (unsigned char)b2, (unsigned char)c2, (unsigned char)e2);
+                        if (a2) atomicAdd(&sh[NH + wv][a2], 1); else zeros_b++;
+                        if (b2) atomicAdd(&sh[NH + wv][b2], 1); else zeros_b++;
+                        if (c2) atomicAdd(&sh[NH + wv][c2], 1); else zeros_b++;
+                        if (e2) atomicAdd(&sh[NH + wv][e2], 1); else zeros_b++;
+                        if (a2 | b2 | c2 | e2) { // (the bright image is sparse: a few thousand marks per frame)
+                            int cx = x4 >> 2;
+                            atomicOr((unsigned long long *)&cellbm_b[((size_t)g * bm_bands + gyv[u] / CELLBM_ROWS) * CELLBM_WORDS + (cx >> 6)], 1ull << (cx & 63));
+                        }
+                    }
                 }
             }
             band[r * SW + 4 + x4] = word;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) zeros += __shfl_down(zeros, off);
+    for (int off = 32; off > 0; off >>= 1) {
+        zeros += __shfl_down(zeros, off);
+        ones += __shfl_down(ones, off);
+        if (DUAL) zeros_b += __shfl_down(zeros_b, off);
+    }
     if (lfd_lane() == 0 && zeros) atomicAdd(&sh[wv][0], zeros);
+    if (lfd_lane() == 0 && ones) atomicAdd(&sh[wv][1], ones);
+    if (DUAL && lfd_lane() == 0 && zeros_b) atomicAdd(&sh[NH + wv][0], zeros_b);
     __syncthreads();
     if (threadIdx.x < 256) {
         int b = threadIdx.x, t = 0;
-        for (int k = 0; k < PE_THREADS / 64; k++) t += sh[k][b];
+        for (int k = 0; k < NH; k++) t += sh[k][b];
         if (t) atomicAdd(&hist[g * 256 + b], t);
+    } else if (DUAL && threadIdx.x < 512) {
+        int b = threadIdx.x - 256, t = 0;
+        for (int k = 0; k < NH; k++) t += sh[NH + k][b];
+        if (t) atomicAdd(&hist_b[g * 256 + b], t);
     }
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     // vertical minimum, pads included (they stay 0xFF)
+    const int dro = PE_THREADS / SW, djo = PE_THREADS - dro * SW;
+    int o_c = threadIdx.x / SW, j_c = threadIdx.x - o_c * SW;
     for (int it = threadIdx.x; it < BR * SW; it += PE_THREADS) {
-        int o = it / SW, j = it - o * SW;
+        const int o = o_c, j = j_c;
+        j_c += djo; o_c += dro;
+        if (j_c >= SW) { j_c -= SW; o_c++; }
         us2 mE = __builtin_bit_cast(us2, 0x00FF00FFu), mO = mE;
         for (int dy = 0; dy < kh; dy++) {
             uint32_t t = band[(o + dy) * SW + j];
@@ -270,8 +321,12 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
     // horizontal minimum and store: 16 output bytes per lane
     uint8_t *d = dst + (size_t)g * N;
     const int W16 = w >> 4;
+    const int drh = PE_THREADS / W16, dxh = PE_THREADS - drh * W16;
+    int oh_c = threadIdx.x / W16, xh_c = threadIdx.x - oh_c * W16;
     for (int it = threadIdx.x; it < BR * W16; it += PE_THREADS) {
-        int o = it / W16, x16 = it - o * W16;
+        const int o = oh_c, x16 = xh_c;
+        xh_c += dxh; oh_c += drh;
+        if (xh_c >= W16) { xh_c -= W16; oh_c++; }
         int gy = y0 + o;
         if (gy >= h) continue;
         const uint32_t *rw = vbuf + o * SW;
@@ -355,6 +410,67 @@ k_apply_lut(const uint8_t *src, const uint8_t *lut, uint8_t *dst, size_t N) {
         dst[(size_t)g * N + k] = l[src[(size_t)g * N + k]];
 }
 
+// ---- SWAR helpers of the wave kernels: four pixels as two packed-u16 pairs (E = bytes 0, 2; O = bytes 1, 3) ----
+typedef unsigned short dcw_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dcw_pkmax(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(dcw_us2, a), __builtin_bit_cast(dcw_us2, b)));
+}
+__device__ __forceinline__ uint32_t dcw_pkmin(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(dcw_us2, a), __builtin_bit_cast(dcw_us2, b)));
+}
+// (E, O)[i] <- max((E, O)[i], the same bytes S positions further right), for words 0 .. nw-1 of a split byte row.
+// Byte x + S of a split row: S = 4k: word i + k; S = 4k + 1: E' = O[i+k], O' = (E[i+k] >> 16 | E[i+k+1] << 16); ...
+template <int S, int NWT, bool MIN = false>
+__device__ __forceinline__ void dcw_shift_max(uint32_t (&E)[NWT], uint32_t (&O)[NWT], int nw) {
+    constexpr int K = S / 4, R = S % 4;
+#pragma unroll
+    for (int i = 0; i < NWT; i++) {
+        if (i >= nw || i + K + 1 >= NWT) continue;
+        uint32_t e2, o2;
+        if constexpr (R == 0) { e2 = E[i + K]; o2 = O[i + K]; }
+        else if constexpr (R == 1) { e2 = O[i + K]; o2 = __builtin_amdgcn_alignbyte(E[i + K + 1], E[i + K], 2); }
+        else if constexpr (R == 2) { e2 = __builtin_amdgcn_alignbyte(E[i + K + 1], E[i + K], 2); o2 = __builtin_amdgcn_alignbyte(O[i + K + 1], O[i + K], 2); }
+        else { e2 = __builtin_amdgcn_alignbyte(O[i + K + 1], O[i + K], 2); o2 = E[i + K + 1]; }
+        E[i] = MIN ? dcw_pkmin(E[i], e2) : dcw_pkmax(E[i], e2);
+        O[i] = MIN ? dcw_pkmin(O[i], o2) : dcw_pkmax(O[i], o2);
+    }
+}
+// max over the KW bytes starting at each of the four pixels of output word jj of a staged row (the window of pixel q
+// starts at staged byte CANNY_MOFF - KW/2 + 4 jj + q): running maxima over windows of 1, 2, 4, ... bytes, then
+// max(m_p[x], m_p[x + KW - p]) for the largest power of two p <= KW -- ~3 packed instructions per doubling step and
+// word instead of ~6 per tap.
+// (MIN: running minima for an erosion; BASE: staged byte of output word 0's first pixel -- CANNY_MOFF in the fused tile
+// kernels, MORPH_HALO in k_morph_rect_v.)  Bytes beyond the window that the shifts drag in are zero for a maximum and
+// never reach word 0 of the result in either case.
+template <int KW, bool MIN = false, int BASE = 12>
+__device__ __forceinline__ uint32_t dcw_hmax(const uint32_t *rw, int jj) {
+    constexpr int AX = KW / 2, R0 = (BASE - AX) & 3, Q0 = (BASE - AX) >> 2;
+    constexpr int NB = KW + 3, NW = (NB + 3) / 4, NR = (R0 + NB + 3) / 4, NWT = NW + 9;
+    uint32_t raw[NR + 1];
+#pragma unroll
+    for (int i = 0; i < NR; i++) raw[i] = rw[Q0 + jj + i];
+    raw[NR] = 0;
+    uint32_t E[NWT], O[NWT];
+#pragma unroll
+    for (int i = 0; i < NWT; i++) {
+        uint32_t a = 0;
+        if (i < NW) a = R0 ? __builtin_amdgcn_alignbyte(raw[i + 1 <= NR ? i + 1 : NR], raw[i], R0) : raw[i];
+        E[i] = a & 0x00FF00FFu;
+        O[i] = (a >> 8) & 0x00FF00FFu;
+    }
+    constexpr int P = KW >= 16 ? 16 : (KW >= 8 ? 8 : (KW >= 4 ? 4 : (KW >= 2 ? 2 : 1))), D = KW - P;
+    // words each step still has to produce (bytes needed by the steps after it)
+    constexpr int need1 = 4 + D + (P > 8 ? 8 : 0) + (P > 4 ? 4 : 0) + (P > 2 ? 2 : 0);
+    if constexpr (P >= 2) dcw_shift_max<1, NWT, MIN>(E, O, (need1 + 3) / 4);
+    constexpr int need2 = need1 - 2;
+    if constexpr (P >= 4) dcw_shift_max<2, NWT, MIN>(E, O, (need2 + 3) / 4);
+    constexpr int need4 = need2 - 4;
+    if constexpr (P >= 8) dcw_shift_max<4, NWT, MIN>(E, O, (need4 + 3) / 4);
+    if constexpr (P >= 16) dcw_shift_max<8, NWT, MIN>(E, O, (4 + D + 3) / 4);
+    if constexpr (D > 0) dcw_shift_max<D, NWT, MIN>(E, O, 1);
+    return E[0] | (O[0] << 8);
+}
+
 // ------------------------------------------------------------------------------------------
 // erode / dilate with an all-ones kh x kw kernel: separable running min/max staged in LDS.
 // dst(y,x) = op over dy<kh, dx<kw of src(y+dy-kh/2, x+dx-kw/2), out-of-image samples ignored.
@@ -424,12 +540,19 @@ k_morph_rect(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, in
 // LDS and written with 16 B per lane.
 #define MORPH_HALO 16
 
-template <int OP>
+// KHC, KWC > 0: the kernel's size at compile time (unrolled; the horizontal pass by doubling, dcw_hmax); 0: run-time sizes.
+// Erosion (OP == 1) of a sparse image -- the dim pass's 8-bit image is mostly zeros with isolated ones -- skips what cannot
+// survive: a kw-wide window of non-zero bytes must contain a whole aligned word of non-zero bytes (kw >= 7), so a staged row
+// without such a word erodes to zeros, an output row needs kh live input rows, and a tile without a live row is all zeros
+// without touching LDS.
+template <int OP, int KHC = 0, int KWC = 0>
 __global__ void __launch_bounds__(256)
 k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, int h, int w, int kh,
-               int kw, const int *active) {
+               int kw, const int *active, const u64 *candmask, u64 *cellout, int bm_bands) {
     int g = blockIdx.z;
     if (active && !active[g]) return;
+    // wide erosion of a sparse image: k_erode_cand has zero-filled dst and left one bit per tile that can hold anything
+    if (candmask && !((candmask[((size_t)g * gridDim.y + blockIdx.y) * 2 + (blockIdx.x >> 6)] >> (blockIdx.x & 63)) & 1ull)) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t smv[];
     const int IH = MORPH_TH + kh - 1;
     const int IWB = MORPH_TW + 2 * MORPH_HALO; // bytes per staged row
@@ -445,16 +568,24 @@ k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, 
     const uint8_t *s = src + (size_t)g * N;
     if (lut) slut[threadIdx.x] = lut[g * 256 + threadIdx.x];
     if (threadIdx.x < IH) rowflag[threadIdx.x] = 0;
+    const bool sparse_erode = OP == 1 && kw >= 7; // (a window of >= 7 bytes always contains an aligned 4-byte word)
+    const bool known_empty = false;
     __syncthreads();
     uint32_t any = 0;
     const int IW16 = IWB / 16; // 16-byte pieces per staged row (6)
-    for (int idx = threadIdx.x; idx < IH * IW16; idx += 256) {
+    for (int idx = threadIdx.x; idx < IH * IW16 && !known_empty; idx += 256) {
         int iy = idx / IW16, wx = idx - iy * IW16;
         int gy = y0 + iy - ay, gx = x0 - MORPH_HALO + 16 * wx;
         uint4 v = make_uint4(fillw, fillw, fillw, fillw);
         if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = *(const uint4 *)(s + (size_t)gy * w + gx);
         uint32_t nzv = v.x | v.y | v.z | v.w;
-        if (OP == 0 && nzv) rowflag[iy] = 1;
+        if (OP == 1) {
+            if (sparse_erode) { // any word without a zero byte?  haszero(x) = (x - 0x01010101) & ~x & 0x80808080
+                auto full = [](uint32_t x) { return ((x - 0x01010101u) & ~x & 0x80808080u) == 0u; };
+                nzv = (full(v.x) || full(v.y) || full(v.z) || full(v.w)) ? 1u : 0u;
+            } else nzv = 1u;
+        }
+        if (nzv) rowflag[iy] = 1;
         any |= nzv;
         ((uint4 *)tin)[idx] = v;
     }
@@ -462,8 +593,8 @@ k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, 
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int nz = __syncthreads_or(any != 0);
     uint8_t *d = dst + (size_t)g * N;
-    if (OP == 0 && !nz) {
-        // dilation of an all-zero neighbourhood
+    if (!nz) {
+        // dilation of an all-zero neighbourhood / erosion of rows none of which holds a run of kw non-zero bytes: zeros
         uint32_t z = lut ? slut[0] : 0u;
         z |= z << 8; z |= z << 16;
         if (threadIdx.x < MORPH_TH * 4) {
@@ -489,7 +620,12 @@ k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, 
     for (int it = threadIdx.x; it < IH * (MORPH_TW / 4); it += 256) {
         int ry = it >> 4, j = it & 15;
         uint32_t aE = fsplit, aO = fsplit;
-        if (OP || rowflag[ry]) { // an all-zero staged row dilates to zeros
+        if (!rowflag[ry]) { // an all-zero staged row dilates to zeros; a row without kw non-zero bytes in a row erodes to zeros
+            aE = 0; aO = 0;
+        } else if constexpr (KWC > 0) {
+            uint32_t r4 = dcw_hmax<KWC, OP == 1, MORPH_HALO>(tinw + ry * (IWB / 4), j);
+            aE = r4 & 0x00FF00FFu; aO = (r4 >> 8) & 0x00FF00FFu;
+        } else {
             int o = MORPH_HALO - ax + 4 * j; // byte offset of the window's first column
             const uint32_t *rw = tinw + ry * (IWB / 4);
             int qi = o >> 2;
@@ -512,10 +648,14 @@ k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, 
     for (int it = threadIdx.x; it < MORPH_TH * (MORPH_TW / 4); it += 256) {
         int oy = it >> 4, j = it & 15;
         uint32_t aE = fsplit, aO = fsplit;
-        bool live = OP != 0;
-        if (!OP) for (int dy = 0; dy < kh; dy++) live = live || rowflag[oy + dy];
-        if (live)
-            for (int dy = 0; dy < kh; dy++) {
+        const int khc = KHC > 0 ? KHC : kh;
+        bool live = OP != 0; // dilation: some row of the window is live; erosion: every row of the window is
+        if (!OP) for (int dy = 0; dy < khc; dy++) live = live || rowflag[oy + dy];
+        else for (int dy = 0; dy < khc; dy++) live = live && rowflag[oy + dy];
+        if (!live) { aE = 0; aO = 0; }
+        else
+#pragma unroll
+            for (int dy = 0; dy < khc; dy++) {
                 us2 e = __builtin_bit_cast(us2, tmpE[(oy + dy) * 16 + j]), od = __builtin_bit_cast(us2, tmpO[(oy + dy) * 16 + j]);
                 us2 ce = __builtin_bit_cast(us2, aE), co = __builtin_bit_cast(us2, aO);
                 ce = OP ? __builtin_elementwise_min(ce, e) : __builtin_elementwise_max(ce, e);
@@ -539,8 +679,55 @@ k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, 
     if (threadIdx.x < MORPH_TH * 4) {
         int row = threadIdx.x >> 2, c16 = threadIdx.x & 3;
         int gy = y0 + row, gx = x0 + 16 * c16;
-        if (gy < h && gx < w) *(uint4 *)(d + (size_t)gy * w + gx) = *(const uint4 *)(tout + row * MORPH_TW + 16 * c16);
+        if (gy < h && gx < w) {
+            uint4 ov = *(const uint4 *)(tout + row * MORPH_TW + 16 * c16);
+            *(uint4 *)(d + (size_t)gy * w + gx) = ov;
+            // cell occupancy of the output for the consumer's tile list (k_dc_tiles): a lane's 16 bytes are one cell row
+            if (cellout && (ov.x | ov.y | ov.z | ov.w)) {
+                int cx = gx / CELLBM_COLS;
+                atomicOr((unsigned long long *)&cellout[((size_t)g * bm_bands + gy / CELLBM_ROWS) * CELLBM_WORDS + (cx >> 6)], 1ull << (cx & 63));
+            }
+        }
     }
+}
+
+// Wide erosion (kw >= 7) of a sparse 8-bit image, first step.  The producer left one bit per aligned 4-pixel word ("all four
+// bytes non-zero", k_prep_hist).  A kw-wide run of non-zero bytes contains such a word, so a 64 x 32 tile can only hold a
+// non-zero output if kh consecutive rows of its input rows each have such a word within reach of the tile (words -1 .. 17
+// of the tile's 16).  One wave per tile row: lane = tile column walks the rows counting consecutive live ones -> one
+// candidate bit per tile (candmask, two u64 per tile row), and the wave zero-fills the tile row of dst with 16-byte stores.
+// k_morph_rect_v then only runs on candidate tiles (a dim-pass sky: a handful around stars) instead of staging every tile.
+__global__ void __launch_bounds__(64)
+k_erode_cand(const u64 *fullbits, u64 *candmask, uint8_t *dst, int h, int w, int kh, const int *active) {
+    const int g = blockIdx.y, ty = blockIdx.x, lane = threadIdx.x;
+    if (active && !active[g]) return;
+    const int y0 = ty * MORPH_TH, ay = kh / 2, IH = MORPH_TH + kh - 1, ntx = (w + MORPH_TW - 1) / MORPH_TW, fw = (w + 255) >> 8;
+    for (int half = 0; half < 2; half++) {
+        const int tx = lane + 64 * half;
+        bool cand = false;
+        if (tx < ntx) {
+            const int j0 = 16 * tx - 1, jb = j0 < 0 ? 0 : j0, q = jb >> 6, sh2 = jb & 63, nb = 19 - (jb - j0);
+            int consec = 0;
+            for (int t = 0; t < IH; t++) {
+                int gy = y0 - ay + t;
+                bool live = gy < 0 || gy >= h; // rows outside the image are ignored by an erosion
+                if (!live) {
+                    const u64 *fr = fullbits + ((size_t)g * h + gy) * fw;
+                    u64 b = fr[q] >> sh2;
+                    if (sh2 > 64 - 19 && q + 1 < fw) b |= fr[q + 1] << (64 - sh2);
+                    live = (b & ((1ull << nb) - 1ull)) != 0ull;
+                }
+                consec = live ? consec + 1 : 0;
+                cand = cand || consec >= kh;
+            }
+        }
+        u64 m = __ballot(cand);
+        if (lane == 0) candmask[((size_t)g * gridDim.x + ty) * 2 + half] = m;
+    }
+    uint4 *row = (uint4 *)(dst + (size_t)g * h * w);
+    const int w16 = w >> 4;
+    for (int r = y0; r < y0 + MORPH_TH && r < h; r++)
+        for (int x = lane; x < w16; x += 64) row[(size_t)r * w16 + x] = make_uint4(0, 0, 0, 0);
 }
 
 // arbitrary 0/1 structuring element (the knob is an array: detecttrails.py:205,220-221)
@@ -949,61 +1136,6 @@ k_dilate_canny_v(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
 #define DCW_MAXKH 13         // DCW_PH + kh - 1 <= 32 rows: one 32-bit mask per column
 #define DCW_MAXS 8            // tiles per strip (one wave walks a strip left to right)
 static_assert(DCW_TH == CELLBM_ROWS && CANNY_TW == 4 * CELLBM_COLS, "a tile is one band high and four cells wide");
-
-// ---- SWAR helpers of the wave kernels: four pixels as two packed-u16 pairs (E = bytes 0, 2; O = bytes 1, 3) ----
-typedef unsigned short dcw_us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t dcw_pkmax(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(dcw_us2, a), __builtin_bit_cast(dcw_us2, b)));
-}
-// (E, O)[i] <- max((E, O)[i], the same bytes S positions further right), for words 0 .. nw-1 of a split byte row.
-// Byte x + S of a split row: S = 4k: word i + k; S = 4k + 1: E' = O[i+k], O' = (E[i+k] >> 16 | E[i+k+1] << 16); ...
-template <int S, int NWT>
-__device__ __forceinline__ void dcw_shift_max(uint32_t (&E)[NWT], uint32_t (&O)[NWT], int nw) {
-    constexpr int K = S / 4, R = S % 4;
-#pragma unroll
-    for (int i = 0; i < NWT; i++) {
-        if (i >= nw || i + K + 1 >= NWT) continue;
-        uint32_t e2, o2;
-        if constexpr (R == 0) { e2 = E[i + K]; o2 = O[i + K]; }
-        else if constexpr (R == 1) { e2 = O[i + K]; o2 = __builtin_amdgcn_alignbyte(E[i + K + 1], E[i + K], 2); }
-        else if constexpr (R == 2) { e2 = __builtin_amdgcn_alignbyte(E[i + K + 1], E[i + K], 2); o2 = __builtin_amdgcn_alignbyte(O[i + K + 1], O[i + K], 2); }
-        else { e2 = __builtin_amdgcn_alignbyte(O[i + K + 1], O[i + K], 2); o2 = E[i + K + 1]; }
-        E[i] = dcw_pkmax(E[i], e2);
-        O[i] = dcw_pkmax(O[i], o2);
-    }
-}
-// max over the KW bytes starting at each of the four pixels of output word jj of a staged row (the window of pixel q
-// starts at staged byte CANNY_MOFF - KW/2 + 4 jj + q): running maxima over windows of 1, 2, 4, ... bytes, then
-// max(m_p[x], m_p[x + KW - p]) for the largest power of two p <= KW -- ~3 packed instructions per doubling step and
-// word instead of ~6 per tap.
-template <int KW>
-__device__ __forceinline__ uint32_t dcw_hmax(const uint32_t *rw, int jj) {
-    constexpr int AX = KW / 2, R0 = (CANNY_MOFF - AX) & 3, Q0 = (CANNY_MOFF - AX) >> 2;
-    constexpr int NB = KW + 3, NW = (NB + 3) / 4, NR = (R0 + NB + 3) / 4, NWT = NW + 9;
-    uint32_t raw[NR + 1];
-#pragma unroll
-    for (int i = 0; i < NR; i++) raw[i] = rw[Q0 + jj + i];
-    raw[NR] = 0;
-    uint32_t E[NWT], O[NWT];
-#pragma unroll
-    for (int i = 0; i < NWT; i++) {
-        uint32_t a = 0;
-        if (i < NW) a = R0 ? __builtin_amdgcn_alignbyte(raw[i + 1 <= NR ? i + 1 : NR], raw[i], R0) : raw[i];
-        E[i] = a & 0x00FF00FFu;
-        O[i] = (a >> 8) & 0x00FF00FFu;
-    }
-    constexpr int P = KW >= 16 ? 16 : (KW >= 8 ? 8 : (KW >= 4 ? 4 : (KW >= 2 ? 2 : 1))), D = KW - P;
-    // words each step still has to produce (bytes needed by the steps after it)
-    constexpr int need1 = 4 + D + (P > 8 ? 8 : 0) + (P > 4 ? 4 : 0) + (P > 2 ? 2 : 0);
-    if constexpr (P >= 2) dcw_shift_max<1, NWT>(E, O, (need1 + 3) / 4);
-    constexpr int need2 = need1 - 2;
-    if constexpr (P >= 4) dcw_shift_max<2, NWT>(E, O, (need2 + 3) / 4);
-    constexpr int need4 = need2 - 4;
-    if constexpr (P >= 8) dcw_shift_max<4, NWT>(E, O, (need4 + 3) / 4);
-    if constexpr (P >= 16) dcw_shift_max<8, NWT>(E, O, (4 + D + 3) / 4);
-    if constexpr (D > 0) dcw_shift_max<D, NWT>(E, O, 1);
-    return E[0] | (O[0] << 8);
-}
 
 template <class F>
 __device__ __forceinline__ void dcw_for_live(u64 live, uint32_t colmask, int lane, F f) {

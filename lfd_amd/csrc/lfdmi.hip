@@ -30,14 +30,14 @@ enum {
     KID_REMOVESTARS = 0, KID_PREP_HIST, KID_LUT, KID_ERODE, KID_DILATE, KID_CANNY_NMS, KID_RUNS_INIT_FG,
     KID_RUNS_MERGE8, KID_RUNS_FLATTEN_FG, KID_EDGE, KID_RUNS_INIT_BG, KID_RUNS_MERGE4, KID_RUNS_FLATTEN_BG,
     KID_KEYS, KID_EXTREMES, KID_RECTS, KID_FILL, KID_PIXLIST, KID_VOTE, KID_PEAKS, KID_TOPK, KID_SORT,
-    KID_FINALIZE, KID_DILATE_CANNY, KID_FRAME_FG, KID_FRAME_BG, KID_FRAME_KEYS, KID_PREP_ERODE, KID_MISC, TG_COUNT
+    KID_FINALIZE, KID_DILATE_CANNY, KID_FRAME_FG, KID_FRAME_BG, KID_FRAME_KEYS, KID_PREP_ERODE, KID_PREP_DUAL, KID_MISC, TG_COUNT
 };
 static const char *const KID_NAMES[TG_COUNT] = {
     "k_removestars", "k_prep_hist", "k_lut", "k_morph(erode)", "k_morph(dilate)", "k_canny_nms", "k_runs_init(fg)",
     "k_runs_merge8", "k_runs_flatten(fg)", "k_edge_from_cand", "k_runs_init(bg)", "k_runs_merge4_bg",
     "k_runs_flatten(bg)", "k_keys", "k_extremes", "k_rects", "k_fill_quads", "k_pixlist", "k_hough_vote",
     "k_hough_peaks", "k_hough_topk", "k_hough_sort", "k_finalize", "k_dilate_canny", "k_frame_fg", "k_frame_bg",
-    "k_frame_keys", "k_prep_erode", "misc"};
+    "k_frame_keys", "k_prep_erode", "k_prep_dual", "misc"};
 
 struct TimedSpan { hipEvent_t a, b; int group, pass, det; };
 
@@ -70,7 +70,18 @@ struct lfdmi_ctx {
     float *lines = nullptr, *tab = nullptr;
     int *counters = nullptr, *need_dim = nullptr;
     uint8_t *zero_block = nullptr;     // cellbm | hist | counters
-    size_t zero_bytes = 0;
+    size_t zero_bytes = 0, zero_counters_off = 0;
+    // second set for the dual front end (lfdmi_detect_batch): the dim pass's histogram and cell bitmap are produced during the
+    // bright pass's front end and must survive the zeroing at the start of the dim pass
+    uint8_t *zero_block2 = nullptr;    // cellbm2 | hist2
+    size_t zero_bytes2 = 0;
+    u64 *cellbm2 = nullptr;            // cell occupancy of the eroded image (dual front end; k_morph_rect_v's output marks)
+    u64 *candmask = nullptr;           // per 64 x 32 tile: the wide erosion can leave something there (k_erode_cand), 2 u64 per tile row
+    u64 *fullbits = nullptr;           // one bit per aligned 4-pixel word of the 8-bit image: all four non-zero (k_prep_hist -> wide erosions)
+    int *hist2 = nullptr;
+    bool fuse_dual = false;            // LFDMI_FUSE_DUAL=1: one sweep over the float frames feeds both passes (measured slower:
+                                       // the band kernel is bound by its instruction stream, not by HBM; kept for experiments)
+    int dual_state = 0;                // 0: none; 1: the next run_front is a bright pass that also feeds the dim pass; 2: dim pass already fed
     int2 *rsa = nullptr;               // k_frame_contours: (row slot, component) per candidate run, FRAME_RUNCAP per slot
     long long *prof = nullptr;         // LFDMI_FRAME_PROFILE=1: per-frame phase clocks of k_frame_contours (developer tool)
     u64 *cellbm = nullptr;             // cell occupancy of the last prep output, bm_bands x CELLBM_WORDS words per slot
@@ -263,6 +274,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     ctx->device = device; ctx->H = max_h; ctx->W = max_w; ctx->G = max_inflight;
     if (const char *e = getenv("LFDMI_FRAME_CCL")) ctx->frame_ccl = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_FUSE_PREP_ERODE")) ctx->fuse_prep_erode = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_FUSE_DUAL")) ctx->fuse_dual = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_VOTE_SPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->vote_split = v; }
     if (const char *e = getenv("LFDMI_PE_ROWS")) { int v = atoi(e); if (v >= 2 && v <= 64) ctx->pe_rows = v; }
     if (const char *e = getenv("LFDMI_FRAME_RUNCAP")) { int v = atoi(e); if (v >= 0 && v < FRAME_RUNCAP) ctx->frame_runcap = v; }
@@ -349,6 +361,15 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
         ctx->counters = (int *)(blk + nb_bm + nb_hist);
         ctx->zero_block = blk;
         ctx->zero_bytes = nb_bm + nb_hist + nb_cnt;
+        ctx->zero_counters_off = nb_bm + nb_hist;
+        uint8_t *blk2 = nullptr;
+        RET(dmalloc(ctx, &blk2, nb_bm + nb_hist));
+        ctx->cellbm2 = (u64 *)blk2;
+        ctx->hist2 = (int *)(blk2 + nb_bm);
+        ctx->zero_block2 = blk2;
+        ctx->zero_bytes2 = nb_bm + nb_hist;
+        RET(dmalloc(ctx, &ctx->fullbits, G * (size_t)max_h * ((max_w + 255) >> 8)));
+        RET(dmalloc(ctx, &ctx->candmask, G * (size_t)((max_h + MORPH_TH - 1) / MORPH_TH) * 2));
     }
     RET(dmalloc(ctx, &ctx->need_dim, G));
     RET(dmalloc(ctx, &ctx->pass_flags, G));
@@ -363,7 +384,8 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     HIPCHK(hipFuncSetAttribute((const void *)k_rects_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_dilate_canny_v, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_frame_fg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_frame_contours, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (FRAME_RUNCAP + 4 * (FRAME_RUNCAP / 32)) * (int)sizeof(int)));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -525,7 +547,7 @@ static dim3 word_grid(int h, int w, int n) { return dim3((unsigned)((h * LFD_WQ(
 
 // ---- stage runners (device pointers only, nc <= G images in workspace slots 0..nc-1) --------
 static int run_prep(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int mode,
-                    double minFlux, double addFlux, const int *active, bool zeroed = false) {
+                    double minFlux, double addFlux, const int *active, bool zeroed = false, u64 *fullbits = nullptr) {
     if (!zeroed) {
         HIPCHK(hipMemsetAsync(ctx->hist, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->cellbm, 0, (size_t)nc * ctx->bm_bands * CELLBM_WORDS * sizeof(u64), ctx->stream));
@@ -533,7 +555,7 @@ static int run_prep(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, i
     {
         Span sp(ctx, KID_PREP_HIST);
         k_prep_hist<<<dim3((h + PREP_ROWS - 1) / PREP_ROWS, nc), 256, 0, ctx->stream>>>(
-            src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist, ctx->cellbm, ctx->bm_bands, active);
+            src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist, ctx->cellbm, ctx->bm_bands, active, fullbits);
         KCHK("k_prep_hist");
     }
     Span sp(ctx, KID_LUT);
@@ -549,7 +571,9 @@ static bool all_ones(const uint8_t *k, int kh, int kw) {
 
 // dst = op(src) with optional LUT / bit rows; kernel mask on the host
 static int run_morph(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, const uint8_t *kernel,
-                     int kh, int kw, int op, int nc, int h, int w, const int *active) {
+                     int kh, int kw, int op, int nc, int h, int w, const int *active, const u64 *fullbits = nullptr, u64 *cellout = nullptr,
+                     bool *marked = nullptr) {
+    if (marked) *marked = false;
     if (!kernel || kh <= 0 || kw <= 0 || kh > LFDMI_MAX_MORPH_K || kw > LFDMI_MAX_MORPH_K)
         return fail(ctx, LFDMI_ERR_UNSUPPORTED, "structuring element must be 1..31 on both sides");
     Span sp(ctx, op ? KID_ERODE : KID_DILATE);
@@ -558,8 +582,19 @@ static int run_morph(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, u64 *bits
         // staged tile + split horizontal result (2 dwords per 4 px) + output tile
         size_t lds = (size_t)IH * (MORPH_TW + 2 * MORPH_HALO) + (size_t)IH * MORPH_TW * 2 + (size_t)MORPH_TH * MORPH_TW;
         dim3 grid((w + MORPH_TW - 1) / MORPH_TW, (h + MORPH_TH - 1) / MORPH_TH, nc);
-        if (op == 0) k_morph_rect_v<0><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active);
-        else k_morph_rect_v<1><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active);
+        const u64 *cand = nullptr;
+        if (op == 1 && fullbits && kw >= 7 && !lut && !bits && grid.x <= 128 && kh <= 33) {
+            // sparse input with its "full word" bits: zero fill + candidate tiles first, then only those tiles are eroded
+            k_erode_cand<<<dim3(grid.y, nc), 64, 0, ctx->stream>>>(fullbits, ctx->candmask, dst, h, w, kh, active);
+            KCHK("k_erode_cand");
+            cand = ctx->candmask;
+        }
+        fullbits = cand;
+        if (op == 0) k_morph_rect_v<0><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active, nullptr, cellout, ctx->bm_bands);
+        else if (kh == 9 && kw == 9 && ctx->dc_specialize) // BASELINE configs[4]: unrolled, running minima by doubling
+            k_morph_rect_v<1, 9, 9><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active, fullbits, cellout, ctx->bm_bands);
+        else k_morph_rect_v<1><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active, fullbits, cellout, ctx->bm_bands);
+        if (marked) *marked = cellout != nullptr;
         KCHK("k_morph_rect_v");
     } else if (all_ones(kernel, kh, kw)) {
         int IH = MORPH_TH + kh - 1, IW = MORPH_TW + kw - 1;
@@ -648,7 +683,8 @@ static bool can_fuse_dilate_canny(const uint8_t *kernel, int kh, int kw, int w) 
 }
 
 static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, int w, const uint8_t *lut, int kh, int kw,
-                            const int *active, bool use_bm) {
+                            const int *active, const u64 *cellbm) {
+    const bool use_bm = cellbm != nullptr;
     if (kh <= DCW_MAXKH) { // one wave per 64 x 16 tile, mask-driven (the sparse pass images)
         int IH = DCW_PH + kh - 1, MGB = DCW_MH * CANNY_MW * 2;
         size_t lds = (size_t)(IH * DCW_TS > MGB ? IH * DCW_TS : MGB) + (size_t)IH * DCW_NWD * 4 + (size_t)DCW_PH * DCW_TS;
@@ -656,7 +692,7 @@ static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, i
         if (ctx->dc_tilelist && tiles_x <= 128 && tiles_y <= DCT_MAXBANDS) {
             // active-tile list from the cell bitmap (or every tile), background of the bit planes, then the tile stages
             Span sp(ctx, KID_DILATE_CANNY);
-            k_dc_tiles<<<nc, DCT_THREADS, 0, ctx->stream>>>(use_bm ? ctx->cellbm : nullptr, ctx->bm_bands, lut, ctx->tile_list, ctx->tile_cap,
+            k_dc_tiles<<<nc, DCT_THREADS, 0, ctx->stream>>>(cellbm, ctx->bm_bands, lut, ctx->tile_list, ctx->tile_cap,
                                                              ctx->counters, ctx->equb, ctx->candb, ctx->strongb, ctx->keep_equ ? ctx->equ : nullptr,
                                                              h, w, active);
             KCHK("k_dc_tiles");
@@ -690,7 +726,8 @@ static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, i
         Span sp(ctx, KID_DILATE_CANNY);
         k_dilate_canny_w<<<grid, 64, lds, ctx->stream>>>(src, ctx->keep_equ ? ctx->equ : nullptr, ctx->equb, ctx->candb,
                                                           ctx->strongb, lut, h, w, kh, kw, 0, 255, active, nc, tiles_x, nstripx, S, SS,
-                                                          use_bm ? ctx->cellbm : nullptr, ctx->bm_bands);
+                                                          cellbm, ctx->bm_bands);
+        (void)use_bm;
         KCHK("k_dilate_canny_w");
         return 0;
     }
@@ -984,8 +1021,9 @@ static int run_prep_erode(lfdmi_ctx *ctx, const void *src, int nc, int h, int w,
     size_t lds = (size_t)(2 * BR + kh - 1) * (w + 32) + 16; // (+ one piece: the sliding window peeks one word ahead)
     {
         Span sp(ctx, KID_PREP_ERODE);
-        k_prep_erode<<<dim3((h + BR - 1) / BR, nc), PE_THREADS, lds, ctx->stream>>>((const float *)src, h, w, flip, mode, (float)minFlux,
-                                                                               (float)addFlux, ctx->tmp, ctx->hist, kh, kw, BR, ctx->cellbm, ctx->bm_bands, active);
+        k_prep_erode<false><<<dim3((h + BR - 1) / BR, nc), PE_THREADS, lds, ctx->stream>>>((const float *)src, h, w, flip, mode, (float)minFlux,
+                                                                               (float)addFlux, ctx->tmp, ctx->hist, kh, kw, BR, ctx->cellbm, ctx->bm_bands, active,
+                                                                               nullptr, nullptr, nullptr);
         KCHK("k_prep_erode");
     }
     Span sp(ctx, KID_LUT);
@@ -994,21 +1032,62 @@ static int run_prep_erode(lfdmi_ctx *ctx, const void *src, int nc, int h, int w,
     return 0;
 }
 
+// Both passes' front ends in one sweep over the float frames (lfdmi_detect_batch): bright image + histogram + cell bitmap into
+// gray / hist / cellbm, dim pass's eroded image + histogram + cell bitmap into tmp / hist2 / cellbm2; LUT of the bright pass.
+static int run_prep_dual(lfdmi_ctx *ctx, const void *src, int nc, int h, int w, int flip, const lfdmi_params *dimp) {
+    int kh = dimp->erode_kh, kw = dimp->erode_kw;
+    int BR = prep_erode_rows(ctx, w, kh);
+    size_t lds = (size_t)(2 * BR + kh - 1) * (w + 32) + 16;
+    HIPCHK(hipMemsetAsync(ctx->zero_block2, 0, ctx->zero_bytes2, ctx->stream));
+    {
+        Span sp(ctx, KID_PREP_DUAL);
+        k_prep_erode<true><<<dim3((h + BR - 1) / BR, nc), PE_THREADS, lds, ctx->stream>>>((const float *)src, h, w, flip, LFDMI_PREP_BRIGHT_THEN_DIM,
+                                                                              (float)dimp->minFlux, (float)dimp->addFlux, ctx->tmp, ctx->hist2, kh, kw, BR,
+                                                                              ctx->cellbm2, ctx->bm_bands, nullptr, ctx->gray, ctx->hist, ctx->cellbm);
+        KCHK("k_prep_dual");
+    }
+    Span sp(ctx, KID_LUT);
+    k_lut<<<nc, 256, 0, ctx->stream>>>(ctx->hist, h * w, ctx->lut, nullptr);
+    KCHK("k_lut");
+    return 0;
+}
+
 // One detection pass on nc images already resident at src (device).  Front end: mask .. fit_minAreaRect (counters,
 // bit rows, box image); tail: HoughLines on both images at one rho + check_theta -> res (device records of the slots).
 static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int prep_mode, bool dim,
-                     const lfdmi_params *p, const int *active) {
-    HIPCHK(hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream)); // counters, histograms, cell bitmap
+                     const lfdmi_params *p, const int *active, const lfdmi_params *dual_dim = nullptr) {
     const uint8_t *dil_src = ctx->gray;
+    const u64 *bm = ctx->cellbm;
+    if (dim && ctx->dual_state == 2) {
+        // the bright pass's front end already produced this pass's eroded image, histogram and cell bitmap (run_prep_dual)
+        HIPCHK(hipMemsetAsync(ctx->zero_block + ctx->zero_counters_off, 0, ctx->zero_bytes - ctx->zero_counters_off, ctx->stream));
+        Span sp(ctx, KID_LUT);
+        k_lut<<<nc, 256, 0, ctx->stream>>>(ctx->hist2, h * w, ctx->lut, active);
+        KCHK("k_lut");
+        dil_src = ctx->tmp;
+        bm = ctx->cellbm2;
+    } else {
+    HIPCHK(hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream)); // counters, histograms, cell bitmap
+    if (!dim && dual_dim) {
+        RET(run_prep_dual(ctx, src, nc, h, w, flip, dual_dim));
+    } else
     if (dim && can_fuse_prep_erode(ctx, dtype, w, p->erodeKernel, p->erode_kh, p->erode_kw)) {
         RET(run_prep_erode(ctx, src, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, p->erode_kh, p->erode_kw, active));
         dil_src = ctx->tmp;
     } else {
-        RET(run_prep(ctx, src, dtype, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, active, true));
+        // (dim: the prep kernel also marks the cells an erosion at least 7 wide can survive in, the erosion marks the cells of
+        // its output: the fused dilate + Canny kernel then only visits tiles near what is left)
+        const bool wide = dim && p->erode_kw >= 7 && dtype == LFDMI_F32 && (w & 3) == 0 && p->erode_kh <= 33;
+        if (dim) HIPCHK(hipMemsetAsync(ctx->zero_block2, 0, ctx->zero_bytes2, ctx->stream));
+        RET(run_prep(ctx, src, dtype, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, active, true, wide ? ctx->fullbits : nullptr));
         if (dim) {
-            RET(run_morph(ctx, ctx->gray, ctx->tmp, nullptr, nullptr, p->erodeKernel, p->erode_kh, p->erode_kw, 1, nc, h, w, active));
+            bool marked = false;
+            RET(run_morph(ctx, ctx->gray, ctx->tmp, nullptr, nullptr, p->erodeKernel, p->erode_kh, p->erode_kw, 1, nc, h, w, active,
+                          wide ? ctx->fullbits : nullptr, ctx->cellbm2, &marked));
             dil_src = ctx->tmp;
+            if (marked) bm = ctx->cellbm2;
         }
+    }
     }
     if (p->gaussKernel > 0) { // optional smoothing of Canny's input (off in the reference): separate dilate, blur, Canny
         RET(run_morph(ctx, dil_src, ctx->equ, ctx->equb, ctx->lut, p->dilateKernel, p->dilate_kh, p->dilate_kw, 0, nc, h, w, active));
@@ -1017,7 +1096,7 @@ static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, 
         RET(run_canny(ctx, (const uint8_t *)ctx->scratch, nc, h, w, 0, 255, active));
     } else if (can_fuse_dilate_canny(p->dilateKernel, p->dilate_kh, p->dilate_kw, w)) {
         // the prep kernel of this pass left the cell occupancy of its output (a superset of the eroded image's)
-        RET(run_dilate_canny(ctx, dil_src, nc, h, w, ctx->lut, p->dilate_kh, p->dilate_kw, active, ctx->use_cellbm));
+        RET(run_dilate_canny(ctx, dil_src, nc, h, w, ctx->lut, p->dilate_kh, p->dilate_kw, active, ctx->use_cellbm ? bm : nullptr));
         RET(run_canny(ctx, ctx->equ, nc, h, w, 0, 255, active, true));
     } else {
         RET(run_morph(ctx, dil_src, ctx->equ, ctx->equb, ctx->lut, p->dilateKernel, p->dilate_kh, p->dilate_kw, 0, nc, h, w, active));
@@ -1043,8 +1122,8 @@ static int run_tail(lfdmi_ctx *ctx, int nc, int h, int w, double rho, bool dim, 
 }
 
 static int run_pass(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int prep_mode, bool dim,
-                    const lfdmi_params *p, const int *active, int *need_dim) {
-    RET(run_front(ctx, src, dtype, nc, h, w, flip, prep_mode, dim, p, active));
+                    const lfdmi_params *p, const int *active, int *need_dim, const lfdmi_params *dual_dim = nullptr) {
+    RET(run_front(ctx, src, dtype, nc, h, w, flip, prep_mode, dim, p, active, dual_dim));
     return run_tail(ctx, nc, h, w, p->houghMethod, dim, p, active, need_dim, ctx->res_dev, false);
 }
 
@@ -1637,11 +1716,17 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
         for (;;) { // (again, with the general run kernels, if a frame turned out to need them)
         k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, ctx->pass_flags, nc);
         KCHK("k_init_results");
+        // both passes read the same float frames: one sweep feeds both where the dim pass's front end can be fused at all
+        const bool dual = ctx->fuse_dual && can_fuse_prep_erode(ctx, LFDMI_F32, w, dim->erodeKernel, dim->erode_kh, dim->erode_kw);
+        struct DualState { lfdmi_ctx *c; ~DualState() { c->dual_state = 0; } } dual_guard{ctx};
         ctx->cur_pass = 0;
-        RET(run_pass(ctx, d, LFDMI_F32, nc, h, w, 1, LFDMI_PREP_BRIGHT, false, bright, nullptr, ctx->need_dim));
+        ctx->dual_state = 0;
+        RET(run_pass(ctx, d, LFDMI_F32, nc, h, w, 1, LFDMI_PREP_BRIGHT, false, bright, nullptr, ctx->need_dim, dual ? dim : nullptr));
         ctx->cur_pass = 1;
+        ctx->dual_state = dual ? 2 : 0;
         RET(run_pass(ctx, d, LFDMI_F32, nc, h, w, 1, LFDMI_PREP_BRIGHT_THEN_DIM, true, dim, ctx->need_dim, nullptr));
         ctx->cur_pass = 0;
+        ctx->dual_state = 0;
         if (host_blot && !blotted) { // host threads zero-fill the caller's frames in the background (joined below / at the end)
             if (blotter.joinable()) blotter.join();
             blotter = std::thread([=, bx = boxes] { blot_host_frames(frames + (size_t)c0 * N, nc, h, w, cat, c0, bx); });
