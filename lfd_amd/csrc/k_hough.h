@@ -43,16 +43,24 @@ k_pixlist(const u64 *bits0, const u64 *bits1, uint32_t *list0, uint32_t *list1, 
     const int nw = h * wq;
     uint32_t *lg = list + (size_t)g * list_cap;
     const int lane = lfd_lane();
+    u64 cw[PIXLIST_WORDS]; // all of a thread's words first: independent loads in flight together
+#pragma unroll
+    for (int it = 0; it < PIXLIST_WORDS; it++) {
+        int idx = (blockIdx.x * PIXLIST_WORDS + it) * 256 + threadIdx.x;
+        cw[it] = idx < nw ? bits[(size_t)g * nw + idx] : 0ull;
+    }
+#pragma unroll
     for (int it = 0; it < PIXLIST_WORDS; it++) {
         int idx = (blockIdx.x * PIXLIST_WORDS + it) * 256 + threadIdx.x;
         if (idx - (int)threadIdx.x >= nw) break;
+        if (__ballot(cw[it] != 0) == 0ull) continue; // a wave of empty words (most of them)
         u64 c = 0;
         int y = 0, q = 0;
         if (idx < nw) {
             y = idx / wq; q = idx - y * wq;
-            c = bits[(size_t)g * nw + idx] & valid_mask(q, w);
+            c = cw[it] & valid_mask(q, w);
         }
-        if (__ballot(c != 0) == 0ull) continue; // a wave of empty words (most of them)
+        if (__ballot(c != 0) == 0ull) continue;
         // chunks of this word: every maximal stretch of set bits, cut every chunk_max pixels
         int n = 0;
         for (u64 r = c; r;) {

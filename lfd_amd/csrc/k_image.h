@@ -1179,6 +1179,7 @@ k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
     __shared__ uint8_t slut[256];
     __shared__ uint32_t Pm[8];                         // input piece column p: rows holding a non-zero byte
     __shared__ u64 rowc[DCW_TH], rows[DCW_TH];         // NMS output bit rows of the tile
+    __shared__ u64 rowe[DCW_TH];                       // != 0 bits of the dilated, equalised tile
     const int lane = threadIdx.x;
     const int ay = kh / 2, ax = kw / 2;
     const size_t N = (size_t)h * w;
@@ -1424,6 +1425,7 @@ k_dilate_canny_t(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
     __shared__ uint8_t slut[256];
     __shared__ uint32_t Pm[8];                         // input piece column p: rows holding a non-zero byte
     __shared__ u64 rowc[DCW_TH], rows[DCW_TH];         // NMS output bit rows of the tile
+    __shared__ u64 rowe[DCW_TH];                       // != 0 bits of the dilated, equalised tile
     const int lane = threadIdx.x;
     const int ay = kh / 2, ax = kw / 2;
     const size_t N = (size_t)h * w;
