@@ -8,8 +8,10 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 #include <string.h>
 
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -108,7 +110,6 @@ struct lfdmi_ctx {
     size_t feed_bytes = 0;
     hipStream_t feed_copy = nullptr;
     hipEvent_t feed_up[2] = {nullptr, nullptr};
-    std::thread feed_thread[2];
     int feed_threads = 8;              // host threads copying a chunk into the pinned buffer (LFDMI_FEED_THREADS)
     size_t feed_chunk_bytes = 800u << 20; // largest feed chunk (LFDMI_FEED_MB): 64 SDSS frames, 11 frames of 4096 x 4096
     int4 *rs_boxes = nullptr;          // remove_stars squares of the chunk (host-frame path)
@@ -429,7 +430,6 @@ extern "C" void lfdmi_ctx_destroy(lfdmi_ctx *ctx) {
     for (void *p : ctx->allocs) hipFree(p);
     if (ctx->stage) hipFree(ctx->stage);
     for (int i = 0; i < 2; i++) {
-        if (ctx->feed_thread[i].joinable()) ctx->feed_thread[i].join();
         if (ctx->feed_pin[i]) hipHostFree(ctx->feed_pin[i]);
         if (ctx->feed_dev[i]) hipFree(ctx->feed_dev[i]);
         if (ctx->feed_up[i]) hipEventDestroy(ctx->feed_up[i]);
@@ -1628,37 +1628,59 @@ static int feed_prepare(lfdmi_ctx *ctx, size_t bytes) {
     return 0;
 }
 
-// Chunk `slot`: host threads copy the caller's bytes into the pinned buffer piece by piece, and every piece is sent on
-// its way (copy stream) as soon as it is staged, so the DMA engine starts after the first piece (32 MB, < 1 ms), not
-// after the whole chunk.  Runs on its own thread; feed_wait joins it and makes the launch stream wait for the upload.
+// One feeder thread per call walks the chunks IN ORDER: host threads copy a piece (32 MB) of the caller's frames into the
+// pinned buffer of the chunk's slot, the piece is sent on its way at once (copy stream), and after the chunk's last piece an
+// event is recorded.  The DMA engine therefore starts after the first piece (< 1 ms) and never sees two chunks interleaved.
+// Chunk j reuses the buffers of chunk j - 2: the feeder waits until the main thread has finished that chunk (`done`).
 #define FEED_PIECE (32u << 20)
-static void feed_chunk_async(lfdmi_ctx *ctx, int slot, const char *src, size_t bytes) {
-    char *pin = (char *)ctx->feed_pin[slot], *dev = (char *)ctx->feed_dev[slot];
+struct FeedState {
+    std::atomic<int> issued{0}, done{0};
+    std::atomic<bool> stop{false};
+    std::thread th;
+};
+static void feed_start(lfdmi_ctx *ctx, FeedState *fs, const char *src, size_t frame_bytes, int n, int per) {
+    char *pin[2] = {(char *)ctx->feed_pin[0], (char *)ctx->feed_pin[1]}, *dev[2] = {(char *)ctx->feed_dev[0], (char *)ctx->feed_dev[1]};
+    hipEvent_t up[2] = {ctx->feed_up[0], ctx->feed_up[1]};
     const int T = ctx->feed_threads, device = ctx->device;
     hipStream_t copy = ctx->feed_copy;
-    hipEvent_t up = ctx->feed_up[slot];
-    ctx->feed_thread[slot] = std::thread([=] {
+    fs->th = std::thread([=] {
         hipSetDevice(device);
-        for (size_t o = 0; o < bytes; o += FEED_PIECE) {
-            size_t pb = std::min<size_t>(FEED_PIECE, bytes - o);
-            int t_n = pb >= (size_t)T * (1u << 20) ? T : 1;
-            std::vector<std::thread> th;
-            for (int t = 1; t < t_n; t++) {
-                size_t a = pb / t_n * t, b = (t == t_n - 1) ? pb : pb / t_n * (t + 1);
-                th.emplace_back([=] { memcpy(pin + o + a, src + o + a, b - a); });
+        int j = 0;
+        for (int c0 = 0; c0 < n; c0 += per, j++) {
+            while (fs->done.load(std::memory_order_acquire) < j - 1) { // buffers of chunk j - 2 still in use
+                if (fs->stop.load()) return;
+                std::this_thread::yield();
             }
-            memcpy(pin + o, src + o, t_n > 1 ? pb / t_n : pb);
-            for (auto &x : th) x.join();
-            hipMemcpyAsync(dev + o, pin + o, pb, hipMemcpyHostToDevice, copy);
+            const size_t bytes = (size_t)std::min(per, n - c0) * frame_bytes;
+            const char *s = src + (size_t)c0 * frame_bytes;
+            const int slot = j & 1;
+            for (size_t o = 0; o < bytes; o += FEED_PIECE) {
+                size_t pb = std::min<size_t>(FEED_PIECE, bytes - o);
+                int t_n = pb >= (size_t)T * (1u << 20) ? T : 1;
+                std::vector<std::thread> th;
+                for (int t = 1; t < t_n; t++) {
+                    size_t a = pb / t_n * t, b = (t == t_n - 1) ? pb : pb / t_n * (t + 1);
+                    th.emplace_back([=] { memcpy(pin[slot] + o + a, s + o + a, b - a); });
+                }
+                memcpy(pin[slot] + o, s + o, t_n > 1 ? pb / t_n : pb);
+                for (auto &x : th) x.join();
+                hipMemcpyAsync(dev[slot] + o, pin[slot] + o, pb, hipMemcpyHostToDevice, copy);
+            }
+            hipEventRecord(up[slot], copy);
+            fs->issued.store(j + 1, std::memory_order_release);
         }
-        hipEventRecord(up, copy);
     });
 }
 
-static int feed_wait(lfdmi_ctx *ctx, int slot) {
-    if (ctx->feed_thread[slot].joinable()) ctx->feed_thread[slot].join();
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->feed_up[slot], 0));
+static double feed_now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+// the launch stream waits for chunk j's upload
+static int feed_wait(lfdmi_ctx *ctx, FeedState *fs, int j) {
+    while (fs->issued.load(std::memory_order_acquire) <= j) std::this_thread::yield();
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->feed_up[j & 1], 0));
     return 0;
 }
 
@@ -1692,24 +1714,28 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
         size_t fpc = ctx->feed_chunk_bytes / (N * 4);
         per = (int)std::min<size_t>((size_t)ctx->G, std::max<size_t>(1, fpc));
         RET(feed_prepare(ctx, (size_t)std::min(per, n) * N * 4));
-        feed_chunk_async(ctx, 0, (const char *)frames, (size_t)std::min(per, n) * N * 4);
-        if (per < n) feed_chunk_async(ctx, 1, (const char *)frames + (size_t)per * N * 4, (size_t)std::min(per, n - per) * N * 4);
     }
+    FeedState fs;
     std::thread blotter; // remove_stars on the caller's host array (see blot_host_frames)
-    struct FeedJoin { lfdmi_ctx *c; std::thread *b; ~FeedJoin() { for (auto &t : c->feed_thread) if (t.joinable()) t.join(); if (b->joinable()) b->join(); } }
-        feed_join{ctx, &blotter}; // (every exit path)
+    struct FeedJoin { FeedState *f; std::thread *b; ~FeedJoin() { f->stop.store(true); f->done.store(1 << 30); if (f->th.joinable()) f->th.join(); if (b->joinable()) b->join(); } }
+        feed_join{&fs, &blotter}; // (every exit path)
+    if (feed) feed_start(ctx, &fs, (const char *)frames, N * 4, n, per);
     for (int c0 = 0, kc = 0; c0 < n; c0 += per, kc++) {
         int nc = n - c0 < per ? n - c0 : per;
         const void *d;
         if (feed) {
             d = ctx->feed_dev[kc & 1];
-            RET(feed_wait(ctx, kc & 1)); // the launch stream waits for chunk kc's upload (chunk kc + 1 follows it back to back)
+            RET(feed_wait(ctx, &fs, kc)); // the launch stream waits for chunk kc's upload (chunk kc + 1 follows it back to back)
         } else RET(in_ptr(ctx, frames, (size_t)c0 * N * 4, (size_t)nc * N * 4, loc, &d));
         const bool host_blot = cat && loc == LFDMI_HOST && cat->loc == LFDMI_HOST;
         if (cat) {
             RET(run_removestars(ctx, (float *)d, c0, nc, h, w, cat, rs, host_blot ? &boxes : nullptr));
             if (loc == LFDMI_HOST && !host_blot) RET(out_copy(ctx, frames, (size_t)c0 * N * 4, d, (size_t)nc * N * 4, loc));
-            if (host_blot) HIPCHK(hipStreamSynchronize(ctx->stream)); // the squares are on the host; the passes are enqueued next
+            if (host_blot) {
+                double t0_ = feed && getenv("LFDMI_FEED_TRACE") ? feed_now() : 0;
+                HIPCHK(hipStreamSynchronize(ctx->stream)); // the squares are on the host; the passes are enqueued next
+                if (t0_ > 0) fprintf(stderr, "[feed] chunk %d: upload + remove_stars synced after %.2f ms (t=%.2f)\n", kc, feed_now() - t0_, feed_now());
+            }
         }
         bool blotted = false;
         GeneralGuard gg(ctx);
@@ -1734,7 +1760,9 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
         }
         HIPCHK(hipMemcpyAsync(host.data(), ctx->res_dev, (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(flags.data(), ctx->pass_flags, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        { double t0_ = feed && getenv("LFDMI_FEED_TRACE") ? feed_now() : 0;
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (t0_ > 0) fprintf(stderr, "[feed] chunk %d (%d frames): passes synced after %.2f ms (t=%.2f)\n", kc, nc, feed_now() - t0_, feed_now()); }
         if (!gg.again(flags.data(), nc)) break;
         }
         {
@@ -1742,10 +1770,7 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
             for (int i = 0; i < nc; i++) { nd[0] += flags[i] & 1; na[1] += (flags[i] >> 1) & 1; nd[1] += (flags[i] >> 2) & 1; }
             RET(sync(ctx, nc, na, nd));
         }
-        if (feed && c0 + 2 * per < n) { // this chunk's two buffers are free again (its upload and passes are done): chunk kc + 2 starts
-            int nn = std::min(per, n - (c0 + 2 * per));
-            feed_chunk_async(ctx, kc & 1, (const char *)frames + (size_t)(c0 + 2 * per) * N * 4, (size_t)nn * N * 4);
-        }
+        if (feed) fs.done.store(kc + 1, std::memory_order_release); // this chunk's two buffers are free again: chunk kc + 2 may start
         for (int i = 0; i < nc; i++) {
             if (host[i].status == LFDMI_ERR_CAPACITY) {
                 // a table of this workspace was too small for the frame: once more, alone, in the worst-case workspace.
