@@ -1,4 +1,5 @@
-// Developer probe (not part of the library): costs of the host->device feed primitives on this box.
+// Developer probe (not part of the library): costs of the host->device feed primitives on this box (pageable vs pinned vs
+// registered memory, threaded staging).  hipcc --offload-arch=gfx950 -O2 -o tools/feed_probe tools/feed_probe.cpp -lpthread
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
