@@ -63,24 +63,30 @@ KERNEL_BYTES_PER_PX = {
     "k_runs_init(fg)": 0.25, "k_frame_fg": 0.75, "k_runs_init(bg)": 0.25, "k_frame_bg": 1.0, "k_rects": 0.5, "k_fill_quads": 0.25,
     "k_pixlist": 0.5, "k_hough_vote": 1.25, "k_hough_peaks": 0.25,
 }
-TRAFFIC_KEYS = {"k_morph(dilate)": "k_morph_rect_v<0>", "k_morph(erode)": "k_morph_rect_v<1>", "k_canny_nms": "k_canny_nms_v",
-                "k_dilate_canny": "k_dilate_canny_w", "k_frame_bg": "k_frame_contours"}
+# timing slot of the library -> the kernels it brackets, as rocprofv3 names them (template variants are averaged, the kernels of a slot summed)
+TRAFFIC_KEYS = {"k_morph(dilate)": ["k_morph_rect_v<0"], "k_morph(erode)": ["k_erode_cand", "k_morph_rect_v<1"], "k_canny_nms": ["k_canny_nms_v"],
+                "k_dilate_canny": ["k_dc_tiles", "k_dilate_canny_t"], "k_frame_bg": ["k_frame_contours"], "k_prep_dual": ["k_prep_erode<true"],
+                "k_prep_erode": ["k_prep_erode<false"]}
 
 
 def load_traffic(name, cfg):
-    """HBM bytes per launch of kernel `name` from the committed PMC passes (profiles/r*_traffic.json), for this config only."""
+    """HBM bytes per launch of kernel `name` from the committed PMC passes (profiles/r*_traffic*.json), for this config only."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
         try:
             with open(path) as f:
                 tj = json.load(f)
             c = tj["config"]
             if (c.get("workload", "sdss"), c["frames_per_gpu"], c["inflight"], c["lanes"], c["shape"]) != cfg:
                 continue
-            key = TRAFFIC_KEYS.get(name, name.split("(")[0])
-            for k, v in tj["kernels"].items():
-                if k == key or k.startswith(key + "<"):
-                    return v["hbm_bytes_per_launch"], os.path.basename(path)
+            total = 0
+            for key in TRAFFIC_KEYS.get(name, [name.split("(")[0]]):
+                hits = [v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items() if k == key or k.startswith(key + "<") or k.startswith(key + ",")
+                        or (key.endswith(("<0", "<1", "<false", "<true")) and k.startswith(key))]
+                if not hits:
+                    raise KeyError(key)
+                total += sum(hits) / len(hits)
+            return int(total), os.path.basename(path)
         except (OSError, KeyError, ValueError):
             continue
     return None, None

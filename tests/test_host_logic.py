@@ -166,3 +166,19 @@ def test_synthetic_frames_are_deterministic():
         assert t["streak"] == gold[str(k)]["streak"] and len(c["NOBSERVE"]) == gold[str(k)]["n_obj"]
     c1 = synth.make_config1_frame()
     assert c1.dtype == np.uint8 and c1.shape == (1489, 2048) and set(np.unique(c1)) == {0, 200, 255}
+
+
+def test_parallel_frame_generator_matches_the_serial_one():
+    """bench.py / tools generate their frames with child processes (never forks of a possibly GPU-initialised caller);
+    the frames and catalogues are those of synth.make_frame."""
+    shape = (96, 128)
+    frames, cats = synth.make_frames(5, 6, shape, workers=3)
+    assert frames.shape == (6, 96, 128) and frames.dtype == np.float32 and len(cats) == 6
+    for i in range(6):
+        img, cat, _ = synth.make_frame(5 + i, shape)
+        assert np.array_equal(frames[i], img)
+        for k in cat:
+            assert np.array_equal(cats[i][k], cat[k]), k
+    one, cats1 = synth.make_frames(7, 1, shape, workers=8, with_catalog=False)
+    assert np.array_equal(one[0], synth.make_frame(7, shape)[0]) and cats1 == [None]
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("lfd_synth_")] if os.path.isdir("/dev/shm") else True
