@@ -49,16 +49,32 @@ k_pixlist(const u64 *bits0, const u64 *bits1, uint32_t *list0, uint32_t *list1, 
         int idx = (blockIdx.x * PIXLIST_WORDS + it) * 256 + threadIdx.x;
         cw[it] = idx < nw ? bits[(size_t)g * nw + idx] : 0ull;
     }
+    // Most words are empty and the rest are scattered: a wave first packs its non-zero words (up to 64 PIXLIST_WORDS of them)
+    // into LDS and then cuts them into chunks with all lanes busy, instead of running the chunk loops once per 64 words
+    // with one or two live lanes.
+    __shared__ u64 sw[4][PIXLIST_WORDS * 64];
+    __shared__ int si[4][PIXLIST_WORDS * 64];
+    const int wv = threadIdx.x >> 6;
+    int nloc = 0;
 #pragma unroll
     for (int it = 0; it < PIXLIST_WORDS; it++) {
-        int idx = (blockIdx.x * PIXLIST_WORDS + it) * 256 + threadIdx.x;
-        if (idx - (int)threadIdx.x >= nw) break;
-        if (__ballot(cw[it] != 0) == 0ull) continue; // a wave of empty words (most of them)
+        const u64 bal = __ballot(cw[it] != 0);
+        if (bal == 0ull) continue; // a wave of empty words (most of them)
+        if (cw[it]) {
+            int pos = nloc + __popcll(bal & ((1ull << lane) - 1ull));
+            sw[wv][pos] = cw[it];
+            si[wv][pos] = (blockIdx.x * PIXLIST_WORDS + it) * 256 + threadIdx.x;
+        }
+        nloc += __popcll(bal);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int kb = 0; kb < nloc; kb += 64) {
         u64 c = 0;
         int y = 0, q = 0;
-        if (idx < nw) {
+        if (kb + lane < nloc) {
+            int idx = si[wv][kb + lane];
             y = idx / wq; q = idx - y * wq;
-            c = cw[it] & valid_mask(q, w);
+            c = sw[wv][kb + lane] & valid_mask(q, w);
         }
         if (__ballot(c != 0) == 0ull) continue;
         // chunks of this word: every maximal stretch of set bits, cut every chunk_max pixels

@@ -98,13 +98,41 @@ __device__ __forceinline__ unsigned prep_f32(float x, int mode, float mf, float 
     if (mode & 2) { if (x < mf) x = 0.0f; if (x > 0.0f) x = __fadd_rn(x, af); }
     return sat_u8_f32(x);
 }
+// the same with the mode known at compile time and selects instead of branches (the float kernels are bound by their
+// instruction stream, not by HBM: every instruction per pixel counts)
+template <int MODE>
+__device__ __forceinline__ unsigned prep_f32_m(float x, float mf, float af) {
+    if (MODE & 1) x = x < 0.0f ? 0.0f : x;
+    if (MODE & 2) { x = x < mf ? 0.0f : x; x = x > 0.0f ? __fadd_rn(x, af) : x; }
+    return sat_u8_f32(x);
+}
+// Histogram of four converted pixels (one packed word).  Sky frames are zeros (bright pass) or zeros and ones (dim pass:
+// 78 % / 22 %): words made of those two values are counted in registers (n01 words, ones01 one-bytes among them), only
+// the others touch the LDS histogram.
+struct HistAcc { int n01 = 0, ones01 = 0, zeros = 0, ones = 0; };
+__device__ __forceinline__ void hist_word(uint32_t word, int *shrow, HistAcc &A) {
+    if ((word & 0xFEFEFEFEu) == 0u) { A.n01++; A.ones01 += __popc(word); return; }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        unsigned v = (word >> (8 * q)) & 0xffu;
+        if (v > 1u) atomicAdd(&shrow[v], 1);
+        else if (v) A.ones++;
+        else A.zeros++;
+    }
+}
+__device__ __forceinline__ void hist_flush(HistAcc &A, int *shrow) { // one LDS add per wave and value
+    int z = 4 * A.n01 - A.ones01 + A.zeros, o = A.ones01 + A.ones;
+    for (int off = 32; off > 0; off >>= 1) { z += __shfl_down(z, off); o += __shfl_down(o, off); }
+    if (lfd_lane() == 0 && z) atomicAdd(&shrow[0], z);
+    if (lfd_lane() == 0 && o) atomicAdd(&shrow[1], o);
+}
+__device__ __forceinline__ bool no_zero_byte(uint32_t w) { return ((w - 0x01010101u) & ~w & 0x80808080u) == 0u; }
 __device__ __forceinline__ unsigned prep_f64(double x, int mode, double mf, double af) {
     if (mode & 1) { if (x < 0.0) x = 0.0; }
     if (mode & 2) { if (x < mf) x = 0.0; if (x > 0.0) x = __dadd_rn(x, af); }
     return sat_u8_f64(x);
 }
 
-#define PREP_ROWS 4
 
 // Cell occupancy bitmap handed from the prep kernels to k_dilate_canny_w: per band of 16 image rows
 // CELLBM_WORDS u64, bit c = "some byte of columns 16 c .. 16 c + 15 of this band is non-zero" (a superset is
@@ -112,11 +140,12 @@ __device__ __forceinline__ unsigned prep_f64(double x, int mode, double mf, doub
 #define CELLBM_ROWS 16
 #define CELLBM_COLS 16
 #define CELLBM_WORDS 8 // 512 cells: image widths up to 8191
-static_assert(16 % PREP_ROWS == 0, "a workgroup's rows lie in one band");
 
+template <int MODE> // 0 .. 3: float32 frames with the mode known at compile time; -1: any dtype, run-time mode
 __global__ void __launch_bounds__(256)
 k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double minFlux,
-            double addFlux, uint8_t *gray, int *hist, u64 *cellbm, int bm_bands, const int *active, u64 *fullbits) {
+            double addFlux, uint8_t *gray, int *hist, u64 *cellbm, int bm_bands, const int *active, u64 *fullbits,
+            int prep_rows) { // rows per workgroup: a divisor of CELLBM_ROWS (a workgroup's rows lie in one band)
     int g = blockIdx.y;
     if (active && !active[g]) return;
     __shared__ int sh[4][256];
@@ -126,33 +155,46 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
     size_t N = (size_t)h * w;
     uint8_t *gout = gray + (size_t)g * N;
     int zeros = 0;
-    int r0 = blockIdx.x * PREP_ROWS;
+    HistAcc acc;
+    int r0 = blockIdx.x * prep_rows;
     float mf = (float)minFlux, af = (float)addFlux;
     unsigned nzpos = 0; // bit i: this lane met a non-zero value at its i-th column position (any of the rows)
-    for (int r = r0; r < r0 + PREP_ROWS && r < h; r++) {
-        int sr = flip ? (h - 1 - r) : r;
-        if (dtype == 1 && (w & 3) == 0) {
-            const float4 *s = (const float4 *)((const float *)src + (size_t)g * N + (size_t)sr * w);
-            uchar4 *d = (uchar4 *)(gout + (size_t)r * w);
+    if (MODE >= 0) {
+        // float rows, four pixels per lane; the loads of four rows are issued together (64 B per lane in flight: the kernel
+        // lives on memory latency otherwise)
+        const float *fs = (const float *)src + (size_t)g * N;
+        for (int rb = r0; rb < r0 + prep_rows && rb < h; rb += 4) {
             for (int x4 = threadIdx.x, i = 0; x4 < (w >> 2); x4 += 256, i++) {
-                float4 v = s[x4];
-                unsigned a = prep_f32(v.x, mode, mf, af), b = prep_f32(v.y, mode, mf, af),
-                         c = prep_f32(v.z, mode, mf, af), e = prep_f32(v.w, mode, mf, af);
-                d[x4] = make_uchar4((unsigned char)a, (unsigned char)b, (unsigned char)c, (unsigned char)e);
-                if (a | b | c | e) nzpos |= 1u << i;
-                // one bit per aligned word of four pixels: "all four non-zero".  Only where such words line up can a wide
-                // erosion leave anything (k_morph_rect_v decides from these bits without loading the image); a wave's 64
-                // lanes are 64 consecutive words, so the ballot is one u64 of the plane
-                if (fullbits) {
-                    u64 fb = __ballot(a && b && c && e);
-                    if (lfd_lane() == 0) fullbits[((size_t)g * h + r) * ((w + 255) >> 8) + (x4 >> 6)] = fb;
+                float4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int r = rb + k;
+                    if (k < prep_rows && r < h) v[k] = ((const float4 *)(fs + (size_t)(flip ? (h - 1 - r) : r) * w))[x4];
                 }
-                if (a) atomicAdd(&sh[wv][a], 1); else zeros++;
-                if (b) atomicAdd(&sh[wv][b], 1); else zeros++;
-                if (c) atomicAdd(&sh[wv][c], 1); else zeros++;
-                if (e) atomicAdd(&sh[wv][e], 1); else zeros++;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int r = rb + k;
+                    if (k >= prep_rows || r >= h) break;
+                    constexpr int M = MODE >= 0 ? MODE : 0;
+                    const uint32_t word = prep_f32_m<M>(v[k].x, mf, af) | (prep_f32_m<M>(v[k].y, mf, af) << 8) |
+                                          (prep_f32_m<M>(v[k].z, mf, af) << 16) | (prep_f32_m<M>(v[k].w, mf, af) << 24);
+                    ((uint32_t *)(gout + (size_t)r * w))[x4] = word;
+                    if (word) nzpos |= 1u << i;
+                    // one bit per aligned word of four pixels: "all four non-zero".  Only where such words line up can a wide
+                    // erosion leave anything (k_morph_rect_v decides from these bits without loading the image); a wave's 64
+                    // lanes are 64 consecutive words, so the ballot is one u64 of the plane
+                    if (fullbits) {
+                        u64 fb = __ballot(no_zero_byte(word));
+                        if (lfd_lane() == 0) fullbits[((size_t)g * h + r) * ((w + 255) >> 8) + (x4 >> 6)] = fb;
+                    }
+                    hist_word(word, sh[wv], acc);
+                }
             }
-        } else {
+        }
+    } else
+    for (int r = r0; r < r0 + prep_rows && r < h; r++) {
+        int sr = flip ? (h - 1 - r) : r;
+        {
             for (int x = threadIdx.x, i = 0; x < w; x += 256, i++) {
                 unsigned a;
                 size_t k = (size_t)g * N + (size_t)sr * w + x;
@@ -166,12 +208,12 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
         }
     }
     // zeros dominate sky frames: count them in registers, one LDS add per wave
-    for (int off = 32; off > 0; off >>= 1) zeros += __shfl_down(zeros, off);
-    if (lfd_lane() == 0 && zeros) atomicAdd(&sh[wv][0], zeros);
+    acc.zeros += zeros;
+    hist_flush(acc, sh[wv]);
     // occupied cells of this workgroup's rows (one band): position i of wave wv covers ppl pixels per lane
     // from column 256 ppl i + 64 ppl wv on, i.e. (64 ppl / 16) cells
     if (cellbm && r0 < h) {
-        const int ppl = (dtype == 1 && (w & 3) == 0) ? 4 : 1, lpc = CELLBM_COLS / ppl; // lanes per cell: 4 or 16
+        const int ppl = MODE >= 0 ? 4 : 1, lpc = CELLBM_COLS / ppl; // lanes per cell: 4 or 16
         u64 *bw = cellbm + ((size_t)g * bm_bands + r0 / CELLBM_ROWS) * CELLBM_WORDS;
         for (int i = 0; (256 * ppl) * i < w; i++) {
             u64 m = __ballot((nzpos >> i) & 1u);
@@ -206,7 +248,7 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
 // and its cell occupancy (gray_b / hist_b / cellbm_b) for the band's own rows: lfdmi_detect_batch runs both passes on the
 // same frames, so the 12.2 MB of a frame cross HBM once instead of twice (the dim outputs of frames the bright pass then
 // accepts are not used).
-template <bool DUAL>
+template <bool DUAL, int MODE>
 __global__ void __launch_bounds__(PE_THREADS)
 k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float af, uint8_t *dst, int *hist, int kh, int kw,
              int BR, u64 *cellbm, int bm_bands, const int *active, uint8_t *gray_b, int *hist_b, u64 *cellbm_b) {
@@ -229,7 +271,8 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
         band[r * SW + (k < 4 ? k : W4 + k)] = 0xFFFFFFFFu;
     }
     __syncthreads();
-    int zeros = 0, ones = 0, zeros_b = 0;
+    int zeros_b = 0;
+    HistAcc acc;
     // piece `it` of the band is (row it / W4, 16-byte column it % W4); a lane's pieces are PE_THREADS apart, so it carries
     // (row, column) along instead of dividing for every piece (an integer division is ~40 vector instructions)
     const int dr1 = PE_THREADS / W4, dx1 = PE_THREADS - dr1 * W4;
@@ -257,13 +300,10 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
             if (r >= R) continue;
             uint32_t word = 0xFFFFFFFFu;
             if (gyv[u] >= 0) {
-                unsigned a = prep_f32(v[u].x, mode, mf, af), b = prep_f32(v[u].y, mode, mf, af), c = prep_f32(v[u].z, mode, mf, af),
-                         e = prep_f32(v[u].w, mode, mf, af);
-                word = a | (b << 8) | (c << 16) | (e << 24);
+                word = prep_f32_m<MODE>(v[u].x, mf, af) | (prep_f32_m<MODE>(v[u].y, mf, af) << 8) |
+                       (prep_f32_m<MODE>(v[u].z, mf, af) << 16) | (prep_f32_m<MODE>(v[u].w, mf, af) << 24);
                 if (gyv[u] >= y0 && gyv[u] < y0 + BR) { // the band's own rows: every image row is counted once
-                    // (a dim-pass sky is zeros and ones: both are counted in registers, the rest goes to the LDS histogram)
-                    auto cnt = [&](unsigned q) { if (q == 0) zeros++; else if (q == 1) ones++; else atomicAdd(&sh[wv][q], 1); };
-                    cnt(a); cnt(b); cnt(c); cnt(e);
+                    hist_word(word, sh[wv], acc);
                     if (DUAL) { // the bright pass's image of the same pixels
                         unsigned a2 = prep_f32(v[u].x, 1, 0.f, 0.f), b2 = prep_f32(v[u].y, 1, 0.f, 0.f), c2 = prep_f32(v[u].z, 1, 0.f, 0.f),
                                  e2 = prep_f32(v[u].w, 1, 0.f, 0.f);
@@ -283,14 +323,11 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
             band[r * SW + 4 + x4] = word;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        zeros += __shfl_down(zeros, off);
-        ones += __shfl_down(ones, off);
-        if (DUAL) zeros_b += __shfl_down(zeros_b, off);
+    hist_flush(acc, sh[wv]);
+    if (DUAL) {
+        for (int off = 32; off > 0; off >>= 1) zeros_b += __shfl_down(zeros_b, off);
+        if (lfd_lane() == 0 && zeros_b) atomicAdd(&sh[NH + wv][0], zeros_b);
     }
-    if (lfd_lane() == 0 && zeros) atomicAdd(&sh[wv][0], zeros);
-    if (lfd_lane() == 0 && ones) atomicAdd(&sh[wv][1], ones);
-    if (DUAL && lfd_lane() == 0 && zeros_b) atomicAdd(&sh[NH + wv][0], zeros_b);
     __syncthreads();
     if (threadIdx.x < 256) {
         int b = threadIdx.x, t = 0;
@@ -321,6 +358,7 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
     // horizontal minimum and store: 16 output bytes per lane
     uint8_t *d = dst + (size_t)g * N;
     const int W16 = w >> 4;
+    const bool near_only = ax <= 4 && kw - 1 - ax <= 4; // the window reaches at most one word beyond the piece
     const int drh = PE_THREADS / W16, dxh = PE_THREADS - drh * W16;
     int oh_c = threadIdx.x / W16, xh_c = threadIdx.x - oh_c * W16;
     for (int it = threadIdx.x; it < BR * W16; it += PE_THREADS) {
@@ -331,6 +369,15 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
         if (gy >= h) continue;
         const uint32_t *rw = vbuf + o * SW;
         uint32_t outw[4];
+        if (near_only) {
+            // the vertical minimum of a sky frame is zero almost everywhere (a byte survives only where kh rows are all
+            // non-zero): a piece whose 16 bytes and the words either side of them are clear erodes to zeros
+            const uint4 cpc = *(const uint4 *)(rw + 4 + 4 * x16);
+            if ((cpc.x | cpc.y | cpc.z | cpc.w | rw[3 + 4 * x16] | rw[8 + 4 * x16]) == 0u) {
+                *(uint4 *)(d + (size_t)gy * w + 16 * x16) = make_uint4(0, 0, 0, 0);
+                continue;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             int ob = 16 + 16 * x16 + 4 * q - ax; // byte offset of the window's first column in the padded row

@@ -153,7 +153,7 @@ struct lfdmi_ctx {
     bool dc_specialize = true;         // LFDMI_DC_SPECIALIZE=0: the run-time-size instantiation of k_dilate_canny_t for every kernel size
     bool dc_profile = false;           // LFDMI_DC_PROFILE=1: stage clocks of k_dilate_canny_t into `prof` (developer tool)
     bool dc_tilelist = true;           // LFDMI_DC_TILELIST=0: the strip-walking kernel k_dilate_canny_w instead
-    int dc_parts = 0;                  // waves per frame of k_dilate_canny_t (0: tiles per frame / 64, LFDMI_DC_PARTS)
+    int dc_parts = 0;                  // waves per frame of k_dilate_canny_t (0: tiles per frame / 8, at most 256; LFDMI_DC_PARTS)
     int dc_substrips = 4;              // strips a wave of k_dilate_canny_w walks one after the other
     int dc_strip = 8;                  // tiles per wave strip in k_dilate_canny_w
     bool keep_equ = true;              // write the equalised+dilated stage image (off in lfdmi_detect_batch)
@@ -385,8 +385,11 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     HIPCHK(hipFuncSetAttribute((const void *)k_rects_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_dilate_canny_v, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_frame_fg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<true, LFDMI_PREP_BRIGHT_THEN_DIM>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_frame_contours, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (FRAME_RUNCAP + 4 * (FRAME_RUNCAP / 32)) * (int)sizeof(int)));
     HIPCHK(hipFuncSetAttribute((const void *)k_morph_rect<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -554,8 +557,24 @@ static int run_prep(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, i
     }
     {
         Span sp(ctx, KID_PREP_HIST);
-        k_prep_hist<<<dim3((h + PREP_ROWS - 1) / PREP_ROWS, nc), 256, 0, ctx->stream>>>(
-            src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist, ctx->cellbm, ctx->bm_bands, active, fullbits);
+        static const int prep_rows = [] { // rows per workgroup (tuning knob): 1, 2, 4, 8 or 16
+            const char *e = getenv("LFDMI_PREP_ROWS");
+            int v = e ? atoi(e) : 8;
+            return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 8;
+        }();
+        const dim3 pgrid((h + prep_rows - 1) / prep_rows, nc);
+#define LFD_PREP_LAUNCH(M_)                                                                                                          \
+    k_prep_hist<M_><<<pgrid, 256, 0, ctx->stream>>>(src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist, ctx->cellbm, \
+                                                    ctx->bm_bands, active, fullbits, prep_rows)
+        if (dtype == LFDMI_F32 && (w & 3) == 0) { // float frames: the mode as a compile-time constant
+            switch (mode & 3) {
+            case 0: LFD_PREP_LAUNCH(0); break;
+            case 1: LFD_PREP_LAUNCH(1); break;
+            case 2: LFD_PREP_LAUNCH(2); break;
+            default: LFD_PREP_LAUNCH(3); break;
+            }
+        } else LFD_PREP_LAUNCH(-1);
+#undef LFD_PREP_LAUNCH
         KCHK("k_prep_hist");
     }
     Span sp(ctx, KID_LUT);
@@ -696,7 +715,9 @@ static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, i
                                                              ctx->counters, ctx->equb, ctx->candb, ctx->strongb, ctx->keep_equ ? ctx->equ : nullptr,
                                                              h, w, active);
             KCHK("k_dc_tiles");
-            int parts = ctx->dc_parts > 0 ? ctx->dc_parts : std::max(8, std::min(256, tiles_x * tiles_y / 64));
+            // many short waves: the dispatcher evens out frames and regions with more occupied tiles than others (a wave gets
+            // 1 / parts of the frame's list: 3-5 tiles on SDSS frames; 47 parts: 1.46 ms per step, 256: 1.29 ms)
+            int parts = ctx->dc_parts > 0 ? ctx->dc_parts : std::max(8, std::min(256, tiles_x * tiles_y / 8));
             unsigned grid = 8u * ((nc + 7) / 8) * parts;
             long long *prof = nullptr;
             if (ctx->dc_profile && ctx->prof) {
@@ -947,7 +968,8 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
     {
         // cut each pixel list into pieces so that a launch carries several workgroups per CU
         int nsplit = 1;
-        while (nsplit < ctx->vote_split && nslabs * n_img * nc * nsplit < 6144) nsplit <<= 1;
+        static const int vote_wgs = getenv("LFDMI_VOTE_WGS") ? atoi(getenv("LFDMI_VOTE_WGS")) : 6144;
+        while (nsplit < ctx->vote_split && nslabs * n_img * nc * nsplit < vote_wgs) nsplit <<= 1;
         int acc_n = (na + 2) * (nr + 2);
         { Span sp(ctx, KID_PIXLIST, need_detect);
         // per-slot accumulator pairs are 2 * acc_cap apart; the kernel indexes by slot itself
@@ -1021,9 +1043,17 @@ static int run_prep_erode(lfdmi_ctx *ctx, const void *src, int nc, int h, int w,
     size_t lds = (size_t)(2 * BR + kh - 1) * (w + 32) + 16; // (+ one piece: the sliding window peeks one word ahead)
     {
         Span sp(ctx, KID_PREP_ERODE);
-        k_prep_erode<false><<<dim3((h + BR - 1) / BR, nc), PE_THREADS, lds, ctx->stream>>>((const float *)src, h, w, flip, mode, (float)minFlux,
-                                                                               (float)addFlux, ctx->tmp, ctx->hist, kh, kw, BR, ctx->cellbm, ctx->bm_bands, active,
-                                                                               nullptr, nullptr, nullptr);
+#define LFD_PE_LAUNCH(M_)                                                                                                             \
+    k_prep_erode<false, M_><<<dim3((h + BR - 1) / BR, nc), PE_THREADS, lds, ctx->stream>>>(                                           \
+        (const float *)src, h, w, flip, mode, (float)minFlux, (float)addFlux, ctx->tmp, ctx->hist, kh, kw, BR, ctx->cellbm, ctx->bm_bands, \
+        active, nullptr, nullptr, nullptr)
+        switch (mode & 3) {
+        case 0: LFD_PE_LAUNCH(0); break;
+        case 1: LFD_PE_LAUNCH(1); break;
+        case 2: LFD_PE_LAUNCH(2); break;
+        default: LFD_PE_LAUNCH(3); break;
+        }
+#undef LFD_PE_LAUNCH
         KCHK("k_prep_erode");
     }
     Span sp(ctx, KID_LUT);
@@ -1041,7 +1071,7 @@ static int run_prep_dual(lfdmi_ctx *ctx, const void *src, int nc, int h, int w, 
     HIPCHK(hipMemsetAsync(ctx->zero_block2, 0, ctx->zero_bytes2, ctx->stream));
     {
         Span sp(ctx, KID_PREP_DUAL);
-        k_prep_erode<true><<<dim3((h + BR - 1) / BR, nc), PE_THREADS, lds, ctx->stream>>>((const float *)src, h, w, flip, LFDMI_PREP_BRIGHT_THEN_DIM,
+        k_prep_erode<true, LFDMI_PREP_BRIGHT_THEN_DIM><<<dim3((h + BR - 1) / BR, nc), PE_THREADS, lds, ctx->stream>>>((const float *)src, h, w, flip, LFDMI_PREP_BRIGHT_THEN_DIM,
                                                                               (float)dimp->minFlux, (float)dimp->addFlux, ctx->tmp, ctx->hist2, kh, kw, BR,
                                                                               ctx->cellbm2, ctx->bm_bands, nullptr, ctx->gray, ctx->hist, ctx->cellbm);
         KCHK("k_prep_dual");
