@@ -271,8 +271,7 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
         band[r * SW + (k < 4 ? k : W4 + k)] = 0xFFFFFFFFu;
     }
     __syncthreads();
-    int zeros_b = 0;
-    HistAcc acc;
+    HistAcc acc, acc_b;
     // piece `it` of the band is (row it / W4, 16-byte column it % W4); a lane's pieces are PE_THREADS apart, so it carries
     // (row, column) along instead of dividing for every piece (an integer division is ~40 vector instructions)
     const int dr1 = PE_THREADS / W4, dx1 = PE_THREADS - dr1 * W4;
@@ -305,15 +304,11 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
                 if (gyv[u] >= y0 && gyv[u] < y0 + BR) { // the band's own rows: every image row is counted once
                     hist_word(word, sh[wv], acc);
                     if (DUAL) { // the bright pass's image of the same pixels
-                        unsigned a2 = prep_f32(v[u].x, 1, 0.f, 0.f), b2 = prep_f32(v[u].y, 1, 0.f, 0.f), c2 = prep_f32(v[u].z, 1, 0.f, 0.f),
-                                 e2 = prep_f32(v[u].w, 1, 0.f, 0.f);
-                        ((uchar4 *)(gray_b + (size_t)g * N + (size_t)gyv[u] * w))[x4] =
-                            make_uchar4((unsigned char)a2, (unsigned char)b2, (unsigned char)c2, (unsigned char)e2);
-                        if (a2) atomicAdd(&sh[NH + wv][a2], 1); else zeros_b++;
-                        if (b2) atomicAdd(&sh[NH + wv][b2], 1); else zeros_b++;
-                        if (c2) atomicAdd(&sh[NH + wv][c2], 1); else zeros_b++;
-                        if (e2) atomicAdd(&sh[NH + wv][e2], 1); else zeros_b++;
-                        if (a2 | b2 | c2 | e2) { // (the bright image is sparse: a few thousand marks per frame)
+                        const uint32_t word2 = prep_f32_m<1>(v[u].x, 0.f, 0.f) | (prep_f32_m<1>(v[u].y, 0.f, 0.f) << 8) |
+                                               (prep_f32_m<1>(v[u].z, 0.f, 0.f) << 16) | (prep_f32_m<1>(v[u].w, 0.f, 0.f) << 24);
+                        ((uint32_t *)(gray_b + (size_t)g * N + (size_t)gyv[u] * w))[x4] = word2;
+                        hist_word(word2, sh[NH + wv], acc_b);
+                        if (word2) { // (the bright image is sparse: a few thousand marks per frame)
                             int cx = x4 >> 2;
                             atomicOr((unsigned long long *)&cellbm_b[((size_t)g * bm_bands + gyv[u] / CELLBM_ROWS) * CELLBM_WORDS + (cx >> 6)], 1ull << (cx & 63));
                         }
@@ -324,10 +319,7 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
         }
     }
     hist_flush(acc, sh[wv]);
-    if (DUAL) {
-        for (int off = 32; off > 0; off >>= 1) zeros_b += __shfl_down(zeros_b, off);
-        if (lfd_lane() == 0 && zeros_b) atomicAdd(&sh[NH + wv][0], zeros_b);
-    }
+    if (DUAL) hist_flush(acc_b, sh[NH + wv]);
     __syncthreads();
     if (threadIdx.x < 256) {
         int b = threadIdx.x, t = 0;
