@@ -64,18 +64,59 @@ __device__ __forceinline__ u64 start_bits(const u64 *row, int wq, int val, int W
 //   k_scan_count: per 64-word segment (one wave each) the run starts and the work-list entries -> segcnt
 //   k_scan_bases: per frame, exclusive scan of the segment counts in place, totals -> counters
 //   k_scan_write: per segment, the per-word scan values, the work-list entries (raster order), the clear
-#define SCANW_WAVES 4 // segments per workgroup
-__device__ __forceinline__ void scan_word(const u64 *b, int i, int nw, int wq, int val, int W, bool lists, int *c, bool *tf, bool *tb) {
-    *c = 0; *tf = false; *tb = false;
-    if (i >= nw) return;
-    int y = i / wq, q = i - y * wq;
-    *c = __popcll(start_bits(b + (size_t)y * wq, q, val, W));
-    if (lists) {
-        u64 m = b[i];
-        *tf = m != 0;
-        if (q > 0) m |= b[i - 1] >> 63;
-        if (y > 0) { m |= b[i - wq]; if (q > 0) m |= b[i - wq - 1] >> 63; }
-        *tb = (m != 0) || (q == 0);
+#define SCANW_WAVES 4 // waves per workgroup
+#define SCAN_SEGS 8   // consecutive segments per wave: all their loads are issued together (a wave per 512 bytes lived on
+                      // launch overhead and on its own load latency: 1 M waves per launch on 4096 x 4096 frames)
+// Per segment k of the wave (words ((seg0 + k) << 6) + lane): run starts of the lane's word, "holds a candidate bit" (fg work
+// list) and "a 0-run can start or join here" (bg work list).  The word to the left comes from the neighbouring lane, the
+// first lane's from the previous segment's last lane.
+__device__ __forceinline__ void scan_words(const u64 *b, int seg0, int nseg, int nw, int wq, int val, int W, bool lists, int lane,
+                                           int *c, bool *tf, bool *tb) {
+    u64 cur[SCAN_SEGS], up[SCAN_SEGS];
+    int yy[SCAN_SEGS], qq[SCAN_SEGS];
+    bool in[SCAN_SEGS];
+    const float inv = 1.0f / (float)wq;
+#pragma unroll
+    for (int k = 0; k < SCAN_SEGS; k++) {
+        const int i = ((seg0 + k) << 6) + lane;
+        int y = (int)((float)i * inv), q = i - y * wq; // i < 2^24: the quotient is off by one at most
+        if (q < 0) { y--; q += wq; } else if (q >= wq) { y++; q -= wq; }
+        yy[k] = y; qq[k] = q;
+        in[k] = seg0 + k < nseg && i < nw;
+        cur[k] = in[k] ? b[i] : 0ull;
+        up[k] = (in[k] && lists && y > 0) ? b[i - wq] : 0ull;
+    }
+    u64 first_prev = 0ull, first_upprev = 0ull;
+    {
+        const int i = seg0 << 6;
+        if (lane == 0 && i > 0 && i < nw) {
+            first_prev = b[i - 1];
+            if (lists && i - wq - 1 >= 0) first_upprev = b[i - wq - 1];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SCAN_SEGS; k++) {
+        u64 prev = __shfl_up(cur[k], 1), upprev = __shfl_up(up[k], 1);
+        {
+            auto last = [](u64 v) { // lane 63's value, read by every lane
+                return (u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63) |
+                       ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63) << 32);
+            };
+            const u64 lp = k > 0 ? last(cur[k > 0 ? k - 1 : 0]) : first_prev, lu = k > 0 ? last(up[k > 0 ? k - 1 : 0]) : first_upprev;
+            if (lane == 0) { prev = lp; upprev = lu; }
+        }
+        const int q = qq[k], y = yy[k];
+        u64 cc = (val ? cur[k] : ~cur[k]) & valid_mask(q, W);
+        const u64 pm = q > 0 ? ((val ? prev : ~prev) >> 63) : 0ull;
+        c[k] = in[k] ? __popcll(cc & ~((cc << 1) | pm)) : 0;
+        tf[k] = false; tb[k] = false;
+        if (lists && in[k]) {
+            u64 m = cur[k];
+            tf[k] = m != 0;
+            if (q > 0) m |= prev >> 63;
+            if (y > 0) { m |= up[k]; if (q > 0) m |= upprev >> 63; }
+            tb[k] = (m != 0) || (q == 0);
+        }
     }
 }
 
@@ -84,13 +125,18 @@ k_scan_count(const u64 *bits, int val, int4 *segcnt, int h, int w, int lists, co
     int g = blockIdx.y;
     if (active && !active[g]) return;
     const int wq = LFD_WQ(w), nw = h * wq, nseg = (nw + 63) >> 6;
-    int seg = blockIdx.x * SCANW_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (seg >= nseg) return;
-    int c; bool tf, tb;
-    scan_word(bits + (size_t)g * nw, (seg << 6) + lane, nw, wq, val, w, lists != 0, &c, &tf, &tb);
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-    int nf = __popcll(__ballot(tf)), nb = __popcll(__ballot(tb));
-    if (lane == 0) segcnt[(size_t)g * SCAN_MAX_SEG + seg] = make_int4(c, nf, nb, 0);
+    const int seg0 = (blockIdx.x * SCANW_WAVES + (threadIdx.x >> 6)) * SCAN_SEGS, lane = threadIdx.x & 63;
+    if (seg0 >= nseg) return;
+    int c[SCAN_SEGS]; bool tf[SCAN_SEGS], tb[SCAN_SEGS];
+    scan_words(bits + (size_t)g * nw, seg0, nseg, nw, wq, val, w, lists != 0, lane, c, tf, tb);
+#pragma unroll
+    for (int k = 0; k < SCAN_SEGS; k++) {
+        if (seg0 + k >= nseg) break;
+        int cs = c[k];
+        for (int off = 32; off > 0; off >>= 1) cs += __shfl_down(cs, off);
+        int nf = __popcll(__ballot(tf[k])), nb = __popcll(__ballot(tb[k]));
+        if (lane == 0) segcnt[(size_t)g * SCAN_MAX_SEG + seg0 + k] = make_int4(cs, nf, nb, 0);
+    }
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
@@ -136,24 +182,31 @@ k_scan_write(const u64 *bits, int val, const int4 *segcnt, int *scan, int h, int
     int g = blockIdx.y;
     if (active && !active[g]) return;
     const int wq = LFD_WQ(w), nw = h * wq, nseg = (nw + 63) >> 6;
-    int seg = blockIdx.x * SCANW_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (seg >= nseg) return;
-    int i = (seg << 6) + lane, c; bool tf, tb;
-    scan_word(bits + (size_t)g * nw, i, nw, wq, val, w, wl_fg != nullptr, &c, &tf, &tb);
-    int incl = c;
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
-    int4 base = segcnt[(size_t)g * SCAN_MAX_SEG + seg];
-    if (wl_fg) {
-        u64 bf = __ballot(tf), bb = __ballot(tb), lt = (1ull << lane) - 1ull;
-        if (tf) wl_fg[(size_t)g * nw + base.y + __popcll(bf & lt)] = i;
-        if (tb) wl_bg[(size_t)g * nw + base.z + __popcll(bb & lt)] = i;
-    }
-    if (i < nw) {
-        scan[(size_t)g * nw + i] = base.x + incl - c;
-        if (clear) clear[(size_t)g * nw + i] = 0ull;
+    const int seg0 = (blockIdx.x * SCANW_WAVES + (threadIdx.x >> 6)) * SCAN_SEGS, lane = threadIdx.x & 63;
+    if (seg0 >= nseg) return;
+    int c[SCAN_SEGS]; bool tf[SCAN_SEGS], tb[SCAN_SEGS];
+    scan_words(bits + (size_t)g * nw, seg0, nseg, nw, wq, val, w, wl_fg != nullptr, lane, c, tf, tb);
+    int4 base[SCAN_SEGS];
+#pragma unroll
+    for (int k = 0; k < SCAN_SEGS; k++) base[k] = seg0 + k < nseg ? segcnt[(size_t)g * SCAN_MAX_SEG + seg0 + k] : make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < SCAN_SEGS; k++) {
+        if (seg0 + k >= nseg) break;
+        const int i = ((seg0 + k) << 6) + lane;
+        int incl = c[k];
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (wl_fg) {
+            u64 bf = __ballot(tf[k]), bb = __ballot(tb[k]), lt = (1ull << lane) - 1ull;
+            if (tf[k]) wl_fg[(size_t)g * nw + base[k].y + __popcll(bf & lt)] = i;
+            if (tb[k]) wl_bg[(size_t)g * nw + base[k].z + __popcll(bb & lt)] = i;
+        }
+        if (i < nw) {
+            scan[(size_t)g * nw + i] = base[k].x + incl - c[k];
+            if (clear) clear[(size_t)g * nw + i] = 0ull;
+        }
     }
 }
 

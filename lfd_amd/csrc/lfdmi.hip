@@ -638,7 +638,7 @@ static int run_morph(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, u64 *bits
 static int run_scan(lfdmi_ctx *ctx, const u64 *bits, int val, int *scan, int cidx, int nc, int h, int w, int *wl_fg, int *wl_bg,
                     u64 *clear, const int *active) {
     int nseg = (h * LFD_WQ(w) + 63) / 64;
-    dim3 grid((nseg + SCANW_WAVES - 1) / SCANW_WAVES, nc);
+    dim3 grid((nseg + SCANW_WAVES * SCAN_SEGS - 1) / (SCANW_WAVES * SCAN_SEGS), nc);
     k_scan_count<<<grid, 64 * SCANW_WAVES, 0, ctx->stream>>>(bits, val, ctx->segcnt, h, w, wl_fg != nullptr, active);
     KCHK("k_scan_count");
     k_scan_bases<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->segcnt, ctx->counters, cidx, h, w, ctx->run_cap, wl_fg != nullptr, active);
