@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LFDMI_VERSION 200
+#define LFDMI_VERSION 201
 
 enum lfdmi_status {
     LFDMI_OK = 0,
@@ -218,8 +218,14 @@ int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w,
                        const lfdmi_catalog *cat, const lfdmi_rs_params *rs,
                        const lfdmi_params *bright, const lfdmi_params *dim, lfdmi_result *results,
                        int loc);
+/* Which calls keep the 8-bit stage images (gray, eroded, equalised+dilated: what the reference's debug PNGs show) for
+ * lfdmi_get_stage.  mode -1 (default): the per-pass entry points (lfdmi_process_bright / _dim / _multiscale) do,
+ * lfdmi_detect_batch does not; 0: no call does (batches through the per-pass entry points: an image per frame less to
+ * write, and the dim pass may fuse its front end); 1: every call does.  The edge map and box image are always available. */
+int lfdmi_set_stage_images(lfdmi_ctx *ctx, int mode);
 /* copy a stage image (u8, h x w) of in-flight slot `slot` of the LAST call to dst; h, w must be the shape of
- * that call (LFDMI_ERR_ARG otherwise: dst is then too small or too large for what the workspace holds) */
+ * that call (LFDMI_ERR_ARG otherwise: dst is then too small or too large for what the workspace holds), and for the
+ * 8-bit images the call must have kept them (lfdmi_set_stage_images; LFDMI_ERR_ARG otherwise) */
 int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, int h, int w, uint8_t *dst, int loc);
 /* diagnostics: the work counters of in-flight slots [slot0, slot0 + n) as left by the LAST pass
  * (LFDMI_COUNTERS int32 values per slot; order: keys, row slots, rectangles, equ list entries, box

@@ -31,7 +31,7 @@ SYMBOLS = (
     "lfdmi_max_inflight", "lfdmi_prep_u8", "lfdmi_equalize_hist", "lfdmi_dilate", "lfdmi_erode",
     "lfdmi_canny", "lfdmi_gaussian_blur", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
     "lfdmi_hough_dims", "lfdmi_remove_stars", "lfdmi_process_bright", "lfdmi_process_dim",
-    "lfdmi_detect_batch", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_timing_select", "lfdmi_get_timing",
+    "lfdmi_detect_batch", "lfdmi_set_stage_images", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_timing_select", "lfdmi_get_timing",
     "lfdmi_timing_slots", "lfdmi_timing_name",
 )
 
@@ -223,6 +223,11 @@ class Context:
 
     def set_stream(self, stream_handle):
         self._chk(self._lib.lfdmi_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+
+    def set_stage_images(self, mode):
+        """Which calls keep the 8-bit stage images for get_stage: -1 the per-pass calls do and detect_batch does not
+        (default), 0 none (batches), 1 all."""
+        self._chk(self._lib.lfdmi_set_stage_images(self._h, int(mode)))
 
     def enable_timing(self, on=True):
         self._chk(self._lib.lfdmi_enable_timing(self._h, int(on)))

@@ -58,11 +58,13 @@ class BatchDetector:
     this is the same frame-parallel sharding as across GPUs, one level down.
     """
 
-    def __init__(self, device=0, shape=(1489, 2048), inflight=32, stream=None, lanes=1, caps=None):
+    def __init__(self, device=0, shape=(1489, 2048), inflight=32, stream=None, lanes=1, caps=None, stage_images=False):
         from concurrent.futures import ThreadPoolExecutor
         self.lanes = max(1, int(lanes))
         per = max(1, inflight // self.lanes)
         self.ctxs = [_native.Context(device, shape[0], shape[1], per, caps=caps) for _ in range(self.lanes)]
+        for c in self.ctxs:  # a batch detector is for throughput: no 8-bit debug images per frame unless asked for
+            c.set_stage_images(1 if stage_images else 0)
         self.ctx = self.ctxs[0]
         if stream is not None and self.lanes == 1:
             self.ctx.set_stream(stream)

@@ -1348,66 +1348,70 @@ __device__ __forceinline__ unsigned dct_cells(const u64 *m, int b0) { // bits b0
 __global__ void __launch_bounds__(DCT_THREADS)
 k_dc_tiles(const u64 *cellbm, int bm_bands, const uint8_t *lut, int *tile_list, int tile_cap, int *counters, u64 *equb, u64 *cand,
            u64 *strong, uint8_t *equ, int h, int w, const int *active) {
+    // grid (frames, fill parts): part 0 builds the frame's tile list, every part writes its share of the background
     const int g = blockIdx.x;
     if (active && !active[g]) return;
+    const int fpart = blockIdx.y, fparts = gridDim.y;
     const int tiles_x = (w + CANNY_TW - 1) / CANNY_TW, tiles_y = (h + DCW_TH - 1) / DCW_TH;
     __shared__ int band_off[DCT_MAXBANDS + 1];
     __shared__ u64 band_mask[DCT_MAXBANDS][2];
     __shared__ u64 rowm[DCT_THREADS / 64][CELLBM_WORDS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = DCT_THREADS / 64;
-    // ---- which tiles have an occupied cell within reach: cells 4 tx - 1 .. 4 tx + 4 of bands ty - 1 .. ty + 1
-    for (int ty = wv; ty < tiles_y; ty += nwv) {
-        if (lane < CELLBM_WORDS) {
-            u64 m = cellbm ? 0ull : ~0ull;
-            if (cellbm)
-                for (int b = ty - 1; b <= ty + 1; b++)
-                    if (b >= 0 && b < bm_bands) m |= cellbm[((size_t)g * bm_bands + b) * CELLBM_WORDS + lane];
-            rowm[wv][lane] = m;
-        }
-        __builtin_amdgcn_wave_barrier();
-        int n = 0;
-        for (int half = 0; half < 2; half++) {
-            int tx = lane + 64 * half;
-            bool on = tx < tiles_x && dct_cells(rowm[wv], 4 * tx - 1) != 0;
-            u64 bal = __ballot(on);
-            if (lane == 0) band_mask[ty][half] = bal;
-            n += __popcll(bal);
-        }
-        if (lane == 0) band_off[ty] = n;
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    if (wv == 0) { // exclusive scan of the band counts: 8 bands per lane, then across the wave
-        int v[DCT_MAXBANDS / 64], loc = 0;
-        for (int k = 0; k < DCT_MAXBANDS / 64; k++) {
-            int b = lane * (DCT_MAXBANDS / 64) + k;
-            v[k] = b < tiles_y ? band_off[b] : 0;
-            loc += v[k];
-        }
-        int inc = loc;
-        for (int off = 1; off < 64; off <<= 1) {
-            int t = __shfl_up(inc, off);
-            if (lane >= off) inc += t;
-        }
-        int run = inc - loc;
-        for (int k = 0; k < DCT_MAXBANDS / 64; k++) {
-            int b = lane * (DCT_MAXBANDS / 64) + k;
-            if (b < tiles_y) band_off[b] = run;
-            run += v[k];
-        }
-        if (lane == 63) { band_off[DCT_MAXBANDS] = inc; counters[g * C_COUNT + C_NTILES] = inc < tile_cap ? inc : tile_cap; }
-    }
-    __syncthreads();
-    int *tl = tile_list + (size_t)g * tile_cap;
-    for (int ty = wv; ty < tiles_y; ty += nwv) {
-        int o = band_off[ty];
-        for (int half = 0; half < 2; half++) {
-            u64 bal = band_mask[ty][half];
-            if ((bal >> lane) & 1ull) {
-                int k = o + __popcll(bal & ((1ull << lane) - 1ull));
-                if (k < tile_cap) tl[k] = (ty << 16) | (lane + 64 * half);
+    if (fpart == 0) { // (uniform per workgroup: the barriers inside are safe)
+        // ---- which tiles have an occupied cell within reach: cells 4 tx - 1 .. 4 tx + 4 of bands ty - 1 .. ty + 1
+        for (int ty = wv; ty < tiles_y; ty += nwv) {
+            if (lane < CELLBM_WORDS) {
+                u64 m = cellbm ? 0ull : ~0ull;
+                if (cellbm)
+                    for (int b = ty - 1; b <= ty + 1; b++)
+                        if (b >= 0 && b < bm_bands) m |= cellbm[((size_t)g * bm_bands + b) * CELLBM_WORDS + lane];
+                rowm[wv][lane] = m;
             }
-            o += __popcll(bal);
+            __builtin_amdgcn_wave_barrier();
+            int n = 0;
+            for (int half = 0; half < 2; half++) {
+                int tx = lane + 64 * half;
+                bool on = tx < tiles_x && dct_cells(rowm[wv], 4 * tx - 1) != 0;
+                u64 bal = __ballot(on);
+                if (lane == 0) band_mask[ty][half] = bal;
+                n += __popcll(bal);
+            }
+            if (lane == 0) band_off[ty] = n;
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        if (wv == 0) { // exclusive scan of the band counts: 8 bands per lane, then across the wave
+            int v[DCT_MAXBANDS / 64], loc = 0;
+            for (int k = 0; k < DCT_MAXBANDS / 64; k++) {
+                int b = lane * (DCT_MAXBANDS / 64) + k;
+                v[k] = b < tiles_y ? band_off[b] : 0;
+                loc += v[k];
+            }
+            int inc = loc;
+            for (int off = 1; off < 64; off <<= 1) {
+                int t = __shfl_up(inc, off);
+                if (lane >= off) inc += t;
+            }
+            int run = inc - loc;
+            for (int k = 0; k < DCT_MAXBANDS / 64; k++) {
+                int b = lane * (DCT_MAXBANDS / 64) + k;
+                if (b < tiles_y) band_off[b] = run;
+                run += v[k];
+            }
+            if (lane == 63) { band_off[DCT_MAXBANDS] = inc; counters[g * C_COUNT + C_NTILES] = inc < tile_cap ? inc : tile_cap; }
+        }
+        __syncthreads();
+        int *tl = tile_list + (size_t)g * tile_cap;
+        for (int ty = wv; ty < tiles_y; ty += nwv) {
+            int o = band_off[ty];
+            for (int half = 0; half < 2; half++) {
+                u64 bal = band_mask[ty][half];
+                if ((bal >> lane) & 1ull) {
+                    int k = o + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (k < tile_cap) tl[k] = (ty << 16) | (lane + 64 * half);
+                }
+                o += __popcll(bal);
+            }
         }
     }
     // ---- background of the outputs: the dilated, equalised image is lut[0] wherever nothing is within reach
@@ -1415,13 +1419,14 @@ k_dc_tiles(const u64 *cellbm, int bm_bands, const uint8_t *lut, int *tile_list, 
     const int wq = LFD_WQ(w);
     const size_t BW = (size_t)h * wq;
     u64 *pe = equb + (size_t)g * BW, *pc = cand + (size_t)g * BW, *ps = strong + (size_t)g * BW;
+    const size_t t0 = (size_t)fpart * DCT_THREADS + threadIdx.x, tstep = (size_t)fparts * DCT_THREADS;
     if (z == 0 && (BW & 1) == 0) {
         const uint4 zero = make_uint4(0, 0, 0, 0);
-        for (size_t i = threadIdx.x; i < BW / 2; i += DCT_THREADS) {
+        for (size_t i = t0; i < BW / 2; i += tstep) {
             ((uint4 *)pe)[i] = zero; ((uint4 *)pc)[i] = zero; ((uint4 *)ps)[i] = zero;
         }
     } else {
-        for (size_t i = threadIdx.x; i < BW; i += DCT_THREADS) {
+        for (size_t i = t0; i < BW; i += tstep) {
             pe[i] = z ? valid_mask((int)(i % wq), w) : 0ull;
             pc[i] = 0ull; ps[i] = 0ull;
         }
@@ -1429,7 +1434,7 @@ k_dc_tiles(const u64 *cellbm, int bm_bands, const uint8_t *lut, int *tile_list, 
     if (equ) { // stage image requested: its background too
         const unsigned zz = z * 0x01010101u;
         uint4 *pq = (uint4 *)(equ + (size_t)g * h * w);
-        for (size_t i = threadIdx.x; i < (size_t)h * w / 16; i += DCT_THREADS) pq[i] = make_uint4(zz, zz, zz, zz);
+        for (size_t i = t0; i < (size_t)h * w / 16; i += tstep) pq[i] = make_uint4(zz, zz, zz, zz);
     }
 }
 

@@ -139,7 +139,9 @@ struct lfdmi_ctx {
     float t_ms[TG_COUNT] = {0};
     int t_n[TG_COUNT] = {0};
     long long t_units[TG_COUNT] = {0}; // frames (images) the timed launches actually worked on
-    bool want_stage_images = false;    // lfdmi_detect_batch writes the equ stage image only on request
+    int stage_mode = -1;               // lfdmi_set_stage_images: -1 the per-pass entry points keep the 8-bit stage images, lfdmi_detect_batch
+                                       // does not; 0 never; 1 always
+    bool stages_valid = false;         // the last call kept them (lfdmi_get_stage)
     int vote_split = 4;                // pieces a frame's Hough list is cut into at most
     int pe_rows = 12;                  // rows per band of k_prep_erode
     bool fuse_prep_erode = true;       // dim pass: prep + histogram + erosion in one kernel (LFDMI_FUSE_PREP_ERODE=0: separate)
@@ -499,6 +501,7 @@ static int check_shape(lfdmi_ctx *ctx, int n, int h, int w) {
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, LFDMI_ERR_HIP, "hipSetDevice");
     (void)hipGetLastError(); // a failed earlier call must not poison this one
     ctx->last_h = h; ctx->last_w = w;
+    ctx->stages_valid = true; // (the pass-level entry points overwrite this with what they keep)
     return 0;
 }
 
@@ -711,7 +714,11 @@ static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, i
         if (ctx->dc_tilelist && tiles_x <= 128 && tiles_y <= DCT_MAXBANDS) {
             // active-tile list from the cell bitmap (or every tile), background of the bit planes, then the tile stages
             Span sp(ctx, KID_DILATE_CANNY);
-            k_dc_tiles<<<nc, DCT_THREADS, 0, ctx->stream>>>(cellbm, ctx->bm_bands, lut, ctx->tile_list, ctx->tile_cap,
+            // (one workgroup per frame writing 1-6 MB of background is bound by its own store latency: the fill is spread over
+            // a workgroup per ~256 KB)
+            int fill_parts = (int)std::min<size_t>(64, std::max<size_t>(1, ((size_t)h * LFD_WQ(w) * 24 + (256u << 10) - 1) / (256u << 10)));
+            if (const char *e = getenv("LFDMI_DCT_FILLPARTS")) fill_parts = std::max(1, atoi(e));
+            k_dc_tiles<<<dim3(nc, fill_parts), DCT_THREADS, 0, ctx->stream>>>(cellbm, ctx->bm_bands, lut, ctx->tile_list, ctx->tile_cap,
                                                              ctx->counters, ctx->equb, ctx->candb, ctx->strongb, ctx->keep_equ ? ctx->equ : nullptr,
                                                              h, w, active);
             KCHK("k_dc_tiles");
@@ -1532,6 +1539,8 @@ struct GeneralGuard {
 };
 
 // results[s * rstride + i]: frame i at Hough scale s (rhos == nullptr: one scale, p->houghMethod)
+struct KeepEqu { lfdmi_ctx *c; bool old; KeepEqu(lfdmi_ctx *c_, bool v) : c(c_), old(c_->keep_equ) { c->keep_equ = v; } ~KeepEqu() { c->keep_equ = old; } };
+
 static int pass_api(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, int w, int flip, int prep_mode, bool dim,
                     const lfdmi_params *p, int n_scales, const double *rhos, lfdmi_result *results, size_t rstride, float *lines_equ,
                     float *lines_box, int loc) {
@@ -1553,6 +1562,8 @@ static int pass_api(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, in
     size_t N = (size_t)h * w, es = dtype_size(dtype);
     int K = p->nlinesInSet;
     const size_t G = (size_t)ctx->G;
+    KeepEqu keep_guard(ctx, ctx->stage_mode != 0); // the 8-bit stage images for lfdmi_get_stage unless switched off (batches)
+    ctx->stages_valid = ctx->keep_equ;
     std::vector<lfdmi_result> host(G * n_scales);
     std::vector<float> hl(G * 2 * K * 2);
     std::vector<int> flags(G);
@@ -1733,8 +1744,8 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
     std::vector<lfdmi_result> host((size_t)ctx->G);
     std::vector<int> flags((size_t)ctx->G);
     std::vector<int4> boxes;
-    struct KeepEqu { lfdmi_ctx *c; bool old; KeepEqu(lfdmi_ctx *c_, bool v) : c(c_), old(c_->keep_equ) { c->keep_equ = v; } ~KeepEqu() { c->keep_equ = old; } }
-        keep_guard(ctx, ctx->want_stage_images);
+    KeepEqu keep_guard(ctx, ctx->stage_mode == 1);
+    ctx->stages_valid = ctx->keep_equ;
     // Host frames: chunks of up to ~feed_chunk_bytes (and at most G frames) go through the pinned double buffer
     // (feed_* above), chunk k+1 uploading while chunk k is processed.  Device frames (LFDMI_FEED_MB=0, tiny batches):
     // chunks of G frames, used in place / staged by the runtime.
@@ -1838,6 +1849,12 @@ extern "C" int lfdmi_debug_frame_profile(lfdmi_ctx *ctx, int n, long long *dst) 
     return 0;
 }
 
+extern "C" int lfdmi_set_stage_images(lfdmi_ctx *ctx, int mode) {
+    if (!ctx || mode < -1 || mode > 1) return LFDMI_ERR_ARG;
+    ctx->stage_mode = mode;
+    return 0;
+}
+
 extern "C" int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, int h, int w, uint8_t *dst, int loc) {
     if (!ctx || !dst || slot < 0 || slot >= ctx->G) return LFDMI_ERR_ARG;
     if (ctx->last_h <= 0) return fail(ctx, LFDMI_ERR_ARG, "no call has run yet");
@@ -1845,6 +1862,8 @@ extern "C" int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, int h, int w
     size_t N = (size_t)h * w, BW = (size_t)h * LFD_WQ(w);
     HIPCHK(hipSetDevice(ctx->device));
     const uint8_t *src = nullptr;
+    if (which != LFDMI_STAGE_CANNY && which != LFDMI_STAGE_BOX && !ctx->stages_valid)
+        return fail(ctx, LFDMI_ERR_ARG, "lfdmi_get_stage: the last call did not keep the 8-bit stage images (lfdmi_set_stage_images)");
     if (which == LFDMI_STAGE_GRAY) src = ctx->gray + slot * N;
     else if (which == LFDMI_STAGE_EQU) src = ctx->equ + slot * N;
     else if (which == LFDMI_STAGE_EQUALIZED || which == LFDMI_STAGE_ERODED) {

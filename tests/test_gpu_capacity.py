@@ -132,6 +132,48 @@ def test_get_stage_checks_the_shape_of_the_last_call():
         assert out.shape == (64, 128) and out[25, 60] == 200
 
 
+def test_stage_images_are_kept_only_where_asked_for(oracle):
+    """lfdmi_set_stage_images: the per-pass calls keep the 8-bit stage images by default and lfdmi_detect_batch does not;
+    a batch detector switches them off (get_stage then refuses instead of handing out stale bytes), mode 1 keeps them in
+    detect_batch too; records and the always-available edge / box images are the same in every mode."""
+    from lfd_amd import _native, synth
+    from lfd_amd.batch import BatchDetector
+    from lfd_amd.detecttrails import default_params
+    pb, pd, _ = default_params()
+    h, w = 256, 512
+    rng = np.random.default_rng(5)
+    img = rng.normal(0.3, 0.8, (h, w)).astype(np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img[np.abs(yy - (0.4 * xx + 20)) < 2.0] += 60.0
+    want = oracle.process_dim(img, pd)
+    with _native.Context(0, h, w, 2) as ctx:
+        res, _, _ = ctx.process_dim(img.copy(), pd)
+        assert res["found"] == want["found"] and res["rho"] == want["rho"] and res["theta"] == want["theta"]
+        equ_kept = ctx.get_stage(0, _native.STAGE_EQU, h, w)              # default: kept by the per-pass call
+        edges = ctx.get_stage(0, _native.STAGE_CANNY, h, w)
+        ctx.set_stage_images(0)
+        res0, _, _ = ctx.process_dim(img.copy(), pd)
+        assert res0.tobytes() == res.tobytes()
+        with pytest.raises(_native.NativeError):
+            ctx.get_stage(0, _native.STAGE_EQU, h, w)
+        assert np.array_equal(ctx.get_stage(0, _native.STAGE_CANNY, h, w), edges)
+        ctx.set_stage_images(-1)
+        rb = ctx.detect_batch(img.copy()[None], pb, pd)
+        with pytest.raises(_native.NativeError):
+            ctx.get_stage(0, _native.STAGE_EQU, h, w)                     # default: not kept by detect_batch
+        ctx.set_stage_images(1)
+        rb1 = ctx.detect_batch(img.copy()[None], pb, pd)
+        assert rb1.tobytes() == rb.tobytes()
+        assert ctx.get_stage(0, _native.STAGE_EQU, h, w).shape == equ_kept.shape
+    det = BatchDetector(0, (h, w), 2)
+    try:
+        det.multiscale(img.copy()[None], pd, [20.0, 10.0], dim=True, flip=False)
+        with pytest.raises(_native.NativeError):
+            det.ctx.get_stage(0, _native.STAGE_EQU, h, w)
+    finally:
+        det.close()
+
+
 def test_default_workspace_sizes_for_the_baseline_batches():
     """Bytes per in-flight frame of the default capacities: 256 SDSS frames and 256 LSST-size frames
     both fit one GPU with room to spare (the theoretical-maximum layout took ~95 GB and ~470 GB)."""
