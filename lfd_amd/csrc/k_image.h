@@ -584,14 +584,9 @@ k_morph_rect(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, in
 // survive: a kw-wide window of non-zero bytes must contain a whole aligned word of non-zero bytes (kw >= 7), so a staged row
 // without such a word erodes to zeros, an output row needs kh live input rows, and a tile without a live row is all zeros
 // without touching LDS.
-template <int OP, int KHC = 0, int KWC = 0>
-__global__ void __launch_bounds__(256)
-k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, int h, int w, int kh,
-               int kw, const int *active, const u64 *candmask, u64 *cellout, int bm_bands) {
-    int g = blockIdx.z;
-    if (active && !active[g]) return;
-    // wide erosion of a sparse image: k_erode_cand has zero-filled dst and left one bit per tile that can hold anything
-    if (candmask && !((candmask[((size_t)g * gridDim.y + blockIdx.y) * 2 + (blockIdx.x >> 6)] >> (blockIdx.x & 63)) & 1ull)) return;
+template <int OP, int KHC, int KWC>
+__device__ __forceinline__ void morph_rect_tile(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, int h, int w, int kh,
+                                                int kw, u64 *cellout, int bm_bands, const int bx, const int by, const int g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smv[];
     const int IH = MORPH_TH + kh - 1;
     const int IWB = MORPH_TW + 2 * MORPH_HALO; // bytes per staged row
@@ -601,7 +596,7 @@ k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, 
     __shared__ uint8_t slut[256];
     __shared__ int rowflag[MORPH_TH + LFDMI_MAX_MORPH_K]; // dilation: staged row holds a non-zero byte
     const uint32_t fillw = OP ? 0xffffffffu : 0u;
-    int x0 = blockIdx.x * MORPH_TW, y0 = blockIdx.y * MORPH_TH;
+    int x0 = bx * MORPH_TW, y0 = by * MORPH_TH;
     int ay = kh / 2, ax = kw / 2;
     size_t N = (size_t)h * w;
     const uint8_t *s = src + (size_t)g * N;
@@ -642,9 +637,9 @@ k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, 
             if (gy < h && gx < w) *(uint4 *)(d + (size_t)gy * w + gx) = make_uint4(z, z, z, z);
         }
         if (bits) {
-            u64 bal = z ? valid_mask(blockIdx.x, w) : 0ull;
+            u64 bal = z ? valid_mask(bx, w) : 0ull;
             if (threadIdx.x < MORPH_TH && y0 + threadIdx.x < h)
-                bits[(size_t)g * h * wq + (size_t)(y0 + threadIdx.x) * wq + blockIdx.x] = bal;
+                bits[(size_t)g * h * wq + (size_t)(y0 + threadIdx.x) * wq + bx] = bal;
         }
         return;
     }
@@ -713,7 +708,7 @@ k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, 
         for (int oy = wv; oy < MORPH_TH; oy += 4) {
             int gy = y0 + oy, gx = x0 + lane;
             u64 bal = __ballot(gy < h && gx < w && tout[oy * MORPH_TW + lane] != 0);
-            if (lane == 0 && gy < h) bits[(size_t)g * h * wq + (size_t)gy * wq + blockIdx.x] = bal;
+            if (lane == 0 && gy < h) bits[(size_t)g * h * wq + (size_t)gy * wq + bx] = bal;
         }
     if (threadIdx.x < MORPH_TH * 4) {
         int row = threadIdx.x >> 2, c16 = threadIdx.x & 3;
@@ -726,6 +721,35 @@ k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, 
                 int cx = gx / CELLBM_COLS;
                 atomicOr((unsigned long long *)&cellout[((size_t)g * bm_bands + gy / CELLBM_ROWS) * CELLBM_WORDS + (cx >> 6)], 1ull << (cx & 63));
             }
+        }
+    }
+}
+
+template <int OP, int KHC = 0, int KWC = 0>
+__global__ void __launch_bounds__(256)
+k_morph_rect_v(const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, int h, int w, int kh,
+               int kw, const int *active, u64 *cellout, int bm_bands) {
+    int g = blockIdx.z;
+    if (active && !active[g]) return;
+    morph_rect_tile<OP, KHC, KWC>(src, dst, bits, lut, h, w, kh, kw, cellout, bm_bands, blockIdx.x, blockIdx.y, g);
+}
+
+// The candidate tiles of a wide erosion of a sparse image (k_erode_cand below has zero-filled dst and left one bit per tile
+// that can hold anything): one workgroup per tile ROW walks the set bits of the row's two mask words.  (A workgroup per tile
+// that exits when its bit is clear spent the launch on 2 M workgroups per 256 LSST-size frames, 85 % of them empty.)
+template <int OP, int KHC = 0, int KWC = 0>
+__global__ void __launch_bounds__(256)
+k_morph_rect_rows(const uint8_t *src, uint8_t *dst, const uint8_t *lut, int h, int w, int kh, int kw, const int *active,
+                  const u64 *candmask, u64 *cellout, int bm_bands) {
+    const int g = blockIdx.y, by = blockIdx.x;
+    if (active && !active[g]) return;
+    for (int half = 0; half < 2; half++) {
+        u64 m = candmask[((size_t)g * gridDim.x + by) * 2 + half];
+        while (m) {
+            const int bx = 64 * half + __ffsll((long long)m) - 1;
+            m &= m - 1;
+            __syncthreads(); // the previous tile's LDS reads are done
+            morph_rect_tile<OP, KHC, KWC>(src, dst, nullptr, lut, h, w, kh, kw, cellout, bm_bands, bx, by, g);
         }
     }
 }

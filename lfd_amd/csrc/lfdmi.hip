@@ -611,11 +611,15 @@ static int run_morph(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, u64 *bits
             KCHK("k_erode_cand");
             cand = ctx->candmask;
         }
-        fullbits = cand;
-        if (op == 0) k_morph_rect_v<0><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active, nullptr, cellout, ctx->bm_bands);
-        else if (kh == 9 && kw == 9 && ctx->dc_specialize) // BASELINE configs[4]: unrolled, running minima by doubling
-            k_morph_rect_v<1, 9, 9><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active, fullbits, cellout, ctx->bm_bands);
-        else k_morph_rect_v<1><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active, fullbits, cellout, ctx->bm_bands);
+        if (op == 0) k_morph_rect_v<0><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active, cellout, ctx->bm_bands);
+        else if (cand) { // a workgroup per tile row walks its candidate tiles
+            dim3 rgrid(grid.y, nc);
+            if (kh == 9 && kw == 9 && ctx->dc_specialize) // BASELINE configs[4]: unrolled, running minima by doubling
+                k_morph_rect_rows<1, 9, 9><<<rgrid, 256, lds, ctx->stream>>>(src, dst, lut, h, w, kh, kw, active, cand, cellout, ctx->bm_bands);
+            else k_morph_rect_rows<1><<<rgrid, 256, lds, ctx->stream>>>(src, dst, lut, h, w, kh, kw, active, cand, cellout, ctx->bm_bands);
+        } else if (kh == 9 && kw == 9 && ctx->dc_specialize)
+            k_morph_rect_v<1, 9, 9><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active, cellout, ctx->bm_bands);
+        else k_morph_rect_v<1><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active, cellout, ctx->bm_bands);
         if (marked) *marked = cellout != nullptr;
         KCHK("k_morph_rect_v");
     } else if (all_ones(kernel, kh, kw)) {
