@@ -299,20 +299,68 @@ k_hough_peaks(const int *accum, u64 *peaks, int *counters, int numangle, int num
     if (need_detect && !cnt[C_DETECT]) return;
     const int *ag = accum + ((size_t)g * 2 + im) * acc_cap;
     u64 *pg = peaks + ((size_t)g * 2 + im) * peak_cap;
-    int ts = numangle + 2;
-    int total = numangle * numrho;
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < total; k += gridDim.x * 256) {
-        int r = k / numangle, n = k - r * numangle;
-        int t = (r + 1) * ts + n + 1;
-        int v = ag[t];
-        // accum[base-1], [base+1]: r -/+ 1;  accum[base -/+ (numrho+2)]: angle -/+ 1
-        if (v > threshold && v > ag[t - ts] && v >= ag[t + ts] && v > ag[t - 1] && v >= ag[t + 1]) {
-            int base = (n + 1) * (numrho + 2) + r + 1;
-            int o = atomicAdd(&cnt[im ? C_NPEAK_BOX : C_NPEAK_EQU], 1);
-            if ((size_t)o < peak_cap) pg[o] = ((u64)(uint32_t)v << 32) | (u64)(uint32_t)(0x7fffffff - base);
+    const int ts = numangle + 2;
+    const int total = numangle * numrho;
+    // Peaks are collected in LDS and handed to the frame's list with ONE global atomic per flush: with threshold 1 an
+    // accumulator has thousands of local maxima, and one atomicAdd each on the same counter serialises (~100 ns apiece).
+    constexpr int PK_BUF = 4096; // (a block of rows adds at most 8 x 256 entries: flushed while that many are free)
+    __shared__ u64 buf[PK_BUF];
+    __shared__ int nbuf, gbase;
+    if (threadIdx.x == 0) nbuf = 0;
+    __syncthreads();
+    auto flush = [&]() { // (all threads; nbuf is stable: callers sit between two barriers)
+        const int nb = nbuf;
+        if (threadIdx.x == 0 && nb) gbase = atomicAdd(&cnt[im ? C_NPEAK_BOX : C_NPEAK_EQU], nb);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += (int)blockDim.x) {
+            if ((size_t)(gbase + i) < peak_cap) pg[gbase + i] = buf[i];
             else cnt[C_OVERFLOW] = 1; // a truncated peak list could lose a top line: run the frame again (spill workspace)
         }
+        __syncthreads();
+        if (threadIdx.x == 0) nbuf = 0;
+        __syncthreads();
+    };
+    // a thread owns an angle column and walks a band of bins, RB rows of loads in flight; the bins above and below come from
+    // registers, the neighbouring angles from the neighbouring lanes (the first and last lane of a wave load theirs)
+    constexpr int RB = 8;
+    const int per = ((numrho + (int)gridDim.x - 1) / (int)gridDim.x + RB - 1) / RB * RB;
+    const int r0 = blockIdx.x * per, r1 = min(numrho, r0 + per);
+    const int lane = threadIdx.x & 63, nth = (int)blockDim.x;
+    int blk = 0;
+    for (int n0 = 0; n0 < numangle; n0 += nth) {
+        const int n = n0 + threadIdx.x;
+        const bool on = n < numangle;
+        const int *col = ag + (on ? n : 0) + 1;
+        for (int rb = r0; rb < r1; rb += RB, blk++) {
+            int v[RB + 2];
+#pragma unroll
+            for (int j = 0; j < RB + 2; j++) { // guarded rows rb .. rb + RB + 1 = bins rb - 1 .. rb + RB
+                const int rr = rb + j;
+                v[j] = (on && rr <= numrho + 1) ? col[(size_t)rr * ts] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < RB; j++) {
+                const int r = rb + j, c = v[j + 1];
+                int left = __shfl_up(c, 1), right = __shfl_down(c, 1);
+                const bool cand = on && r < r1 && c > threshold && c > v[j] && c >= v[j + 2];
+                if (cand) {
+                    const int t = (r + 1) * ts + n + 1;
+                    if (lane == 0) left = ag[t - 1];
+                    if (lane == 63 || n == numangle - 1) right = ag[t + 1];
+                    // accum[base-1], [base+1]: r -/+ 1 (above);  accum[base -/+ (numrho+2)]: angle -/+ 1
+                    if (c > left && c >= right) {
+                        const int base = (n + 1) * (numrho + 2) + r + 1;
+                        buf[atomicAdd(&nbuf, 1)] = ((u64)(uint32_t)c << 32) | (u64)(uint32_t)(0x7fffffff - base);
+                    }
+                }
+            }
+            __syncthreads();
+            if (nbuf > PK_BUF - RB * 256) flush();
+            else __syncthreads();
+        }
     }
+    __syncthreads();
+    flush();
 }
 
 // transposed accumulator -> OpenCV layout (stand-alone lfdmi_hough_accum only)

@@ -1008,7 +1008,8 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         KCHK("k_hough_vote");
     }
     { Span sp(ctx, KID_PEAKS, need_detect);
-    k_hough_peaks<<<dim3(32, n_img, nc), 256, 0, ctx->stream>>>(ctx->accum, ctx->peaks, ctx->counters, na, nr, threshold,
+    static const int peak_rows = getenv("LFDMI_PEAK_ROWS") ? std::max(8, atoi(getenv("LFDMI_PEAK_ROWS"))) : 32; // bins per workgroup at least
+    k_hough_peaks<<<dim3(std::min(32, std::max(1, nr / peak_rows)), n_img, nc), std::min(256, (na + 63) / 64 * 64), 0, ctx->stream>>>(ctx->accum, ctx->peaks, ctx->counters, na, nr, threshold,
                                                                 ctx->acc_cap, ctx->peak_cap, active, need_detect);
     KCHK("k_hough_peaks"); }
     if (K > 0) {
