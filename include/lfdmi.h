@@ -251,6 +251,10 @@ const char *lfdmi_timing_name(int slot);
 /* developer tool (LFDMI_FRAME_PROFILE=1 in the environment when the context is created): per-phase clocks
  * (8 x int64 per slot, 10 ns ticks) of the last per-frame contour kernel launch, slots 0 .. n-1 */
 int lfdmi_debug_frame_profile(lfdmi_ctx *ctx, int n, long long *dst);
+/* developer check: the device's float32 results of the three libm calls on minAreaRect's accept / reject path (angle in
+ * degrees of atan2(y, x) as cv::minAreaRect rounds it; cos / sin of that angle times 0.5 as RotatedRect::points does), for
+ * n host operand pairs -- compared with the host libm by tests/test_gpu_stages.py */
+int lfdmi_debug_trig(lfdmi_ctx *ctx, int n, const double *y, const double *x, float *angle_deg, float *cos_half, float *sin_half);
 
 #ifdef __cplusplus
 }

@@ -664,3 +664,19 @@ k_fill_quads(const int *quads, const int *counters, u64 *box, int h, int w, int 
         }
     }
 }
+
+// Developer check of the three libm calls on the accept / reject path above (minAreaRect's angle, RotatedRect::points):
+// the device evaluates exactly the expressions of rect_from_hull on caller-supplied operands, so that a test can compare
+// the float32 results with the host libm's on millions of inputs (tests/test_gpu_stages.py).
+__global__ void __launch_bounds__(256)
+k_debug_trig(const double *y, const double *x, float *angle_deg, float *cos_half, float *sin_half, int n) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float angle = (float)atan2(y[i], x[i]);
+    angle = (float)((double)__fmul_rn(angle, 180.0f) / 3.1415926535897932384626433832795);
+    double ang = (double)angle * 3.1415926535897932384626433832795 / 180.;
+    angle_deg[i] = angle;
+    cos_half[i] = __fmul_rn((float)cos(ang), 0.5f);
+    sin_half[i] = __fmul_rn((float)sin(ang), 0.5f);
+}
+

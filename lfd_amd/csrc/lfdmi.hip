@@ -1854,6 +1854,24 @@ extern "C" int lfdmi_debug_frame_profile(lfdmi_ctx *ctx, int n, long long *dst) 
     return 0;
 }
 
+extern "C" int lfdmi_debug_trig(lfdmi_ctx *ctx, int n, const double *y, const double *x, float *angle_deg, float *cos_half, float *sin_half) {
+    if (!ctx || n < 0 || !y || !x || !angle_deg || !cos_half || !sin_half) return LFDMI_ERR_ARG;
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    RET(ensure_scratch(ctx, (size_t)n * (2 * sizeof(double) + 3 * sizeof(float))));
+    double *dy = (double *)ctx->scratch, *dx = dy + n;
+    float *o = (float *)(dx + n);
+    HIPCHK(hipMemcpyAsync(dy, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    k_debug_trig<<<(n + 255) / 256, 256, 0, ctx->stream>>>(dy, dx, o, o + n, o + 2 * (size_t)n, n);
+    KCHK("k_debug_trig");
+    HIPCHK(hipMemcpyAsync(angle_deg, o, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(cos_half, o + n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(sin_half, o + 2 * (size_t)n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 extern "C" int lfdmi_set_stage_images(lfdmi_ctx *ctx, int mode) {
     if (!ctx || mode < -1 || mode > 1) return LFDMI_ERR_ARG;
     ctx->stage_mode = mode;

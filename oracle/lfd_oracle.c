@@ -528,6 +528,19 @@ void lfo_box_points(const float rect[5], float box[8]) { /* RotatedRect::points 
     box[7] = 2 * cy - box[3];
 }
 
+/* The libm calls of lfo_min_area_rect / lfo_box_points on caller-supplied operands, vectorised: what the GPU tests compare
+ * the device's libm with (minAreaRect's angle in degrees; cos / sin of it times 0.5) */
+void lfo_debug_trig(int n, const double *y, const double *x, float *angle_deg, float *cos_half, float *sin_half) {
+    for (int i = 0; i < n; i++) {
+        float angle = (float)atan2(y[i], x[i]);
+        angle = (float)((double)(angle * 180.0f) / LFO_PI);
+        double ang = angle * LFO_PI / 180.;
+        angle_deg[i] = angle;
+        cos_half[i] = (float)cos(ang) * 0.5f;
+        sin_half[i] = (float)sin(ang) * 0.5f;
+    }
+}
+
 /* drawing.cpp: clipLine on 64-bit points */
 static int clip_line(int64_t width, int64_t height, int64_t *x1, int64_t *y1, int64_t *x2,
                      int64_t *y2) {

@@ -112,6 +112,7 @@ void lfo_free(void *p);
 int lfo_convex_hull(const int32_t *pts, int n, int32_t *hull /* 2*n ints */, int *n_hull);
 int lfo_min_area_rect(const int32_t *pts, int n, float rect[5]);
 void lfo_box_points(const float rect[5], float box[8]);
+void lfo_debug_trig(int n, const double *y, const double *x, float *angle_deg, float *cos_half, float *sin_half);
 int lfo_fill_poly(uint8_t *img, int h, int w, const int32_t *pts, int npts, uint8_t color);
 int lfo_fit_min_area_rect(const uint8_t *img, int h, int w, int contoursMode, int contoursMethod,
                           double minAreaRectMinLen, double lwTresh, uint8_t *box_img,

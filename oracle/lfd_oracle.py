@@ -220,6 +220,15 @@ def box_points(rect):
     return box.reshape(4, 2)
 
 
+def debug_trig(y, x):
+    """(angle_deg, cos/2, sin/2) float32 of minAreaRect / boxPoints for atan2(y, x), with the host libm."""
+    y = np.ascontiguousarray(y, np.float64)
+    x = np.ascontiguousarray(x, np.float64)
+    out = [np.zeros(y.size, np.float32) for _ in range(3)]
+    lib().lfo_debug_trig(int(y.size), _p(y), _p(x), *[_p(o) for o in out])
+    return out
+
+
 def fill_poly(img, pts, color=255):
     assert img.dtype == np.uint8 and img.flags.c_contiguous
     pts = np.ascontiguousarray(pts, np.int32).reshape(-1, 2)

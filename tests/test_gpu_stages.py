@@ -132,6 +132,29 @@ def test_fit_min_area_rect_dense_nested_contours(gpu_ctx, oracle):
         assert (det_g, nb_g) == (det_o, nb_o) and np.array_equal(box_g, box_o)
 
 
+def test_device_libm_agrees_with_the_host_on_the_rectangle_path(gpu_ctx, oracle):
+    """minAreaRect's angle (atan2 in double, rounded to float32, in degrees) and boxPoints' cos / sin of it are the only
+    libm calls on the accept / reject path; the device evaluates them with its own libm, the oracle with glibc.  Both are
+    accurate to about an ulp in double, so their float32 roundings can only differ where the true value sits on a float32
+    rounding boundary.  4 million operand pairs of the kind the path produces (edge vectors of integer-coordinate hulls,
+    float32 calipers vectors, the axes) and none differs."""
+    rng = np.random.default_rng(99)
+    n = 1_000_000
+    ys = [rng.integers(-4096, 4097, n).astype(np.float64), rng.normal(0, 300, n).astype(np.float32).astype(np.float64),
+          (rng.integers(-64, 65, n) / 2.0), rng.normal(0, 3, n).astype(np.float32).astype(np.float64)]
+    xs = [rng.integers(-4096, 4097, n).astype(np.float64), rng.normal(0, 300, n).astype(np.float32).astype(np.float64),
+          (rng.integers(-64, 65, n) / 2.0), rng.normal(0, 3, n).astype(np.float32).astype(np.float64)]
+    axes = np.array([[0, 1], [1, 0], [0, -1], [-1, 0], [0, 0], [1, 1], [-1, 1], [1, -1], [-1, -1]], np.float64)
+    ys.append(axes[:, 0]); xs.append(axes[:, 1])
+    bad = 0
+    for y, x in zip(ys, xs):
+        dev = gpu_ctx.debug_trig(y, x)
+        host = oracle.debug_trig(y, x)
+        for d, h_ in zip(dev, host):
+            bad += int(np.count_nonzero(d.view(np.uint32) != h_.view(np.uint32)))
+    assert bad == 0
+
+
 def test_unsupported_contour_knobs_raise(gpu_ctx):
     from lfd_amd import _native
     img = np.zeros((32, 32), np.uint8)
