@@ -14,6 +14,8 @@
 #include <atomic>
 #include <string>
 #include <thread>
+#include <mutex>
+#include <memory>
 #include <vector>
 
 #include "../../include/lfdmi.h"
@@ -1690,31 +1692,54 @@ static void feed_start(lfdmi_ctx *ctx, FeedState *fs, const char *src, size_t fr
     const int T = ctx->feed_threads, device = ctx->device;
     hipStream_t copy = ctx->feed_copy;
     fs->th = std::thread([=] {
-        hipSetDevice(device);
-        int j = 0;
-        for (int c0 = 0; c0 < n; c0 += per, j++) {
-            while (fs->done.load(std::memory_order_acquire) < j - 1) { // buffers of chunk j - 2 still in use
-                if (fs->stop.load()) return;
-                std::this_thread::yield();
+        // The call's pieces in order; T workers (this thread is one of them) live for the whole call and copy their slice
+        // of every piece (threads started per piece cost as much as the copy itself); whoever completes a piece sends it
+        // -- and any completed pieces queued behind an unfinished one -- on its way, strictly in order.
+        struct Piece { int chunk; size_t src_off, off, bytes; bool last; };
+        std::vector<Piece> pieces;
+        {
+            int j = 0;
+            for (int c0 = 0; c0 < n; c0 += per, j++) {
+                const size_t bytes = (size_t)std::min(per, n - c0) * frame_bytes;
+                for (size_t o = 0; o < bytes; o += FEED_PIECE)
+                    pieces.push_back({j, (size_t)c0 * frame_bytes, o, std::min<size_t>(FEED_PIECE, bytes - o), o + FEED_PIECE >= bytes});
             }
-            const size_t bytes = (size_t)std::min(per, n - c0) * frame_bytes;
-            const char *s = src + (size_t)c0 * frame_bytes;
-            const int slot = j & 1;
-            for (size_t o = 0; o < bytes; o += FEED_PIECE) {
-                size_t pb = std::min<size_t>(FEED_PIECE, bytes - o);
-                int t_n = pb >= (size_t)T * (1u << 20) ? T : 1;
-                std::vector<std::thread> th;
-                for (int t = 1; t < t_n; t++) {
-                    size_t a = pb / t_n * t, b = (t == t_n - 1) ? pb : pb / t_n * (t + 1);
-                    th.emplace_back([=] { memcpy(pin[slot] + o + a, s + o + a, b - a); });
-                }
-                memcpy(pin[slot] + o, s + o, t_n > 1 ? pb / t_n : pb);
-                for (auto &x : th) x.join();
-                hipMemcpyAsync(dev[slot] + o, pin[slot] + o, pb, hipMemcpyHostToDevice, copy);
-            }
-            hipEventRecord(up[slot], copy);
-            fs->issued.store(j + 1, std::memory_order_release);
         }
+        const int P = (int)pieces.size();
+        std::unique_ptr<std::atomic<int>[]> copied(new std::atomic<int>[P]);
+        for (int k = 0; k < P; k++) copied[k].store(0);
+        std::mutex mu;
+        int next_issue = 0;
+        auto worker = [&](int t) {
+            hipSetDevice(device);
+            for (int k = 0; k < P; k++) {
+                const Piece &pc = pieces[k];
+                while (fs->done.load(std::memory_order_acquire) < pc.chunk - 1) { // buffers of chunk j - 2 still in use
+                    if (fs->stop.load()) return;
+                    std::this_thread::yield();
+                }
+                const int slot = pc.chunk & 1;
+                const size_t a = (pc.bytes * t / T) & ~(size_t)63, b = t == T - 1 ? pc.bytes : ((pc.bytes * (t + 1) / T) & ~(size_t)63);
+                if (b > a) memcpy(pin[slot] + pc.off + a, src + pc.src_off + pc.off + a, b - a);
+                if (copied[k].fetch_add(1, std::memory_order_acq_rel) + 1 == T) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    while (next_issue < P && copied[next_issue].load(std::memory_order_acquire) == T) {
+                        const Piece &q = pieces[next_issue];
+                        const int qs = q.chunk & 1;
+                        hipMemcpyAsync(dev[qs] + q.off, pin[qs] + q.off, q.bytes, hipMemcpyHostToDevice, copy);
+                        if (q.last) {
+                            hipEventRecord(up[qs], copy);
+                            fs->issued.store(q.chunk + 1, std::memory_order_release);
+                        }
+                        next_issue++;
+                    }
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(worker, t);
+        worker(0);
+        for (auto &x : th) x.join();
     });
 }
 
