@@ -64,7 +64,7 @@ KERNEL_BYTES_PER_PX = {
     "k_pixlist": 0.5, "k_hough_vote": 1.25, "k_hough_peaks": 0.25,
 }
 # timing slot of the library -> the kernels it brackets, as rocprofv3 names them (template variants are averaged, the kernels of a slot summed)
-TRAFFIC_KEYS = {"k_morph(dilate)": ["k_morph_rect_v<0"], "k_morph(erode)": ["k_erode_cand", "k_morph_rect_v<1"], "k_canny_nms": ["k_canny_nms_v"],
+TRAFFIC_KEYS = {"k_morph(dilate)": ["k_morph_rect_v<0"], "k_morph(erode)": ["k_erode_cand", ("k_morph_rect_rows<1", "k_morph_rect_v<1")], "k_canny_nms": ["k_canny_nms_v"],
                 "k_dilate_canny": ["k_dc_tiles", "k_dilate_canny_t"], "k_frame_bg": ["k_frame_contours"], "k_prep_dual": ["k_prep_erode<true"],
                 "k_prep_erode": ["k_prep_erode<false"]}
 
@@ -80,11 +80,15 @@ def load_traffic(name, cfg):
             if (c.get("workload", "sdss"), c["frames_per_gpu"], c["inflight"], c["lanes"], c["shape"]) != cfg:
                 continue
             total = 0
-            for key in TRAFFIC_KEYS.get(name, [name.split("(")[0]]):
-                hits = [v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items() if k == key or k.startswith(key + "<") or k.startswith(key + ",")
-                        or (key.endswith(("<0", "<1", "<false", "<true")) and k.startswith(key))]
+            for keys in TRAFFIC_KEYS.get(name, [name.split("(")[0]]):
+                hits = []
+                for key in (keys if isinstance(keys, tuple) else (keys,)):   # a tuple: alternative kernels of one step, first present wins
+                    hits = [v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items() if k == key or k.startswith(key + "<") or k.startswith(key + ",")
+                            or (key.endswith(("<0", "<1", "<false", "<true")) and k.startswith(key))]
+                    if hits:
+                        break
                 if not hits:
-                    raise KeyError(key)
+                    raise KeyError(keys)
                 total += sum(hits) / len(hits)
             return int(total), os.path.basename(path)
         except (OSError, KeyError, ValueError):

@@ -19,9 +19,9 @@ def _oracle(k):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     k0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    workers = min(32, os.cpu_count() or 8)
+    workers = min(16, os.cpu_count() or 8)
     t0 = time.time()
-    with mp.get_context("fork").Pool(workers) as pool:       # before the GPU is touched
+    with mp.get_context("spawn").Pool(workers) as pool:      # fresh interpreters: nothing GPU-related is inherited
         want = pool.map(_oracle, range(k0, k0 + n), chunksize=2)
     t_cpu = time.time() - t0
     from lfd_amd import _native, synth
