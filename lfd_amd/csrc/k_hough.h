@@ -300,7 +300,6 @@ k_hough_peaks(const int *accum, u64 *peaks, int *counters, int numangle, int num
     const int *ag = accum + ((size_t)g * 2 + im) * acc_cap;
     u64 *pg = peaks + ((size_t)g * 2 + im) * peak_cap;
     const int ts = numangle + 2;
-    const int total = numangle * numrho;
     // Peaks are collected in LDS and handed to the frame's list with ONE global atomic per flush: with threshold 1 an
     // accumulator has thousands of local maxima, and one atomicAdd each on the same counter serialises (~100 ns apiece).
     constexpr int PK_BUF = 4096; // (a block of rows adds at most 8 x 256 entries: flushed while that many are free)

@@ -141,21 +141,27 @@ __device__ __forceinline__ unsigned prep_f64(double x, int mode, double mf, doub
 #define CELLBM_COLS 16
 #define CELLBM_WORDS 8 // 512 cells: image widths up to 8191
 
-template <int MODE> // 0 .. 3: float32 frames with the mode known at compile time; -1: any dtype, run-time mode
+// MODE 0 .. 3: float32 frames with the mode known at compile time; -1: any dtype, run-time mode.
+// DELTA (lfdmi_detect_batch's bright pass): the same sweep also evaluates the DIM pass's conversion (mode 3 with mf2 / af2) of
+// every pixel.  With 0 <= addFlux <= 1 and minFlux <= 0.5 that value is the bright one or one more, so one bit per pixel
+// (dbits, a bit-row plane in the output orientation) and the dim image's histogram (hist2) are all the dim pass's front end
+// needs besides the 8-bit bright image: it never reads the float frames again (12.2 MB -> 3.4 MB per SDSS frame).
+template <int MODE, bool DELTA = false>
 __global__ void __launch_bounds__(256)
 k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double minFlux,
             double addFlux, uint8_t *gray, int *hist, u64 *cellbm, int bm_bands, const int *active, u64 *fullbits,
-            int prep_rows) { // rows per workgroup: a divisor of CELLBM_ROWS (a workgroup's rows lie in one band)
+            int prep_rows, // rows per workgroup: a divisor of CELLBM_ROWS (a workgroup's rows lie in one band)
+            u64 *dbits = nullptr, int *hist2 = nullptr, float mf2 = 0.f, float af2 = 0.f, u64 *nzd = nullptr) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
-    __shared__ int sh[4][256];
-    for (int k = threadIdx.x; k < 1024; k += 256) ((int *)sh)[k] = 0;
+    __shared__ int sh[DELTA ? 8 : 4][256];
+    for (int k = threadIdx.x; k < (DELTA ? 2048 : 1024); k += 256) ((int *)sh)[k] = 0;
     __syncthreads();
     int wv = threadIdx.x >> 6;
     size_t N = (size_t)h * w;
     uint8_t *gout = gray + (size_t)g * N;
     int zeros = 0;
-    HistAcc acc;
+    HistAcc acc, acc2;
     int r0 = blockIdx.x * prep_rows;
     float mf = (float)minFlux, af = (float)addFlux;
     unsigned nzpos = 0; // bit i: this lane met a non-zero value at its i-th column position (any of the rows)
@@ -188,6 +194,31 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
                         if (lfd_lane() == 0) fullbits[((size_t)g * h + r) * ((w + 255) >> 8) + (x4 >> 6)] = fb;
                     }
                     hist_word(word, sh[wv], acc);
+                    if (DELTA) {
+                        // (minFlux > 0, the usual case: x < mf covers x < 0, and x >= mf implies x > 0: one compare, one select)
+                        auto dimv = [&](float x) -> unsigned {
+                            return mf2 > 0.f ? sat_u8_f32(x < mf2 ? 0.0f : __fadd_rn(x, af2)) : prep_f32_m<3>(x, mf2, af2);
+                        };
+                        const uint32_t wd = dimv(v[k].x) | (dimv(v[k].y) << 8) | (dimv(v[k].z) << 16) | (dimv(v[k].w) << 24);
+                        hist_word(wd, sh[4 + wv], acc2);
+                        const uint32_t df = wd - word; // 0 or 1 per byte (see above): no borrows
+                        uint32_t nib = (df & 1u) | ((df >> 7) & 2u) | ((df >> 14) & 4u) | ((df >> 21) & 8u);
+                        // eight lanes (32 pixels) make one 32-bit half of a bit-row word: OR over the row of lanes (DPP row_shr)
+                        uint32_t bw = nib << (4 * (threadIdx.x & 7));
+                        bw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bw, 0x111, 0xf, 0xf, true); // row_shr:1
+                        bw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bw, 0x112, 0xf, 0xf, true); // row_shr:2
+                        bw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bw, 0x114, 0xf, 0xf, true); // row_shr:4
+                        if ((threadIdx.x & 7) == 7) ((uint32_t *)(dbits + ((size_t)g * h + r) * LFD_WQ(w)))[x4 >> 3] = bw;
+                        // ... and the same for "dim value non-zero" (k_bits_erode decides from these bits alone where an erosion
+                        // can leave anything)
+                        const uint32_t y_ = (((wd | 0x80808080u) - 0x01010101u) | wd) & 0x80808080u; // 0x80 per non-zero byte
+                        uint32_t nw = ((y_ >> 7) & 1u) | ((y_ >> 14) & 2u) | ((y_ >> 21) & 4u) | ((y_ >> 28) & 8u);
+                        nw <<= 4 * (threadIdx.x & 7);
+                        nw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nw, 0x111, 0xf, 0xf, true);
+                        nw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nw, 0x112, 0xf, 0xf, true);
+                        nw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nw, 0x114, 0xf, 0xf, true);
+                        if ((threadIdx.x & 7) == 7) ((uint32_t *)(nzd + ((size_t)g * h + r) * LFD_WQ(w)))[x4 >> 3] = nw;
+                    }
                 }
             }
         }
@@ -210,6 +241,7 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
     // zeros dominate sky frames: count them in registers, one LDS add per wave
     acc.zeros += zeros;
     hist_flush(acc, sh[wv]);
+    if (DELTA) hist_flush(acc2, sh[4 + wv]);
     // occupied cells of this workgroup's rows (one band): position i of wave wv covers ppl pixels per lane
     // from column 256 ppl i + 64 ppl wv on, i.e. (64 ppl / 16) cells
     if (cellbm && r0 < h) {
@@ -229,6 +261,10 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
     int b = threadIdx.x;
     int s = sh[0][b] + sh[1][b] + sh[2][b] + sh[3][b];
     if (s) atomicAdd(&hist[g * 256 + b], s);
+    if (DELTA) {
+        int s2 = sh[4][b] + sh[5][b] + sh[6][b] + sh[7][b];
+        if (s2) atomicAdd(&hist2[g * 256 + b], s2);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -248,10 +284,14 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
 // and its cell occupancy (gray_b / hist_b / cellbm_b) for the band's own rows: lfdmi_detect_batch runs both passes on the
 // same frames, so the 12.2 MB of a frame cross HBM once instead of twice (the dim outputs of frames the bright pass then
 // accepts are not used).
+// MODE -2: the input is not the float frame but the bright pass's 8-bit image (gsrc, already in output orientation) plus
+// the one-bit-per-pixel plane k_prep_hist<1, true> left (dsrc): dim value = bright value + bit; the histogram was taken there.
 template <bool DUAL, int MODE>
 __global__ void __launch_bounds__(PE_THREADS)
 k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float af, uint8_t *dst, int *hist, int kh, int kw,
-             int BR, u64 *cellbm, int bm_bands, const int *active, uint8_t *gray_b, int *hist_b, u64 *cellbm_b) {
+             int BR, u64 *cellbm, int bm_bands, const int *active, uint8_t *gray_b, int *hist_b, u64 *cellbm_b,
+             const uint8_t *gsrc = nullptr, const u64 *dsrc = nullptr) {
+    constexpr bool FROMBITS = MODE == -2;
     int g = blockIdx.y;
     if (active && !active[g]) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t smb[];
@@ -278,6 +318,8 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
     int r_c = threadIdx.x / W4, x_c = threadIdx.x - r_c * W4;
     for (int it0 = threadIdx.x; it0 < R * W4; it0 += 4 * PE_THREADS) { // four row pieces in flight per lane
         float4 v[4];
+        uint32_t gw[4];
+        u64 dw[4];
         int gyv[4], rr[4], xx[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -290,8 +332,16 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
             const int r = rr[u], x4 = xx[u];
             int gy = y0 - ay + r;
             gyv[u] = (r < R && gy >= 0 && gy < h) ? gy : -1;
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gyv[u] >= 0) v[u] = ((const float4 *)(s + (size_t)(flip ? (h - 1 - gy) : gy) * w))[x4];
+            if constexpr (FROMBITS) {
+                gw[u] = 0u; dw[u] = 0ull;
+                if (gyv[u] >= 0) {
+                    gw[u] = ((const uint32_t *)(gsrc + (size_t)g * N + (size_t)gy * w))[x4];
+                    dw[u] = dsrc[((size_t)g * h + gy) * LFD_WQ(w) + (x4 >> 4)];
+                }
+            } else {
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gyv[u] >= 0) v[u] = ((const float4 *)(s + (size_t)(flip ? (h - 1 - gy) : gy) * w))[x4];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -299,9 +349,15 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
             if (r >= R) continue;
             uint32_t word = 0xFFFFFFFFu;
             if (gyv[u] >= 0) {
-                word = prep_f32_m<MODE>(v[u].x, mf, af) | (prep_f32_m<MODE>(v[u].y, mf, af) << 8) |
-                       (prep_f32_m<MODE>(v[u].z, mf, af) << 16) | (prep_f32_m<MODE>(v[u].w, mf, af) << 24);
-                if (gyv[u] >= y0 && gyv[u] < y0 + BR) { // the band's own rows: every image row is counted once
+                if constexpr (FROMBITS) {
+                    const uint32_t nib = (uint32_t)(dw[u] >> (4 * (x4 & 15))) & 0xFu;
+                    word = gw[u] + ((nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21));
+                } else {
+                    constexpr int M = MODE >= 0 ? MODE : 0;
+                    word = prep_f32_m<M>(v[u].x, mf, af) | (prep_f32_m<M>(v[u].y, mf, af) << 8) |
+                           (prep_f32_m<M>(v[u].z, mf, af) << 16) | (prep_f32_m<M>(v[u].w, mf, af) << 24);
+                }
+                if (!FROMBITS && gyv[u] >= y0 && gyv[u] < y0 + BR) { // the band's own rows: every image row is counted once
                     hist_word(word, sh[wv], acc);
                     if (DUAL) { // the bright pass's image of the same pixels
                         const uint32_t word2 = prep_f32_m<1>(v[u].x, 0.f, 0.f) | (prep_f32_m<1>(v[u].y, 0.f, 0.f) << 8) |
@@ -318,10 +374,11 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
             band[r * SW + 4 + x4] = word;
         }
     }
-    hist_flush(acc, sh[wv]);
+    if (!FROMBITS) hist_flush(acc, sh[wv]);
     if (DUAL) hist_flush(acc_b, sh[NH + wv]);
     __syncthreads();
-    if (threadIdx.x < 256) {
+    if (FROMBITS) {
+    } else if (threadIdx.x < 256) {
         int b = threadIdx.x, t = 0;
         for (int k = 0; k < NH; k++) t += sh[k][b];
         if (t) atomicAdd(&hist[g * 256 + b], t);
@@ -388,6 +445,114 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
         // a lane's 16 bytes are one cell of the occupancy bitmap
         if (cellbm && (outw[0] | outw[1] | outw[2] | outw[3]))
             atomicOr((unsigned long long *)&cellbm[((size_t)g * bm_bands + gy / CELLBM_ROWS) * CELLBM_WORDS + (x16 >> 6)], 1ull << (x16 & 63));
+    }
+}
+
+// Erosion (all-ones kh x kw, anchor at the centre, outside pixels ignored) of the DIM pass's 8-bit image without that image
+// ever being stored: k_prep_hist<1, true> left the bright image (gsrc), one bit per pixel "dim value = bright value + 1"
+// (dbits) and one bit per pixel "dim value non-zero" (nzd).  An eroded pixel is non-zero exactly where all kh x kw input
+// pixels are, which is bit arithmetic on the nzd rows: a lane owns one 64-pixel word of a row, ANDs the shifted words of the
+// kh rows, and the wave writes zeros for its 4096 pixels with 16-byte stores.  Only for the surviving bits (objects: the
+// sky is zeros and ones at random, P(3 x 3 all non-zero) ~ 1e-6) are the window's values fetched and the minimum stored.
+// The float frames are not read again and the sky costs a few bit operations per 64 pixels.
+__global__ void __launch_bounds__(256)
+k_bits_erode(const uint8_t *gsrc, const u64 *dbits, const u64 *nzd, uint8_t *dst, u64 *cellbm, int bm_bands, int h, int w, int kh, int kw,
+             const int *active) {
+    const int g = blockIdx.y;
+    if (active && !active[g]) return;
+    const int wq = LFD_WQ(w), nw = h * wq, lane = threadIdx.x & 63;
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; // this wave's 64 words
+    if (i0 >= nw) return;
+    const int i = i0 + lane;
+    const int ay = kh / 2, ax = kw / 2;
+    const size_t N = (size_t)h * w;
+    const u64 *nz = nzd + (size_t)g * nw;
+    u64 e = 0ull;
+    int y = 0, q = 0;
+    if (i < nw) {
+        y = i / wq; q = i - y * wq;
+        e = valid_mask(q, w);
+        for (int dy = 0; dy < kh; dy++) {
+            const int yy = y + dy - ay;
+            if (yy < 0 || yy >= h) continue; // rows outside the image do not constrain
+            const u64 *row = nz + (size_t)yy * wq;
+            const u64 c = row[q] | ~valid_mask(q, w);           // columns outside the image do not constrain either
+            const u64 p = q > 0 ? row[q - 1] : ~0ull;
+            const u64 n = q + 1 < wq ? (row[q + 1] | ~valid_mask(q + 1, w)) : ~0ull;
+            u64 ha = c;
+            for (int sft = 1; sft <= kw - 1 - ax; sft++) ha &= (c >> sft) | (n << (64 - sft)); // columns x + sft
+            for (int sft = 1; sft <= ax; sft++) ha &= (c << sft) | (p >> (64 - sft));           // columns x - sft
+            e &= ha;
+        }
+    }
+    // zeros for the wave's pixels (64 words = 4096 bytes, contiguous: rows are whole words when w % 64 == 0; otherwise a word's
+    // bytes beyond the row end belong to nobody and are skipped), then the survivors
+    uint8_t *d = dst + (size_t)g * N;
+    if ((w & 63) == 0) {
+        uint4 *dz = (uint4 *)(d + (size_t)i0 * 64);
+        const int n16 = min(64, nw - i0) * 4;
+        for (int k = lane; k < n16; k += 64) dz[k] = make_uint4(0, 0, 0, 0);
+    } else if (i < nw) {
+        const int x0 = q << 6, nb = min(64, w - x0);
+        for (int b = 0; b < nb; b++) d[(size_t)y * w + x0 + b] = 0; // (odd widths are not on the batch path: plain and slow)
+    }
+    u64 todo = __ballot(e != 0ull);
+    if (todo == 0ull) return;
+    if (e) { // cells of the output (16 x 16 pixels: four per word)
+        u64 cells = 0ull;
+        for (int c = 0; c < 4; c++)
+            if ((e >> (16 * c)) & 0xFFFFull) cells |= 1ull << c;
+        const int cx0 = q * 4;
+        atomicOr((unsigned long long *)&cellbm[((size_t)g * bm_bands + y / CELLBM_ROWS) * CELLBM_WORDS + (cx0 >> 6)], cells << (cx0 & 63));
+    }
+    const uint8_t *gs = gsrc + (size_t)g * N;
+    const u64 *db = dbits + (size_t)g * nw;
+    // The survivors of the wave's 64 words are spread over the lanes: every lane queues up to eight of its word's bits per
+    // round in a list in LDS (position from a prefix sum over the lanes), then the wave works through the list a pixel per
+    // lane (a word per iteration kept one lane in eight busy: survivors come as short stretches across a trail or a star).
+    __shared__ unsigned short qlist[4][512];
+    __shared__ int qyq[4][64];
+    const int wvi = threadIdx.x >> 6;
+    qyq[wvi][lane] = (y << 8) | q; // q < 128 (image widths up to 8191)
+    u64 rem = e;
+    for (;;) {
+        const int cnt = min(__popcll(rem), 8);
+        int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        const int total = __shfl(incl, 63);
+        if (total == 0) break;
+        int o = incl - cnt;
+        for (int k = 0; k < cnt; k++) {
+            const int bb = __ffsll((long long)rem) - 1;
+            rem &= rem - 1;
+            qlist[wvi][o++] = (unsigned short)((lane << 6) | bb);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < total; t += 64) {
+            const unsigned ent = qlist[wvi][t];
+            const int yq = qyq[wvi][ent >> 6];
+            const int yy0 = yq >> 8, x = ((yq & 0xff) << 6) + (int)(ent & 63u);
+            auto val = [&](int yy, int xx) -> unsigned {
+                if (yy < 0 || yy >= h || xx < 0 || xx >= w) return 255u; // outside pixels are ignored by an erosion
+                return (unsigned)gs[(size_t)yy * w + xx] + (unsigned)((db[(size_t)yy * wq + (xx >> 6)] >> (xx & 63)) & 1ull);
+            };
+            unsigned m = 255u;
+            if (kh == 3 && kw == 3) { // the reference's default: nine independent loads in flight
+                unsigned v9[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) v9[k] = val(yy0 + k / 3 - 1, x + k % 3 - 1);
+#pragma unroll
+                for (int k = 0; k < 9; k++) m = min(m, v9[k]);
+            } else {
+                for (int dy = 0; dy < kh; dy++)
+                    for (int dx = 0; dx < kw; dx++) m = min(m, val(yy0 + dy - ay, x + dx - ax));
+            }
+            d[(size_t)yy0 * w + x] = (uint8_t)m;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -85,6 +85,9 @@ struct lfdmi_ctx {
     int *hist2 = nullptr;
     bool fuse_dual = false;            // LFDMI_FUSE_DUAL=1: one sweep over the float frames feeds both passes (measured slower:
                                        // the band kernel is bound by its instruction stream, not by HBM; kept for experiments)
+    u64 *dbits = nullptr, *nzd = nullptr; // one bit per pixel each: dim value = bright value + bit; dim value non-zero (k_prep_hist<1, true> -> k_bits_erode)
+    bool delta_dim = true;             // LFDMI_DELTA_DIM=0: the dim pass of lfdmi_detect_batch converts the float frames again
+    int delta_state = 0;               // 1: this bright pass also writes dbits / hist2; 2: this dim pass starts from them
     int dual_state = 0;                // 0: none; 1: the next run_front is a bright pass that also feeds the dim pass; 2: dim pass already fed
     int2 *rsa = nullptr;               // k_frame_contours: (row slot, component) per candidate run, FRAME_RUNCAP per slot
     long long *prof = nullptr;         // LFDMI_FRAME_PROFILE=1: per-frame phase clocks of k_frame_contours (developer tool)
@@ -280,6 +283,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_FRAME_CCL")) ctx->frame_ccl = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_FUSE_PREP_ERODE")) ctx->fuse_prep_erode = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_FUSE_DUAL")) ctx->fuse_dual = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_DELTA_DIM")) ctx->delta_dim = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_VOTE_SPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->vote_split = v; }
     if (const char *e = getenv("LFDMI_PE_ROWS")) { int v = atoi(e); if (v >= 2 && v <= 64) ctx->pe_rows = v; }
     if (const char *e = getenv("LFDMI_FRAME_RUNCAP")) { int v = atoi(e); if (v >= 0 && v < FRAME_RUNCAP) ctx->frame_runcap = v; }
@@ -328,6 +332,8 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     RET(dmalloc(ctx, &ctx->edgeb, G * BW));
     RET(dmalloc(ctx, &ctx->equb, G * BW));
     RET(dmalloc(ctx, &ctx->boxb, G * BW));
+    RET(dmalloc(ctx, &ctx->dbits, G * BW));
+    RET(dmalloc(ctx, &ctx->nzd, G * BW));
     for (int **p : {&ctx->Lf, &ctx->YMf, &ctx->FLf, &ctx->Lb, &ctx->YMb, &ctx->FLb, &ctx->SBf, &ctx->SBb, &ctx->PAb,
                     &ctx->ROWf, &ctx->ROWb})
         RET(dmalloc(ctx, p, G * ctx->run_cap));
@@ -393,6 +399,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, -2>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<true, LFDMI_PREP_BRIGHT_THEN_DIM>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_frame_contours, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (FRAME_RUNCAP + 4 * (FRAME_RUNCAP / 32)) * (int)sizeof(int)));
@@ -555,7 +562,8 @@ static dim3 word_grid(int h, int w, int n) { return dim3((unsigned)((h * LFD_WQ(
 
 // ---- stage runners (device pointers only, nc <= G images in workspace slots 0..nc-1) --------
 static int run_prep(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int mode,
-                    double minFlux, double addFlux, const int *active, bool zeroed = false, u64 *fullbits = nullptr) {
+                    double minFlux, double addFlux, const int *active, bool zeroed = false, u64 *fullbits = nullptr,
+                    const lfdmi_params *delta_dim = nullptr) {
     if (!zeroed) {
         HIPCHK(hipMemsetAsync(ctx->hist, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->cellbm, 0, (size_t)nc * ctx->bm_bands * CELLBM_WORDS * sizeof(u64), ctx->stream));
@@ -571,6 +579,11 @@ static int run_prep(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, i
 #define LFD_PREP_LAUNCH(M_)                                                                                                          \
     k_prep_hist<M_><<<pgrid, 256, 0, ctx->stream>>>(src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist, ctx->cellbm, \
                                                     ctx->bm_bands, active, fullbits, prep_rows)
+        if (delta_dim) { // the bright pass of lfdmi_detect_batch: the dim pass's values and histogram from the same sweep
+            k_prep_hist<1, true><<<pgrid, 256, 0, ctx->stream>>>(src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist,
+                                                                  ctx->cellbm, ctx->bm_bands, active, fullbits, prep_rows, ctx->dbits,
+                                                                  ctx->hist2, (float)delta_dim->minFlux, (float)delta_dim->addFlux, ctx->nzd);
+        } else
         if (dtype == LFDMI_F32 && (w & 3) == 0) { // float frames: the mode as a compile-time constant
             switch (mode & 3) {
             case 0: LFD_PREP_LAUNCH(0); break;
@@ -1052,9 +1065,17 @@ static bool can_fuse_prep_erode(const lfdmi_ctx *ctx, int dtype, int w, const ui
 }
 
 static int run_prep_erode(lfdmi_ctx *ctx, const void *src, int nc, int h, int w, int flip, int mode, double minFlux, double addFlux,
-                          int kh, int kw, const int *active) { // (hist / cellbm zeroed by the caller)
+                          int kh, int kw, const int *active, bool from_bits = false) { // (hist / cellbm zeroed by the caller)
     int BR = prep_erode_rows(ctx, w, kh);
     size_t lds = (size_t)(2 * BR + kh - 1) * (w + 32) + 16; // (+ one piece: the sliding window peeks one word ahead)
+    if (from_bits) { // the bright pass's image and bit planes instead of the float frames; histogram (hist2) taken there; marks into cellbm2
+        Span sp(ctx, KID_PREP_ERODE);
+        const int nwords = h * LFD_WQ(w);
+        k_bits_erode<<<dim3((nwords + 255) / 256, nc), 256, 0, ctx->stream>>>(ctx->gray, ctx->dbits, ctx->nzd, ctx->tmp, ctx->cellbm2,
+                                                                             ctx->bm_bands, h, w, kh, kw, active);
+        KCHK("k_bits_erode");
+        return 0;
+    }
     {
         Span sp(ctx, KID_PREP_ERODE);
 #define LFD_PE_LAUNCH(M_)                                                                                                             \
@@ -1102,6 +1123,17 @@ static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, 
                      const lfdmi_params *p, const int *active, const lfdmi_params *dual_dim = nullptr) {
     const uint8_t *dil_src = ctx->gray;
     const u64 *bm = ctx->cellbm;
+    if (dim && ctx->delta_state == 2) {
+        // the bright pass left this pass's values (gray + one bit per pixel) and their histogram: no second sweep over the floats
+        HIPCHK(hipMemsetAsync(ctx->zero_block + ctx->zero_counters_off, 0, ctx->zero_bytes - ctx->zero_counters_off, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->cellbm2, 0, (size_t)nc * ctx->bm_bands * CELLBM_WORDS * sizeof(u64), ctx->stream));
+        { Span sp(ctx, KID_LUT);
+          k_lut<<<nc, 256, 0, ctx->stream>>>(ctx->hist2, h * w, ctx->lut, active);
+          KCHK("k_lut"); }
+        RET(run_prep_erode(ctx, nullptr, nc, h, w, 0, 0, 0, 0, p->erode_kh, p->erode_kw, active, true));
+        dil_src = ctx->tmp;
+        bm = ctx->cellbm2;
+    } else
     if (dim && ctx->dual_state == 2) {
         // the bright pass's front end already produced this pass's eroded image, histogram and cell bitmap (run_prep_dual)
         HIPCHK(hipMemsetAsync(ctx->zero_block + ctx->zero_counters_off, 0, ctx->zero_bytes - ctx->zero_counters_off, ctx->stream));
@@ -1112,7 +1144,7 @@ static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, 
         bm = ctx->cellbm2;
     } else {
     HIPCHK(hipMemsetAsync(ctx->zero_block, 0, ctx->zero_bytes, ctx->stream)); // counters, histograms, cell bitmap
-    if (!dim && dual_dim) {
+    if (!dim && dual_dim && ctx->delta_state != 1) {
         RET(run_prep_dual(ctx, src, nc, h, w, flip, dual_dim));
     } else
     if (dim && can_fuse_prep_erode(ctx, dtype, w, p->erodeKernel, p->erode_kh, p->erode_kw)) {
@@ -1123,7 +1155,9 @@ static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, 
         // its output: the fused dilate + Canny kernel then only visits tiles near what is left)
         const bool wide = dim && p->erode_kw >= 7 && dtype == LFDMI_F32 && (w & 3) == 0 && p->erode_kh <= 33;
         if (dim) HIPCHK(hipMemsetAsync(ctx->zero_block2, 0, ctx->zero_bytes2, ctx->stream));
-        RET(run_prep(ctx, src, dtype, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, active, true, wide ? ctx->fullbits : nullptr));
+        const lfdmi_params *dd = (!dim && ctx->delta_state == 1) ? dual_dim : nullptr;
+        if (dd) HIPCHK(hipMemsetAsync(ctx->hist2, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
+        RET(run_prep(ctx, src, dtype, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, active, true, wide ? ctx->fullbits : nullptr, dd));
         if (dim) {
             bool marked = false;
             RET(run_morph(ctx, ctx->gray, ctx->tmp, nullptr, nullptr, p->erodeKernel, p->erode_kh, p->erode_kw, 1, nc, h, w, active,
@@ -1816,14 +1850,22 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
         // both passes read the same float frames: one sweep feeds both where the dim pass's front end can be fused at all
         const bool dual = ctx->fuse_dual && can_fuse_prep_erode(ctx, LFDMI_F32, w, dim->erodeKernel, dim->erode_kh, dim->erode_kw);
         struct DualState { lfdmi_ctx *c; ~DualState() { c->dual_state = 0; } } dual_guard{ctx};
+        // ... or, cheaper, the bright pass's sweep leaves one bit per pixel from which the dim pass rebuilds its 8-bit image
+        // (dim value = bright value + bit, for 0 <= addFlux <= 1 and minFlux <= 0.5) together with that image's histogram
+        const bool delta = !dual && ctx->delta_dim && (w % 32) == 0 && dim->addFlux >= 0.0 && dim->addFlux <= 1.0 && dim->minFlux <= 0.5 &&
+                           can_fuse_prep_erode(ctx, LFDMI_F32, w, dim->erodeKernel, dim->erode_kh, dim->erode_kw);
+        struct DeltaState { lfdmi_ctx *c; ~DeltaState() { c->delta_state = 0; } } delta_guard{ctx};
         ctx->cur_pass = 0;
         ctx->dual_state = 0;
-        RET(run_pass(ctx, d, LFDMI_F32, nc, h, w, 1, LFDMI_PREP_BRIGHT, false, bright, nullptr, ctx->need_dim, dual ? dim : nullptr));
+        ctx->delta_state = delta ? 1 : 0;
+        RET(run_pass(ctx, d, LFDMI_F32, nc, h, w, 1, LFDMI_PREP_BRIGHT, false, bright, nullptr, ctx->need_dim, (dual || delta) ? dim : nullptr));
         ctx->cur_pass = 1;
         ctx->dual_state = dual ? 2 : 0;
+        ctx->delta_state = delta ? 2 : 0;
         RET(run_pass(ctx, d, LFDMI_F32, nc, h, w, 1, LFDMI_PREP_BRIGHT_THEN_DIM, true, dim, ctx->need_dim, nullptr));
         ctx->cur_pass = 0;
         ctx->dual_state = 0;
+        ctx->delta_state = 0;
         if (host_blot && !blotted) { // host threads zero-fill the caller's frames in the background (joined below / at the end)
             if (blotter.joinable()) blotter.join();
             blotter = std::thread([=, bx = boxes] { blot_host_frames(frames + (size_t)c0 * N, nc, h, w, cat, c0, bx); });

@@ -247,15 +247,16 @@ def test_cell_bitmap_and_general_run_kernels_do_not_change_results(monkeypatch):
     """LFDMI_CELLBM=0 (every tile of the fused dilate + Canny kernel loads its input), LFDMI_FRAME_CCL=0 (multi-workgroup
     run kernels instead of the per-frame LDS kernels), LFDMI_DC_TILELIST=0 (the strip-walking fused kernel instead of the
     active-tile list), another split of the tile list over waves and LFDMI_DC_SPECIALIZE=0 (run-time instead of compile-time
-    structuring-element sizes in the tile kernel) and LFDMI_FUSE_DUAL=1 (one sweep over the float frames feeds both passes
-    instead of a front end per pass) against the default fast paths: identical records and edge images."""
+    structuring-element sizes in the tile kernel), LFDMI_FUSE_DUAL=1 (one band-kernel sweep over the float frames feeds both
+    passes) and LFDMI_DELTA_DIM=0 (the dim pass converts the float frames again instead of rebuilding its image from the
+    bright image and one bit per pixel) against the default fast paths: identical records and edge images."""
     from lfd_amd import _native, synth
     pb, pd, prs = params()
     frames = np.stack([synth.make_frame(k, with_catalog=False)[0] for k in range(6)])
     outs = []
     for env in ({}, {"LFDMI_CELLBM": "0"}, {"LFDMI_FRAME_CCL": "0"}, {"LFDMI_DC_TILELIST": "0"}, {"LFDMI_DC_TILELIST": "0", "LFDMI_CELLBM": "0"},
-                {"LFDMI_DC_PARTS": "7"}, {"LFDMI_DC_SPECIALIZE": "0"}, {"LFDMI_FUSE_DUAL": "1"}):
-        for k in ("LFDMI_CELLBM", "LFDMI_FRAME_CCL", "LFDMI_DC_TILELIST", "LFDMI_DC_PARTS", "LFDMI_DC_SPECIALIZE", "LFDMI_FUSE_DUAL"):
+                {"LFDMI_DC_PARTS": "7"}, {"LFDMI_DC_SPECIALIZE": "0"}, {"LFDMI_FUSE_DUAL": "1"}, {"LFDMI_DELTA_DIM": "0"}):
+        for k in ("LFDMI_CELLBM", "LFDMI_FRAME_CCL", "LFDMI_DC_TILELIST", "LFDMI_DC_PARTS", "LFDMI_DC_SPECIALIZE", "LFDMI_FUSE_DUAL", "LFDMI_DELTA_DIM"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
