@@ -66,7 +66,7 @@ KERNEL_BYTES_PER_PX = {
 # timing slot of the library -> the kernels it brackets, as rocprofv3 names them (template variants are averaged, the kernels of a slot summed)
 TRAFFIC_KEYS = {"k_morph(dilate)": ["k_morph_rect_v<0"], "k_morph(erode)": ["k_erode_cand", ("k_morph_rect_rows<1", "k_morph_rect_v<1")], "k_canny_nms": ["k_canny_nms_v"],
                 "k_dilate_canny": ["k_dc_tiles", "k_dilate_canny_t"], "k_frame_bg": ["k_frame_contours"], "k_prep_dual": ["k_prep_erode<true"],
-                "k_prep_erode": ["k_prep_erode<false"]}
+                "k_prep_erode": [("k_bits_erode", "k_prep_erode<false")]}
 
 
 def load_traffic(name, cfg):

@@ -146,7 +146,7 @@ __device__ __forceinline__ unsigned prep_f64(double x, int mode, double mf, doub
 // every pixel.  With 0 <= addFlux <= 1 and minFlux <= 0.5 that value is the bright one or one more, so one bit per pixel
 // (dbits, a bit-row plane in the output orientation) and the dim image's histogram (hist2) are all the dim pass's front end
 // needs besides the 8-bit bright image: it never reads the float frames again (12.2 MB -> 3.4 MB per SDSS frame).
-template <int MODE, bool DELTA = false>
+template <int MODE, bool DELTA = false, bool MFPOS = false> // MFPOS: DELTA with mf2 > 0 (one compare and one select per value)
 __global__ void __launch_bounds__(256)
 k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double minFlux,
             double addFlux, uint8_t *gray, int *hist, u64 *cellbm, int bm_bands, const int *active, u64 *fullbits,
@@ -197,7 +197,8 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
                     if (DELTA) {
                         // (minFlux > 0, the usual case: x < mf covers x < 0, and x >= mf implies x > 0: one compare, one select)
                         auto dimv = [&](float x) -> unsigned {
-                            return mf2 > 0.f ? sat_u8_f32(x < mf2 ? 0.0f : __fadd_rn(x, af2)) : prep_f32_m<3>(x, mf2, af2);
+                            if constexpr (MFPOS) return sat_u8_f32(x < mf2 ? 0.0f : __fadd_rn(x, af2));
+                            else return prep_f32_m<3>(x, mf2, af2);
                         };
                         const uint32_t wd = dimv(v[k].x) | (dimv(v[k].y) << 8) | (dimv(v[k].z) << 16) | (dimv(v[k].w) << 24);
                         hist_word(wd, sh[4 + wv], acc2);
@@ -284,14 +285,10 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
 // and its cell occupancy (gray_b / hist_b / cellbm_b) for the band's own rows: lfdmi_detect_batch runs both passes on the
 // same frames, so the 12.2 MB of a frame cross HBM once instead of twice (the dim outputs of frames the bright pass then
 // accepts are not used).
-// MODE -2: the input is not the float frame but the bright pass's 8-bit image (gsrc, already in output orientation) plus
-// the one-bit-per-pixel plane k_prep_hist<1, true> left (dsrc): dim value = bright value + bit; the histogram was taken there.
 template <bool DUAL, int MODE>
 __global__ void __launch_bounds__(PE_THREADS)
 k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float af, uint8_t *dst, int *hist, int kh, int kw,
-             int BR, u64 *cellbm, int bm_bands, const int *active, uint8_t *gray_b, int *hist_b, u64 *cellbm_b,
-             const uint8_t *gsrc = nullptr, const u64 *dsrc = nullptr) {
-    constexpr bool FROMBITS = MODE == -2;
+             int BR, u64 *cellbm, int bm_bands, const int *active, uint8_t *gray_b, int *hist_b, u64 *cellbm_b) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t smb[];
@@ -318,8 +315,6 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
     int r_c = threadIdx.x / W4, x_c = threadIdx.x - r_c * W4;
     for (int it0 = threadIdx.x; it0 < R * W4; it0 += 4 * PE_THREADS) { // four row pieces in flight per lane
         float4 v[4];
-        uint32_t gw[4];
-        u64 dw[4];
         int gyv[4], rr[4], xx[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -332,16 +327,8 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
             const int r = rr[u], x4 = xx[u];
             int gy = y0 - ay + r;
             gyv[u] = (r < R && gy >= 0 && gy < h) ? gy : -1;
-            if constexpr (FROMBITS) {
-                gw[u] = 0u; dw[u] = 0ull;
-                if (gyv[u] >= 0) {
-                    gw[u] = ((const uint32_t *)(gsrc + (size_t)g * N + (size_t)gy * w))[x4];
-                    dw[u] = dsrc[((size_t)g * h + gy) * LFD_WQ(w) + (x4 >> 4)];
-                }
-            } else {
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gyv[u] >= 0) v[u] = ((const float4 *)(s + (size_t)(flip ? (h - 1 - gy) : gy) * w))[x4];
-            }
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gyv[u] >= 0) v[u] = ((const float4 *)(s + (size_t)(flip ? (h - 1 - gy) : gy) * w))[x4];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -349,15 +336,9 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
             if (r >= R) continue;
             uint32_t word = 0xFFFFFFFFu;
             if (gyv[u] >= 0) {
-                if constexpr (FROMBITS) {
-                    const uint32_t nib = (uint32_t)(dw[u] >> (4 * (x4 & 15))) & 0xFu;
-                    word = gw[u] + ((nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21));
-                } else {
-                    constexpr int M = MODE >= 0 ? MODE : 0;
-                    word = prep_f32_m<M>(v[u].x, mf, af) | (prep_f32_m<M>(v[u].y, mf, af) << 8) |
-                           (prep_f32_m<M>(v[u].z, mf, af) << 16) | (prep_f32_m<M>(v[u].w, mf, af) << 24);
-                }
-                if (!FROMBITS && gyv[u] >= y0 && gyv[u] < y0 + BR) { // the band's own rows: every image row is counted once
+                word = prep_f32_m<MODE>(v[u].x, mf, af) | (prep_f32_m<MODE>(v[u].y, mf, af) << 8) |
+                       (prep_f32_m<MODE>(v[u].z, mf, af) << 16) | (prep_f32_m<MODE>(v[u].w, mf, af) << 24);
+                if (gyv[u] >= y0 && gyv[u] < y0 + BR) { // the band's own rows: every image row is counted once
                     hist_word(word, sh[wv], acc);
                     if (DUAL) { // the bright pass's image of the same pixels
                         const uint32_t word2 = prep_f32_m<1>(v[u].x, 0.f, 0.f) | (prep_f32_m<1>(v[u].y, 0.f, 0.f) << 8) |
@@ -374,11 +355,10 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
             band[r * SW + 4 + x4] = word;
         }
     }
-    if (!FROMBITS) hist_flush(acc, sh[wv]);
+    hist_flush(acc, sh[wv]);
     if (DUAL) hist_flush(acc_b, sh[NH + wv]);
     __syncthreads();
-    if (FROMBITS) {
-    } else if (threadIdx.x < 256) {
+    if (threadIdx.x < 256) {
         int b = threadIdx.x, t = 0;
         for (int k = 0; k < NH; k++) t += sh[k][b];
         if (t) atomicAdd(&hist[g * 256 + b], t);

@@ -399,7 +399,6 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, -2>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<true, LFDMI_PREP_BRIGHT_THEN_DIM>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_frame_contours, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (FRAME_RUNCAP + 4 * (FRAME_RUNCAP / 32)) * (int)sizeof(int)));
@@ -580,9 +579,13 @@ static int run_prep(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, i
     k_prep_hist<M_><<<pgrid, 256, 0, ctx->stream>>>(src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist, ctx->cellbm, \
                                                     ctx->bm_bands, active, fullbits, prep_rows)
         if (delta_dim) { // the bright pass of lfdmi_detect_batch: the dim pass's values and histogram from the same sweep
-            k_prep_hist<1, true><<<pgrid, 256, 0, ctx->stream>>>(src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist,
-                                                                  ctx->cellbm, ctx->bm_bands, active, fullbits, prep_rows, ctx->dbits,
-                                                                  ctx->hist2, (float)delta_dim->minFlux, (float)delta_dim->addFlux, ctx->nzd);
+#define LFD_PREP_DELTA(P_)                                                                                                            \
+    k_prep_hist<1, true, P_><<<pgrid, 256, 0, ctx->stream>>>(src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist,     \
+                                                              ctx->cellbm, ctx->bm_bands, active, fullbits, prep_rows, ctx->dbits,    \
+                                                              ctx->hist2, (float)delta_dim->minFlux, (float)delta_dim->addFlux, ctx->nzd)
+            if ((float)delta_dim->minFlux > 0.f) LFD_PREP_DELTA(true);
+            else LFD_PREP_DELTA(false);
+#undef LFD_PREP_DELTA
         } else
         if (dtype == LFDMI_F32 && (w & 3) == 0) { // float frames: the mode as a compile-time constant
             switch (mode & 3) {
