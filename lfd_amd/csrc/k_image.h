@@ -1364,6 +1364,27 @@ __device__ __forceinline__ void dcw_for_live(u64 live, uint32_t colmask, int lan
     }
 }
 
+// The same with ROWS lanes per column instead of 32: 64 / ROWS live columns per pass.  The Sobel items of a tile have 18 rows
+// and the NMS items 16 (rows R0 .. R0 + ROWS - 1): three / four columns per pass instead of two with half the lanes idle.
+template <int ROWS, int R0, typename F>
+__device__ __forceinline__ void dcw_for_live_n(u64 live, uint32_t colmask, int lane, F f) {
+    constexpr int NG = 64 / ROWS;
+    const int gi = lane / ROWS, r = R0 + lane - gi * ROWS;
+    while (live) {
+        uint32_t m = 0;
+        int j = 0;
+#pragma unroll
+        for (int t = 0; t < NG; t++)
+            if (live) {
+                const int jt = __ffsll((long long)live) - 1;
+                live &= live - 1;
+                const uint32_t mt = __builtin_amdgcn_readlane(colmask, jt);
+                if (gi == t) { m = mt; j = jt; }
+            }
+        if (gi < NG && ((m >> r) & 1)) f(r, j);
+    }
+}
+
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
 k_dilate_canny_w(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *strong, const uint8_t *lut, int h, int w,
                  int kh, int kw, int low, int high, const int *active, int nc, int tiles_x, int nstripx, int S, int SS,
