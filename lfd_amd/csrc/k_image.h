@@ -1694,11 +1694,16 @@ k_dilate_canny_t(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
         }
     };
     uint4 v[3];
-    int code = tl[t_begin];
-    load_tile(code, v);
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = 0;
 #define DCW_STAMP(k) do { if (PROF) { long long t_ = (long long)__builtin_amdgcn_s_memtime(); pacc[k] += t_ - pt0; pt0 = t_; } } while (0)
-    for (int ti = t_begin; ti < t_end; ti++) {
+    // the wave's share of the list is fetched up front, one entry per lane (a share is 3-12 tiles on SDSS frames, at most 64 on
+    // 4096 x 4096 ones): the next tile's input can be requested without first waiting for its list entry to arrive
+    for (int tb = t_begin; tb < t_end; tb += 64) {
+    const int cnt = min(64, t_end - tb);
+    const int codes = lane < cnt ? tl[tb + lane] : 0;
+    int code = __builtin_amdgcn_readlane(codes, 0);
+    load_tile(code, v);
+    for (int tk = 0; tk < cnt; tk++) {
         if (PROF) pt0 = (long long)__builtin_amdgcn_s_memtime();
         const int tx = code & 0xffff, x0 = tx * CANNY_TW, y0 = (code >> 16) * DCW_TH;
         uint32_t anyv = 0;
@@ -1710,14 +1715,15 @@ k_dilate_canny_t(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *st
                 anyv |= nzv;
                 *(uint4 *)(tin + iy[p] * TS + wx[p] * 16) = v[p];
             }
-        if (ti + 1 < t_end) { // next tile's input: in flight while this one is processed
-            code = tl[ti + 1];
+        if (tk + 1 < cnt) { // next tile's input: in flight while this one is processed
+            code = __builtin_amdgcn_readlane(codes, tk + 1);
             load_tile(code, v);
         }
         if (__ballot(anyv != 0) == 0ull) continue; // cells marked, bytes clear after all: the background is already in place
         constexpr int DCW_KHC = KH, DCW_KWC = KW;
 #include "k_dcw_tile.inc"
         if (PROF) pacc[7] += 1;
+    }
     }
 #undef DCW_STAMP
     if (PROF && prof && lane == 0)
