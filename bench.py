@@ -44,7 +44,9 @@ STAGES = {
     # both passes' front ends in one sweep over the float frames: 5N for every frame (bright image) + 7N for the frames the dim
     # pass then works on (priced in main(): the split depends on how many frames the bright pass accepts)
     "prep(bright)+prep+erode(dim)": (None, {"k_prep_dual": 1.0}),
-    "erode": (2.0, {"k_morph(erode)": 1.0}),
+    # (k_bits_erode: the dim pass of lfdmi_detect_batch erodes from the planes the bright pass's sweep left -- the dim
+    # conversion, 5N by this table, is part of k_prep_hist's one sweep there and is not charged a second time)
+    "erode": (2.0, {"k_morph(erode)": 1.0, "k_bits_erode": 1.0}),
     "dilate": (2.0, {"k_morph(dilate)": 1.0, "k_dilate_canny": 0.55}),
     # Canny = NMS (the Sobel / NMS stages are ~45 % of the fused tile kernel: stage ablation in profiles/README.md)
     # + hysteresis (candidate-run scan, per-frame union-find, general fallback kernels)
@@ -59,14 +61,14 @@ STAGES = {
 # so that nothing is counted twice (the fused tile kernel: dilate 2N + the image read of the Canny stage, 1N; the other
 # 1N of Canny -- its edge-map output -- belongs to the hysteresis kernels)
 KERNEL_BYTES_PER_PX = {
-    "k_prep_hist": 5.0, "k_prep_erode": 7.0, "k_prep_dual": None, "k_morph(erode)": 2.0, "k_morph(dilate)": 2.0, "k_dilate_canny": 3.0, "k_canny_nms": 1.0,
+    "k_prep_hist": 5.0, "k_prep_erode": 7.0, "k_prep_dual": None, "k_morph(erode)": 2.0, "k_bits_erode": 2.0, "k_morph(dilate)": 2.0, "k_dilate_canny": 3.0, "k_canny_nms": 1.0,
     "k_runs_init(fg)": 0.25, "k_frame_fg": 0.75, "k_runs_init(bg)": 0.25, "k_frame_bg": 1.0, "k_rects": 0.5, "k_fill_quads": 0.25,
     "k_pixlist": 0.5, "k_hough_vote": 1.25, "k_hough_peaks": 0.25,
 }
 # timing slot of the library -> the kernels it brackets, as rocprofv3 names them (template variants are averaged, the kernels of a slot summed)
 TRAFFIC_KEYS = {"k_morph(dilate)": ["k_morph_rect_v<0"], "k_morph(erode)": ["k_erode_cand", ("k_morph_rect_rows<1", "k_morph_rect_v<1")], "k_canny_nms": ["k_canny_nms_v"],
                 "k_dilate_canny": ["k_dc_tiles", "k_dilate_canny_t"], "k_frame_bg": ["k_frame_contours"], "k_prep_dual": ["k_prep_erode<true"],
-                "k_prep_erode": [("k_bits_erode", "k_prep_erode<false")]}
+                "k_prep_erode": ["k_prep_erode<false"]}
 
 
 def load_traffic(name, cfg):

@@ -34,14 +34,14 @@ enum {
     KID_REMOVESTARS = 0, KID_PREP_HIST, KID_LUT, KID_ERODE, KID_DILATE, KID_CANNY_NMS, KID_RUNS_INIT_FG,
     KID_RUNS_MERGE8, KID_RUNS_FLATTEN_FG, KID_EDGE, KID_RUNS_INIT_BG, KID_RUNS_MERGE4, KID_RUNS_FLATTEN_BG,
     KID_KEYS, KID_EXTREMES, KID_RECTS, KID_FILL, KID_PIXLIST, KID_VOTE, KID_PEAKS, KID_TOPK, KID_SORT,
-    KID_FINALIZE, KID_DILATE_CANNY, KID_FRAME_FG, KID_FRAME_BG, KID_FRAME_KEYS, KID_PREP_ERODE, KID_PREP_DUAL, KID_MISC, TG_COUNT
+    KID_FINALIZE, KID_DILATE_CANNY, KID_FRAME_FG, KID_FRAME_BG, KID_FRAME_KEYS, KID_PREP_ERODE, KID_PREP_DUAL, KID_BITS_ERODE, KID_MISC, TG_COUNT
 };
 static const char *const KID_NAMES[TG_COUNT] = {
     "k_removestars", "k_prep_hist", "k_lut", "k_morph(erode)", "k_morph(dilate)", "k_canny_nms", "k_runs_init(fg)",
     "k_runs_merge8", "k_runs_flatten(fg)", "k_edge_from_cand", "k_runs_init(bg)", "k_runs_merge4_bg",
     "k_runs_flatten(bg)", "k_keys", "k_extremes", "k_rects", "k_fill_quads", "k_pixlist", "k_hough_vote",
     "k_hough_peaks", "k_hough_topk", "k_hough_sort", "k_finalize", "k_dilate_canny", "k_frame_fg", "k_frame_bg",
-    "k_frame_keys", "k_prep_erode", "k_prep_dual", "misc"};
+    "k_frame_keys", "k_prep_erode", "k_prep_dual", "k_bits_erode", "misc"};
 
 struct TimedSpan { hipEvent_t a, b; int group, pass, det; };
 
@@ -1072,7 +1072,7 @@ static int run_prep_erode(lfdmi_ctx *ctx, const void *src, int nc, int h, int w,
     int BR = prep_erode_rows(ctx, w, kh);
     size_t lds = (size_t)(2 * BR + kh - 1) * (w + 32) + 16; // (+ one piece: the sliding window peeks one word ahead)
     if (from_bits) { // the bright pass's image and bit planes instead of the float frames; histogram (hist2) taken there; marks into cellbm2
-        Span sp(ctx, KID_PREP_ERODE);
+        Span sp(ctx, KID_BITS_ERODE);
         const int nwords = h * LFD_WQ(w);
         k_bits_erode<<<dim3((nwords + 255) / 256, nc), 256, 0, ctx->stream>>>(ctx->gray, ctx->dbits, ctx->nzd, ctx->tmp, ctx->cellbm2,
                                                                              ctx->bm_bands, h, w, kh, kw, active);
