@@ -85,6 +85,25 @@ def test_device_resident_frames_and_inplace_blotting(gpu_ctx, oracle):
         assert np.array_equal(dframes[i].cpu().numpy(), ref)          # remove_stars mutated the frame identically
 
 
+@pytest.mark.parametrize("min_flux,add_flux", [(0.02, 0.5), (0.4, 0.3), (0.5, 1.0), (0.0, 0.0), (-0.3, 0.7), (0.02, 1.5), (2.0, 0.5)])
+def test_dim_front_end_from_the_bright_sweep_for_any_flux_knobs(oracle, min_flux, add_flux):
+    """lfdmi_detect_batch rebuilds the dim pass's 8-bit image from the bright one plus one bit per pixel when 0 <= addFlux <= 1
+    and minFlux <= 0.5 (with a shorter conversion for minFlux > 0), and converts the float frames a second time otherwise:
+    every combination gives the oracle's records."""
+    from lfd_amd import _native, synth
+    pb, pd, _ = params()
+    pd = dict(pd, minFlux=min_flux, addFlux=add_flux)
+    frames = np.stack([synth.make_frame(k, with_catalog=False)[0] for k in (2, 9, 11, 14)])
+    frames[1, 200:210, 300:900] = np.nan                                # NaN / inf inside a frame: converted to 0 / 255 either way
+    frames[2, 700:704, 100:1500] = np.inf
+    frames[3, 50:60, 50:600] = -np.inf
+    with _native.Context(0, 1489, 2048, 4) as ctx:
+        res = ctx.detect_batch(frames.copy(), pb, pd)
+    for i in range(4):
+        want = oracle.detect_frame(frames[i].copy(), pb, pd)
+        assert same(res[i], want), (min_flux, add_flux, i, want, res[i])
+
+
 def test_python_api_bright_and_dim(oracle):
     from lfd_amd import synth
     from lfd_amd.detecttrails import process_field_bright, process_field_dim, dictify_hough
