@@ -106,12 +106,36 @@ __device__ __forceinline__ unsigned prep_f32_m(float x, float mf, float af) {
     if (MODE & 2) { x = x < mf ? 0.0f : x; x = x > 0.0f ? __fadd_rn(x, af) : x; }
     return sat_u8_f32(x);
 }
+// ... and four values at once: the masks as above, then round-half-even of |x| and V_CVT_PK_U8_F32, which saturates to
+// 0 .. 255 (NaN -> 0) and drops the byte into place: two instructions per pixel after the masks instead of four plus the packing
+template <int MODE>
+__device__ __forceinline__ float prep_mask_m(float x, float mf, float af) {
+    if (MODE & 1) x = x < 0.0f ? 0.0f : x;
+    if (MODE & 2) { x = x < mf ? 0.0f : x; x = x > 0.0f ? __fadd_rn(x, af) : x; }
+    return x;
+}
+__device__ __forceinline__ uint32_t pack_sat_u8x4(float a, float b, float c, float d) {
+    uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fabsf(a)), 0u, 0u);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fabsf(b)), 1u, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fabsf(c)), 2u, w);
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fabsf(d)), 3u, w);
+}
+template <int MODE>
+__device__ __forceinline__ uint32_t prep_word_m(float4 v, float mf, float af) {
+    return pack_sat_u8x4(prep_mask_m<MODE>(v.x, mf, af), prep_mask_m<MODE>(v.y, mf, af), prep_mask_m<MODE>(v.z, mf, af),
+                         prep_mask_m<MODE>(v.w, mf, af));
+}
+// bit 0 of each of a word's four bytes gathered into a nibble (byte j -> bit j): one V_DOT4_U32_U8
+__device__ __forceinline__ uint32_t lsb_nibble(uint32_t w01) { return __builtin_amdgcn_udot4(w01, 0x08040201u, 0u, false); }
 // Histogram of four converted pixels (one packed word).  Sky frames are zeros (bright pass) or zeros and ones (dim pass:
 // 78 % / 22 %): words made of those two values are counted in registers (n01 words, ones01 one-bytes among them), only
 // the others touch the LDS histogram.
 struct HistAcc { int n01 = 0, ones01 = 0, zeros = 0, ones = 0; };
 __device__ __forceinline__ void hist_word(uint32_t word, int *shrow, HistAcc &A) {
-    if ((word & 0xFEFEFEFEu) == 0u) { A.n01++; A.ones01 += __popc(word); return; }
+    const bool f01 = (word & 0xFEFEFEFEu) == 0u;
+    A.n01 += f01 ? 1 : 0;
+    A.ones01 += f01 ? __popc(word) : 0;
+    if (f01) return;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         unsigned v = (word >> (8 * q)) & 0xffu;
@@ -182,8 +206,7 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
                     int r = rb + k;
                     if (k >= prep_rows || r >= h) break;
                     constexpr int M = MODE >= 0 ? MODE : 0;
-                    const uint32_t word = prep_f32_m<M>(v[k].x, mf, af) | (prep_f32_m<M>(v[k].y, mf, af) << 8) |
-                                          (prep_f32_m<M>(v[k].z, mf, af) << 16) | (prep_f32_m<M>(v[k].w, mf, af) << 24);
+                    const uint32_t word = prep_word_m<M>(v[k], mf, af);
                     ((uint32_t *)(gout + (size_t)r * w))[x4] = word;
                     if (word) nzpos |= 1u << i;
                     // one bit per aligned word of four pixels: "all four non-zero".  Only where such words line up can a wide
@@ -196,14 +219,14 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
                     hist_word(word, sh[wv], acc);
                     if (DELTA) {
                         // (minFlux > 0, the usual case: x < mf covers x < 0, and x >= mf implies x > 0: one compare, one select)
-                        auto dimv = [&](float x) -> unsigned {
-                            if constexpr (MFPOS) return sat_u8_f32(x < mf2 ? 0.0f : __fadd_rn(x, af2));
-                            else return prep_f32_m<3>(x, mf2, af2);
+                        auto dimv = [&](float x) -> float {
+                            if constexpr (MFPOS) return x < mf2 ? 0.0f : __fadd_rn(x, af2);
+                            else return prep_mask_m<3>(x, mf2, af2);
                         };
-                        const uint32_t wd = dimv(v[k].x) | (dimv(v[k].y) << 8) | (dimv(v[k].z) << 16) | (dimv(v[k].w) << 24);
+                        const uint32_t wd = pack_sat_u8x4(dimv(v[k].x), dimv(v[k].y), dimv(v[k].z), dimv(v[k].w));
                         hist_word(wd, sh[4 + wv], acc2);
                         const uint32_t df = wd - word; // 0 or 1 per byte (see above): no borrows
-                        uint32_t nib = (df & 1u) | ((df >> 7) & 2u) | ((df >> 14) & 4u) | ((df >> 21) & 8u);
+                        uint32_t nib = lsb_nibble(df);
                         // eight lanes (32 pixels) make one 32-bit half of a bit-row word: OR over the row of lanes (DPP row_shr)
                         uint32_t bw = nib << (4 * (threadIdx.x & 7));
                         bw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bw, 0x111, 0xf, 0xf, true); // row_shr:1
@@ -213,7 +236,7 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
                         // ... and the same for "dim value non-zero" (k_bits_erode decides from these bits alone where an erosion
                         // can leave anything)
                         const uint32_t y_ = (((wd | 0x80808080u) - 0x01010101u) | wd) & 0x80808080u; // 0x80 per non-zero byte
-                        uint32_t nw = ((y_ >> 7) & 1u) | ((y_ >> 14) & 2u) | ((y_ >> 21) & 4u) | ((y_ >> 28) & 8u);
+                        uint32_t nw = lsb_nibble(y_ >> 7);
                         nw <<= 4 * (threadIdx.x & 7);
                         nw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nw, 0x111, 0xf, 0xf, true);
                         nw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nw, 0x112, 0xf, 0xf, true);
@@ -336,13 +359,11 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
             if (r >= R) continue;
             uint32_t word = 0xFFFFFFFFu;
             if (gyv[u] >= 0) {
-                word = prep_f32_m<MODE>(v[u].x, mf, af) | (prep_f32_m<MODE>(v[u].y, mf, af) << 8) |
-                       (prep_f32_m<MODE>(v[u].z, mf, af) << 16) | (prep_f32_m<MODE>(v[u].w, mf, af) << 24);
+                word = prep_word_m<MODE>(v[u], mf, af);
                 if (gyv[u] >= y0 && gyv[u] < y0 + BR) { // the band's own rows: every image row is counted once
                     hist_word(word, sh[wv], acc);
                     if (DUAL) { // the bright pass's image of the same pixels
-                        const uint32_t word2 = prep_f32_m<1>(v[u].x, 0.f, 0.f) | (prep_f32_m<1>(v[u].y, 0.f, 0.f) << 8) |
-                                               (prep_f32_m<1>(v[u].z, 0.f, 0.f) << 16) | (prep_f32_m<1>(v[u].w, 0.f, 0.f) << 24);
+                        const uint32_t word2 = prep_word_m<1>(v[u], 0.f, 0.f);
                         ((uint32_t *)(gray_b + (size_t)g * N + (size_t)gyv[u] * w))[x4] = word2;
                         hist_word(word2, sh[NH + wv], acc_b);
                         if (word2) { // (the bright image is sparse: a few thousand marks per frame)
