@@ -927,7 +927,7 @@ k_morph_rect_rows(const uint8_t *src, uint8_t *dst, const uint8_t *lut, int h, i
 // candidate bit per tile (candmask, two u64 per tile row), and the wave zero-fills the tile row of dst with 16-byte stores.
 // k_morph_rect_v then only runs on candidate tiles (a dim-pass sky: a handful around stars) instead of staging every tile.
 __global__ void __launch_bounds__(64)
-k_erode_cand(const u64 *fullbits, u64 *candmask, uint8_t *dst, int h, int w, int kh, const int *active) {
+k_erode_cand(const u64 *fullbits, u64 *candmask, uint8_t *dst, int h, int w, int kh, const int *active, int fill) {
     const int g = blockIdx.y, ty = blockIdx.x, lane = threadIdx.x;
     if (active && !active[g]) return;
     const int y0 = ty * MORPH_TH, ay = kh / 2, IH = MORPH_TH + kh - 1, ntx = (w + MORPH_TW - 1) / MORPH_TW, fw = (w + 255) >> 8;
@@ -953,10 +953,50 @@ k_erode_cand(const u64 *fullbits, u64 *candmask, uint8_t *dst, int h, int w, int
         u64 m = __ballot(cand);
         if (lane == 0) candmask[((size_t)g * gridDim.x + ty) * 2 + half] = m;
     }
+    if (!fill) return; // (k_fill_around zero-fills what the consumer can reach, once the erosion's output cells are known)
     uint4 *row = (uint4 *)(dst + (size_t)g * h * w);
     const int w16 = w >> 4;
     for (int r = y0; r < y0 + MORPH_TH && r < h; r++)
         for (int x = lane; x < w16; x += 64) row[(size_t)r * w16 + x] = make_uint4(0, 0, 0, 0);
+}
+
+// After the candidate tiles of a wide erosion have been written (k_morph_rect_rows, which also marked the 16 x 16 cells that
+// hold anything): the only consumer, the fused dilate + Canny tile kernel, visits a 64 x 16 tile only if a marked cell lies
+// within one cell band above / below and within cells 4 tx - 1 .. 4 tx + 4, and then reads rows 16 ty - 6 .. 16 ty + 21 (kh <= 9)
+// and columns 64 tx - 16 .. 64 tx + 79.  So a non-candidate 64 x 32 erosion tile (TX, TY) can only be read if a marked cell
+// lies in bands 2 TY - 2 .. 2 TY + 3 and cells 4 TX - 5 .. 4 TX + 8 (one more each way here): those are zero-filled, the rest
+// of the plane -- most of a sky frame after a 9 x 9 erosion -- is left untouched instead of 16 MB of zeros per frame.
+__global__ void __launch_bounds__(64)
+k_fill_around(const u64 *candmask, const u64 *cellbm, int bm_bands, uint8_t *dst, int h, int w, const int *active) {
+    const int g = blockIdx.y, ty = blockIdx.x, lane = threadIdx.x;
+    if (active && !active[g]) return;
+    const int ntx = (w + MORPH_TW - 1) / MORPH_TW;
+    __shared__ u64 m[CELLBM_WORDS];
+    if (lane < CELLBM_WORDS) {
+        u64 v = 0ull;
+        for (int b = 2 * ty - 3; b <= 2 * ty + 4; b++)
+            if (b >= 0 && b < bm_bands) v |= cellbm[((size_t)g * bm_bands + b) * CELLBM_WORDS + lane];
+        m[lane] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint8_t *d = dst + (size_t)g * h * w;
+    for (int half = 0; half < 2; half++) {
+        const int tx = lane + 64 * half;
+        bool need = false;
+        if (tx < ntx && !((candmask[((size_t)g * gridDim.x + ty) * 2 + half] >> lane) & 1ull)) {
+            const int c0 = max(0, 4 * tx - 6), c1 = min(CELLBM_WORDS * 64 - 1, 4 * tx + 9); // cells c0 .. c1 (at most 16)
+            u64 bits = m[c0 >> 6] >> (c0 & 63);
+            if ((c0 & 63) + (c1 - c0) > 63 && (c0 >> 6) + 1 < CELLBM_WORDS) bits |= m[(c0 >> 6) + 1] << (64 - (c0 & 63));
+            need = (bits & ((2ull << (c1 - c0)) - 1ull)) != 0ull;
+        }
+        for (u64 todo = __ballot(need); todo; todo &= todo - 1) {
+            const int t = __ffsll((long long)todo) - 1 + 64 * half, x0 = t * MORPH_TW;
+            for (int it = lane; it < MORPH_TH * (MORPH_TW / 16); it += 64) { // 32 rows x 4 pieces of 16 bytes
+                const int r = ty * MORPH_TH + (it >> 2), x = x0 + 16 * (it & 3);
+                if (r < h && x < w) *(uint4 *)(d + (size_t)r * w + x) = make_uint4(0, 0, 0, 0);
+            }
+        }
+    }
 }
 
 // arbitrary 0/1 structuring element (the knob is an array: detecttrails.py:205,220-221)

@@ -86,6 +86,7 @@ struct lfdmi_ctx {
     bool fuse_dual = false;            // LFDMI_FUSE_DUAL=1: one sweep over the float frames feeds both passes (measured slower:
                                        // the band kernel is bound by its instruction stream, not by HBM; kept for experiments)
     u64 *dbits = nullptr, *nzd = nullptr; // one bit per pixel each: dim value = bright value + bit; dim value non-zero (k_prep_hist<1, true> -> k_bits_erode)
+    bool sparse_erode_fill = true;     // LFDMI_SPARSE_ERODE_FILL=0: a wide erosion zero-fills its whole output plane
     bool delta_dim = true;             // LFDMI_DELTA_DIM=0: the dim pass of lfdmi_detect_batch converts the float frames again
     int delta_state = 0;               // 1: this bright pass also writes dbits / hist2; 2: this dim pass starts from them
     int dual_state = 0;                // 0: none; 1: the next run_front is a bright pass that also feeds the dim pass; 2: dim pass already fed
@@ -284,6 +285,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_FUSE_PREP_ERODE")) ctx->fuse_prep_erode = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_FUSE_DUAL")) ctx->fuse_dual = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_DELTA_DIM")) ctx->delta_dim = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_SPARSE_ERODE_FILL")) ctx->sparse_erode_fill = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_VOTE_SPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->vote_split = v; }
     if (const char *e = getenv("LFDMI_PE_ROWS")) { int v = atoi(e); if (v >= 2 && v <= 64) ctx->pe_rows = v; }
     if (const char *e = getenv("LFDMI_FRAME_RUNCAP")) { int v = atoi(e); if (v >= 0 && v < FRAME_RUNCAP) ctx->frame_runcap = v; }
@@ -612,7 +614,7 @@ static bool all_ones(const uint8_t *k, int kh, int kw) {
 // dst = op(src) with optional LUT / bit rows; kernel mask on the host
 static int run_morph(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, u64 *bits, const uint8_t *lut, const uint8_t *kernel,
                      int kh, int kw, int op, int nc, int h, int w, const int *active, const u64 *fullbits = nullptr, u64 *cellout = nullptr,
-                     bool *marked = nullptr) {
+                     bool *marked = nullptr, bool sparse_fill = false) { // sparse_fill: dst is only read by the tile kernel through cellout's marks
     if (marked) *marked = false;
     if (!kernel || kh <= 0 || kw <= 0 || kh > LFDMI_MAX_MORPH_K || kw > LFDMI_MAX_MORPH_K)
         return fail(ctx, LFDMI_ERR_UNSUPPORTED, "structuring element must be 1..31 on both sides");
@@ -625,7 +627,8 @@ static int run_morph(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, u64 *bits
         const u64 *cand = nullptr;
         if (op == 1 && fullbits && kw >= 7 && !lut && !bits && grid.x <= 128 && kh <= 33) {
             // sparse input with its "full word" bits: zero fill + candidate tiles first, then only those tiles are eroded
-            k_erode_cand<<<dim3(grid.y, nc), 64, 0, ctx->stream>>>(fullbits, ctx->candmask, dst, h, w, kh, active);
+            sparse_fill = sparse_fill && cellout && kh <= 9 && kw <= 33;
+            k_erode_cand<<<dim3(grid.y, nc), 64, 0, ctx->stream>>>(fullbits, ctx->candmask, dst, h, w, kh, active, sparse_fill ? 0 : 1);
             KCHK("k_erode_cand");
             cand = ctx->candmask;
         }
@@ -640,6 +643,10 @@ static int run_morph(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, u64 *bits
         else k_morph_rect_v<1><<<grid, 256, lds, ctx->stream>>>(src, dst, bits, lut, h, w, kh, kw, active, cellout, ctx->bm_bands);
         if (marked) *marked = cellout != nullptr;
         KCHK("k_morph_rect_v");
+        if (cand && sparse_fill) {
+            k_fill_around<<<dim3(grid.y, nc), 64, 0, ctx->stream>>>(cand, cellout, ctx->bm_bands, dst, h, w, active);
+            KCHK("k_fill_around");
+        }
     } else if (all_ones(kernel, kh, kw)) {
         int IH = MORPH_TH + kh - 1, IW = MORPH_TW + kw - 1;
         size_t lds = ((size_t)(IH * IW + 15) & ~(size_t)15) + (size_t)IH * MORPH_TW;
@@ -1163,8 +1170,12 @@ static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, 
         RET(run_prep(ctx, src, dtype, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, active, true, wide ? ctx->fullbits : nullptr, dd));
         if (dim) {
             bool marked = false;
+            // (the eroded plane is zero-filled only where the tile kernel can read it when that kernel is its one consumer)
+            const bool only_tiles = wide && !ctx->keep_equ && ctx->sparse_erode_fill && p->gaussKernel <= 0 && ctx->use_cellbm && ctx->dc_tilelist &&
+                                    p->dilate_kh <= 9 && p->dilate_kh <= DCW_MAXKH && can_fuse_dilate_canny(p->dilateKernel, p->dilate_kh, p->dilate_kw, w) &&
+                                    (w + CANNY_TW - 1) / CANNY_TW <= 128 && (h + DCW_TH - 1) / DCW_TH <= DCT_MAXBANDS; // (the tile-list path)
             RET(run_morph(ctx, ctx->gray, ctx->tmp, nullptr, nullptr, p->erodeKernel, p->erode_kh, p->erode_kw, 1, nc, h, w, active,
-                          wide ? ctx->fullbits : nullptr, ctx->cellbm2, &marked));
+                          wide ? ctx->fullbits : nullptr, ctx->cellbm2, &marked, only_tiles));
             dil_src = ctx->tmp;
             if (marked) bm = ctx->cellbm2;
         }

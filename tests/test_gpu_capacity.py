@@ -132,6 +132,43 @@ def test_get_stage_checks_the_shape_of_the_last_call():
         assert out.shape == (64, 128) and out[25, 60] == 200
 
 
+@pytest.mark.parametrize("fill", ["1", "0"])
+def test_wide_erosion_fills_only_what_the_tile_kernel_reads(oracle, monkeypatch, fill):
+    """A 9 x 9 erosion in a batch context (no stage images kept) zero-fills its output plane only around the cells that hold
+    anything; LFDMI_SPARSE_ERODE_FILL=0 fills all of it.  Frames with objects of every size next to tile borders, a second
+    call on the same context with other frames (stale bytes of the first call lie around), records and edge maps vs the
+    oracle."""
+    from lfd_amd import _native
+    from lfd_amd.detecttrails import default_params
+    monkeypatch.setenv("LFDMI_SPARSE_ERODE_FILL", fill)
+    _, pd, _ = default_params()
+    pd = dict(pd, erodeKernel=np.ones((9, 9), np.uint8))
+    h, w = 512, 1024
+    rng = np.random.default_rng(11)
+
+    def frame(seed):
+        r = np.random.default_rng(seed)
+        img = r.normal(0.0, 0.6, (h, w)).astype(np.float32)
+        yy, xx = np.mgrid[0:h, 0:w]
+        for _ in range(14):                                           # blobs of radius 6 .. 30, some across tile borders
+            cy, cx, rad = r.integers(0, h), r.integers(0, w), r.integers(6, 31)
+            img[(yy - cy) ** 2 + (xx - cx) ** 2 < rad * rad] += r.uniform(5, 200)
+        a, b = r.uniform(-0.8, 0.8), r.uniform(50, h - 50)
+        img[np.abs(yy - (a * xx + b)) < r.uniform(6, 12)] += 80.0     # a wide streak
+        return img
+
+    with _native.Context(0, h, w, 3) as ctx:
+        ctx.set_stage_images(0)
+        for seeds in ((1, 2, 3), (4, 5, 6)):
+            frames = np.stack([frame(s) for s in seeds])
+            res, _, _ = ctx.process_dim(frames.copy(), pd)
+            for i in range(3):
+                want, _, _ = oracle.process_dim(frames[i].copy(), pd, want_images=True)
+                assert all(res[i][k].item() == v for k, v in want.items()), (fill, seeds, i)
+                edges = ctx.get_stage(i, _native.STAGE_BOX, h, w)
+                assert np.array_equal(edges != 0, oracle.process_dim(frames[i].copy(), pd, want_images=True)[2] != 0)
+
+
 def test_stage_images_are_kept_only_where_asked_for(oracle):
     """lfdmi_set_stage_images: the per-pass calls keep the 8-bit stage images by default and lfdmi_detect_batch does not;
     a batch detector switches them off (get_stage then refuses instead of handing out stale bytes), mode 1 keeps them in
