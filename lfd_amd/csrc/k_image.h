@@ -937,17 +937,30 @@ k_erode_cand(const u64 *fullbits, u64 *candmask, uint8_t *dst, int h, int w, int
         if (tx < ntx) {
             const int j0 = 16 * tx - 1, jb = j0 < 0 ? 0 : j0, q = jb >> 6, sh2 = jb & 63, nb = 19 - (jb - j0);
             int consec = 0;
-            for (int t = 0; t < IH; t++) {
-                int gy = y0 - ay + t;
-                bool live = gy < 0 || gy >= h; // rows outside the image are ignored by an erosion
-                if (!live) {
-                    const u64 *fr = fullbits + ((size_t)g * h + gy) * fw;
-                    u64 b = fr[q] >> sh2;
-                    if (sh2 > 64 - 19 && q + 1 < fw) b |= fr[q + 1] << (64 - sh2);
-                    live = (b & ((1ull << nb) - 1ull)) != 0ull;
+            const bool two = sh2 > 64 - 19 && q + 1 < fw; // the 19 bits straddle two words
+            for (int t0 = 0; t0 < IH; t0 += 8) { // eight rows of loads in flight (a row at a time was a chain of 40 round trips)
+                u64 b0[8], b1[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int gy = y0 - ay + t0 + k;
+                    const bool in = t0 + k < IH && gy >= 0 && gy < h;
+                    const u64 *fr = fullbits + ((size_t)g * h + (in ? gy : 0)) * fw;
+                    b0[k] = in ? fr[q] : 0ull;
+                    b1[k] = (in && two) ? fr[q + 1] : 0ull;
                 }
-                consec = live ? consec + 1 : 0;
-                cand = cand || consec >= kh;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (t0 + k >= IH) break;
+                    const int gy = y0 - ay + t0 + k;
+                    bool live = gy < 0 || gy >= h; // rows outside the image are ignored by an erosion
+                    if (!live) {
+                        u64 b = b0[k] >> sh2;
+                        if (two) b |= b1[k] << (64 - sh2);
+                        live = (b & ((1ull << nb) - 1ull)) != 0ull;
+                    }
+                    consec = live ? consec + 1 : 0;
+                    cand = cand || consec >= kh;
+                }
             }
         }
         u64 m = __ballot(cand);
