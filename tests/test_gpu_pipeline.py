@@ -104,6 +104,26 @@ def test_dim_front_end_from_the_bright_sweep_for_any_flux_knobs(oracle, min_flux
         assert same(res[i], want), (min_flux, add_flux, i, want, res[i])
 
 
+@pytest.mark.parametrize("shape", [(250, 1056), (133, 544), (77, 96), (64, 2080)])
+def test_batch_on_widths_that_are_not_whole_bit_row_words(oracle, shape):
+    """Widths that are multiples of 32 but not of 64 (the last 64-pixel word of a bit row is half empty), heights that are not
+    multiples of the 16-row cell bands: lfdmi_detect_batch (bright sweep + bit-plane erosion) against the oracle."""
+    from lfd_amd import _native
+    pb, pd, _ = params()
+    h, w = shape
+    rng = np.random.default_rng(h * 10007 + w)
+    frames = rng.normal(0.2, 0.7, (3, h, w)).astype(np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    frames[0][np.abs(yy - (0.3 * xx + 10)) < 2.5] += 90.0               # bright streak
+    frames[1][np.abs(yy - (h - 5 - 0.2 * xx)) < 4.0] += 6.0             # dim streak running into the right border
+    frames[2][:, w - 40:] += 3.0                                        # a slab touching the last, half-empty word
+    with _native.Context(0, h, w, 2) as ctx:
+        res = ctx.detect_batch(frames.copy(), pb, pd)
+    for i in range(3):
+        want = oracle.detect_frame(frames[i].copy(), pb, pd)
+        assert same(res[i], want), (shape, i, want, res[i])
+
+
 def test_python_api_bright_and_dim(oracle):
     from lfd_amd import synth
     from lfd_amd.detecttrails import process_field_bright, process_field_dim, dictify_hough
