@@ -1866,7 +1866,10 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
         struct DualState { lfdmi_ctx *c; ~DualState() { c->dual_state = 0; } } dual_guard{ctx};
         // ... or, cheaper, the bright pass's sweep leaves one bit per pixel from which the dim pass rebuilds its 8-bit image
         // (dim value = bright value + bit, for 0 <= addFlux <= 1 and minFlux <= 0.5) together with that image's histogram
+        // (small erosion kernels only: k_bits_erode fetches kh x kw values per surviving pixel, which is nothing on sky frames but
+        // would be slow on a dense image with a large kernel; those keep the band kernel)
         const bool delta = !dual && ctx->delta_dim && (w % 32) == 0 && dim->addFlux >= 0.0 && dim->addFlux <= 1.0 && dim->minFlux <= 0.5 &&
+                           dim->erode_kh * dim->erode_kw <= 25 &&
                            can_fuse_prep_erode(ctx, LFDMI_F32, w, dim->erodeKernel, dim->erode_kh, dim->erode_kw);
         struct DeltaState { lfdmi_ctx *c; ~DeltaState() { c->delta_state = 0; } } delta_guard{ctx};
         ctx->cur_pass = 0;
