@@ -146,11 +146,19 @@ def main():
     from lfd_amd.batch import BatchDetector
     from lfd_amd.detecttrails import default_params
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # One rank per GPU.  Rehearsal on a box with fewer GPUs than ranks (LFD_BENCH_SHARE_GPU=1): ranks share devices round-robin
+    # and synchronise over gloo (RCCL refuses two ranks on one device) -- the sharding, timing and reduction code is the same.
+    share = os.environ.get("LFD_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or os.environ.get("LFD_BENCH_FORCE_DIST") == "1"  # the env switch lets a 1-GPU box rehearse the RCCL path
+    red_dev = torch.device("cpu") if share else dev
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     pb, pd, prs = default_params()
     rs = _native.make_rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
@@ -164,7 +172,7 @@ def main():
         packed = synth.pack_catalogs(cats)
         cat = {k: torch.from_numpy(v).to(dev) for k, v in packed.items()}
     stream = torch.cuda.current_stream().cuda_stream
-    det = BatchDetector(local_rank, (h, w), inflight, stream=stream, lanes=args.lanes)
+    det = BatchDetector(dev_index, (h, w), inflight, stream=stream, lanes=args.lanes)
 
     if lsst:
         def run(frames, _cat):
@@ -225,12 +233,12 @@ def main():
         fence()
         host_leg = time.perf_counter() - t0
         if use_dist:
-            t = torch.tensor([host_leg], dtype=torch.float64, device=dev)
+            t = torch.tensor([host_leg], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             host_leg = float(t.item())
         host_leg = (world * n * m / host_leg, m)
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -295,7 +303,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "frames_per_gpu": n, "inflight": inflight, "lanes": args.lanes, "shape": [h, w],
-                       "removestars": (not lsst) and not args.no_removestars, "parallelism": "frame-parallel x%d" % world,
+                       "removestars": (not lsst) and not args.no_removestars, "parallelism": "frame-parallel x%d" % world + (" (rehearsal: ranks share %d GPU(s), gloo)" % torch.cuda.device_count() if share else ""),
                        "found_bright": found_b, "found_dim": found_d, "frame_errors": errors,
                        "hough_rhos": rhos if lsst else [20.0],
                        "hough_nnz_equ_median": int(np.median(nnz_equ)) if len(nnz_equ) else 0,
