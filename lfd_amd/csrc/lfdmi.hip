@@ -114,9 +114,11 @@ struct lfdmi_ctx {
     // stream; chunk k+1 crosses PCIe while chunk k is being processed
     void *feed_pin[2] = {nullptr, nullptr}, *feed_dev[2] = {nullptr, nullptr};
     size_t feed_bytes = 0;
-    hipStream_t feed_copy = nullptr;
+    hipStream_t feed_copy = nullptr, feed_copy2 = nullptr; // (LFDMI_FEED_STREAMS=2: pieces alternate between two copy streams)
+    hipEvent_t feed_mid = nullptr;
+    int feed_streams = 2;
     hipEvent_t feed_up[2] = {nullptr, nullptr};
-    int feed_threads = 8;              // host threads copying a chunk into the pinned buffer (LFDMI_FEED_THREADS)
+    int feed_threads = 4;              // host threads copying a chunk into the pinned buffer (LFDMI_FEED_THREADS)
     size_t feed_chunk_bytes = 800u << 20; // largest feed chunk (LFDMI_FEED_MB): 64 SDSS frames, 11 frames of 4096 x 4096
     int4 *rs_boxes = nullptr;          // remove_stars squares of the chunk (host-frame path)
     size_t rs_boxes_cap = 0;
@@ -293,6 +295,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_DC_STRIP")) { int v = atoi(e); if (v >= 1 && v <= DCW_MAXS) ctx->dc_strip = v; } // tuning knob
     if (const char *e = getenv("LFDMI_DC_TILELIST")) ctx->dc_tilelist = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_DC_PARTS")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->dc_parts = v; }
+    if (const char *e = getenv("LFDMI_FEED_STREAMS")) { int v = atoi(e); if (v == 1 || v == 2) ctx->feed_streams = v; }
     if (const char *e = getenv("LFDMI_FEED_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->feed_threads = v; }
     if (const char *e = getenv("LFDMI_FEED_MB")) { int v = atoi(e); if (v >= 0 && v <= 8192) ctx->feed_chunk_bytes = (size_t)v << 20; } // 0: plain staging
     ctx->N = (size_t)max_h * max_w;
@@ -450,6 +453,8 @@ extern "C" void lfdmi_ctx_destroy(lfdmi_ctx *ctx) {
         if (ctx->feed_up[i]) hipEventDestroy(ctx->feed_up[i]);
     }
     if (ctx->feed_copy) hipStreamDestroy(ctx->feed_copy);
+    if (ctx->feed_copy2) hipStreamDestroy(ctx->feed_copy2);
+    if (ctx->feed_mid) hipEventDestroy(ctx->feed_mid);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->rs_boxes) hipFree(ctx->rs_boxes);
     if (ctx->cat_dev) hipFree(ctx->cat_dev);
@@ -1706,6 +1711,8 @@ extern "C" int lfdmi_process_multiscale(lfdmi_ctx *ctx, const void *img, int dty
 static int feed_prepare(lfdmi_ctx *ctx, size_t bytes) {
     if (!ctx->feed_copy) {
         HIPCHK(hipStreamCreateWithFlags(&ctx->feed_copy, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&ctx->feed_copy2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ctx->feed_mid, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&ctx->feed_up[i], hipEventDisableTiming));
     }
     if (ctx->feed_bytes >= bytes) return 0;
@@ -1738,7 +1745,8 @@ static void feed_start(lfdmi_ctx *ctx, FeedState *fs, const char *src, size_t fr
     char *pin[2] = {(char *)ctx->feed_pin[0], (char *)ctx->feed_pin[1]}, *dev[2] = {(char *)ctx->feed_dev[0], (char *)ctx->feed_dev[1]};
     hipEvent_t up[2] = {ctx->feed_up[0], ctx->feed_up[1]};
     const int T = ctx->feed_threads, device = ctx->device;
-    hipStream_t copy = ctx->feed_copy;
+    hipStream_t copy = ctx->feed_copy, copy2 = ctx->feed_streams == 2 ? ctx->feed_copy2 : ctx->feed_copy;
+    hipEvent_t mid = ctx->feed_mid;
     fs->th = std::thread([=] {
         // The call's pieces in order; T workers (this thread is one of them) live for the whole call and copy their slice
         // of every piece (threads started per piece cost as much as the copy itself); whoever completes a piece sends it
@@ -1774,8 +1782,9 @@ static void feed_start(lfdmi_ctx *ctx, FeedState *fs, const char *src, size_t fr
                     while (next_issue < P && copied[next_issue].load(std::memory_order_acquire) == T) {
                         const Piece &q = pieces[next_issue];
                         const int qs = q.chunk & 1;
-                        hipMemcpyAsync(dev[qs] + q.off, pin[qs] + q.off, q.bytes, hipMemcpyHostToDevice, copy);
+                        hipMemcpyAsync(dev[qs] + q.off, pin[qs] + q.off, q.bytes, hipMemcpyHostToDevice, (next_issue & 1) ? copy2 : copy);
                         if (q.last) {
+                            if (copy2 != copy) { hipEventRecord(mid, copy2); hipStreamWaitEvent(copy, mid, 0); }
                             hipEventRecord(up[qs], copy);
                             fs->issued.store(q.chunk + 1, std::memory_order_release);
                         }
