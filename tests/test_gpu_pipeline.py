@@ -124,6 +124,26 @@ def test_batch_on_widths_that_are_not_whole_bit_row_words(oracle, shape):
         assert same(res[i], want), (shape, i, want, res[i])
 
 
+@pytest.mark.parametrize("knobs", [dict(contoursMode=0), dict(contoursMode=3), dict(gaussKernel=5), dict(gaussKernel=3, gaussSigma=1.2, contoursMode=0),
+                                   dict(erodeKernel=np.ones((5, 5), np.uint8)), dict(erodeKernel=np.ones((7, 3), np.uint8)),
+                                   dict(dilateKernel=np.ones((5, 7), np.uint8)), dict(dilateKernel=np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8))])
+def test_batch_with_other_knob_values(oracle, knobs):
+    """lfdmi_detect_batch with contour modes, the optional Gaussian stage and other structuring elements in the dim pass
+    (its front end comes out of the bright sweep where the erosion kernel is small; the plane it leaves is then read by a
+    separate dilation or blur kernel rather than the fused tile kernel): records equal the oracle's."""
+    from lfd_amd import _native, synth
+    pb, pd, _ = params()
+    pd = dict(pd, **knobs)
+    if "contoursMode" in knobs or "gaussKernel" in knobs:
+        pb = dict(pb, **{k: v for k, v in knobs.items() if k in ("contoursMode", "gaussKernel", "gaussSigma")})
+    frames = np.stack([synth.make_frame(k, with_catalog=False)[0] for k in (0, 4, 8, 13, 17)])
+    with _native.Context(0, 1489, 2048, 3) as ctx:
+        res = ctx.detect_batch(frames.copy(), pb, pd)
+    for i in range(len(frames)):
+        want = oracle.detect_frame(frames[i].copy(), pb, pd)
+        assert same(res[i], want), (knobs, i, want, res[i])
+
+
 def test_python_api_bright_and_dim(oracle):
     from lfd_amd import synth
     from lfd_amd.detecttrails import process_field_bright, process_field_dim, dictify_hough
