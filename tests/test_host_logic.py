@@ -182,3 +182,21 @@ def test_parallel_frame_generator_matches_the_serial_one():
     one, cats1 = synth.make_frames(7, 1, shape, workers=8, with_catalog=False)
     assert np.array_equal(one[0], synth.make_frame(7, shape)[0]) and cats1 == [None]
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("lfd_synth_")] if os.path.isdir("/dev/shm") else True
+
+
+def test_bench_finds_the_committed_traffic_counters():
+    """bench.py prices `roofline.traffic` from profiles/r*_traffic*.json (PMC passes of the same command): the timing slots of
+    the kernels that can dominate a step resolve to kernels of the committed files, for both workloads."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sdss = ("sdss", 256, 256, 1, [1489, 2048])
+    lsst = ("lsst", 256, 256, 1, [4096, 4096])
+    for name, cfg in (("k_dilate_canny", sdss), ("k_prep_hist", sdss), ("k_bits_erode", sdss), ("k_hough_vote", sdss),
+                      ("k_prep_hist", lsst), ("k_morph(erode)", lsst), ("k_dilate_canny", lsst), ("k_hough_vote", lsst)):
+        nbytes, src = bench.load_traffic(name, cfg)
+        assert nbytes and nbytes > 1e6 and src.endswith(".json"), (name, cfg[0])
+
