@@ -329,7 +329,9 @@ def main():
         if host_leg:
             out["host_resident"] = {"value": round(host_leg[0], 2), "unit": "frames/s", "steps": host_leg[1],
                                     "note": "same step with the frames handed over as host buffers (PCIe-inclusive); never `value`"}
-        if cpu_sample > 0:
+        if world > 1:
+            out["cpu_baseline"] = None  # (the host baseline is timed at N = 1 only: rank 0 would keep the other ranks waiting)
+        elif cpu_sample > 0:
             from concurrent.futures import ThreadPoolExecutor
             from oracle import lfd_oracle as O
             rs_o = O.rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
