@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Headline benchmark: frames/s of the detecttrails hot path on N MI355X.
 
-    python bench.py --gpus 1 --steps 5 --warmup 1                      # BASELINE configs[2] (default)
-    python bench.py --workload lsst                                     # BASELINE configs[4]
+    python bench.py --gpus 1 --steps 5 --warmup 1                      # BASELINE configs[2] (default) + secondary legs
+    python bench.py --workload lsst                                     # BASELINE configs[4] as the headline of the run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W           # what the driver's scaling step runs
 
 workload sdss (BASELINE.json configs[2], the configuration the metric is quoted on): one "step" = one pass of the
 full pipe (remove_stars -> flip -> bright pass -> dim pass where the bright pass found nothing;
@@ -19,8 +19,16 @@ step costs ~6 % of it, so inside the timed region only the few largest kernels a
 fully bracketed warm-up steps); the dominant one is priced with ITS share of SURVEY.md 8(d)'s algorithmic bytes
 (KERNEL_BYTES_PER_PX: every stage's bytes are charged exactly once across its kernels) x the frames its launches
 worked on.  `stages` and `canny_hough` come from one extra, fully bracketed step run after the timed region.
-cpu_baseline: the C oracle (oracle/, a port of the reference's algorithm; the reference's own OpenCV path cannot
-run here or on the GPU box) on a bounded sample of the same frames: one host thread, and all host cores.
+
+Secondary fields of the default (N = 1, sdss) invocation -- never `value`:
+  host_resident  the same step with the frames handed over as host buffers (PCIe-inclusive);
+  sustained      the same device-resident step repeated for >= 3 s, GPU clock before / after;
+  dropin         DetectTrails(run=...).process(batch=256) over a synthetic $BOSS tree of FITS files in /dev/shm (plain and
+                 .bz2), rows compared with the device-resident run (the drop-in itself, file reading included);
+  lsst           the configs[4] step (value, roofline, canny_hough) -- the driver never passes --workload lsst;
+  cpu_baseline   the C oracle (oracle/, a port of the reference's algorithm) on a bounded sample of the same frames: one
+                 host thread, and all of the rank's host cores; `opencv`: the reference's own cv2 call sequence
+                 (oracle/cv2_path.py) where `import cv2` works, "unavailable" otherwise.
 """
 import argparse
 import json
@@ -34,10 +42,43 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# SURVEY 8(d)'s secondary bound for HoughLines (180 votes per non-zero pixel): one LDS atomic add per vote.  A wave64
+# ds_add costs 4 LDS cycles (MI355X_MICROARCH.md, LDS: ds_write_b32-class, 2 x 32 lanes + the address/data transfer), i.e.
+# 16 votes per clock per CU; 256 CUs at 2.4 GHz.  The vector units would allow more: >= 4 lane-operations per vote
+# (x cos, + y sin, round, address) on 4 SIMD-32 per CU.
+CU_COUNT, CLOCK_HZ = 256, 2.4e9
+LDS_ATOMIC_VOTES_PER_S = CU_COUNT * 16 * CLOCK_HZ
+VALU_VOTES_PER_S = CU_COUNT * 4 * 32 * CLOCK_HZ / 4.0
 
 # algorithmic bytes per pixel of every stage of a pass, and the kernels (timing slots of the library)
 # that make up the stage.  A kernel that spans two stages appears with a share of each (bytes, fraction of its time).
 #   prep 5N | erode 2N | dilate 2N | Canny 2N | contours+rect+fill 2N | Hough 1N per image
+# The fused tile kernel's time is split between dilate and Canny by the committed stage-clock profile (dc_split()).
+
+
+def dc_split():
+    """(dilate share, Canny share, source) of k_dilate_canny's time from the newest profiles/r*_dc_stage_clocks.txt
+    (tools/dc_profile.py: s_memtime stamps per stage): hmax + vmax+lut + borders are the dilation, sobel + nms+store are
+    Canny, the input wait and the activity masks serve both and are split in the same proportion."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dc_stage_clocks.txt")), reverse=True):
+        try:
+            dil = can = 0.0
+            for line in open(path):
+                if "hmax" not in line:
+                    continue
+                v = {k.strip(): float(x) for k, x in re.findall(r"([a-z+ ]+?)\s+(\d+)\s+\(\d+%\)", line)}
+                dil += v["hmax"] + v["vmax+lut"] + v["borders+equ bits"]
+                can += v["sobel"] + v["nms+store"]
+            if dil > 0 and can > 0:
+                return dil / (dil + can), can / (dil + can), os.path.basename(path)
+        except (OSError, KeyError, ValueError):
+            continue
+    return 0.5, 0.5, None
+
+
+DC_DILATE, DC_CANNY, DC_SRC = dc_split()
 STAGES = {
     "prep": (5.0, {"k_prep_hist": 1.0, "k_lut": 1.0, "k_removestars": 1.0}),
     "prep+erode": (7.0, {"k_prep_erode": 1.0}),
@@ -47,10 +88,10 @@ STAGES = {
     # (k_bits_erode: the dim pass of lfdmi_detect_batch erodes from the planes the bright pass's sweep left -- the dim
     # conversion, 5N by this table, is part of k_prep_hist's one sweep there and is not charged a second time)
     "erode": (2.0, {"k_morph(erode)": 1.0, "k_bits_erode": 1.0}),
-    "dilate": (2.0, {"k_morph(dilate)": 1.0, "k_dilate_canny": 0.55}),
-    # Canny = NMS (the Sobel / NMS stages are ~45 % of the fused tile kernel: stage ablation in profiles/README.md)
-    # + hysteresis (candidate-run scan, per-frame union-find, general fallback kernels)
-    "canny": (2.0, {"k_dilate_canny": 0.45, "k_canny_nms": 1.0, "k_runs_init(fg)": 1.0, "k_frame_fg": 1.0, "k_runs_merge8": 1.0,
+    "dilate": (2.0, {"k_morph(dilate)": 1.0, "k_dilate_canny": DC_DILATE}),
+    # Canny = NMS (the Sobel / NMS stages of the fused tile kernel) + hysteresis (candidate-run scan, per-frame union-find,
+    # general fallback kernels)
+    "canny": (2.0, {"k_dilate_canny": DC_CANNY, "k_canny_nms": 1.0, "k_runs_init(fg)": 1.0, "k_frame_fg": 1.0, "k_runs_merge8": 1.0,
                     "k_runs_flatten(fg)": 1.0, "k_edge_from_cand": 1.0}),
     "contours+rect+fill": (2.0, {"k_runs_init(bg)": 1.0, "k_frame_bg": 1.0, "k_frame_keys": 1.0, "k_runs_merge4_bg": 1.0,
                                  "k_runs_flatten(bg)": 1.0, "k_keys": 1.0, "k_extremes": 1.0, "k_rects": 1.0, "k_fill_quads": 1.0}),
@@ -98,67 +139,59 @@ def load_traffic(name, cfg):
     return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=("sdss", "lsst"), default="sdss")
-    ap.add_argument("--frames-per-gpu", type=int, default=None, help="default 256 (configs[2]: 256 per GPU; configs[4]: 2048 over 8 GPUs)")
-    ap.add_argument("--inflight", type=int, default=None, help="frames per launch (default: the whole batch)")
-    ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches (streams) per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=None, help="frames timed through the CPU oracle on one thread (0 = skip)")
-    ap.add_argument("--gen-workers", type=int, default=-1)
-    ap.add_argument("--no-removestars", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true",
-                    help="developer: leave the per-launch HIP events off (no roofline entry) to see what they cost")
-    ap.add_argument("--host-frames", action="store_true",
-                    help="developer: time ONLY the host-resident (PCIe-inclusive) path as the headline value of this run")
-    ap.add_argument("--no-host-leg", action="store_true", help="skip the secondary PCIe-inclusive measurement")
-    args = ap.parse_args()
+def gpu_clock_mhz(index=0):
+    """Current shader clock of the card (the level marked '*' in pp_dpm_sclk), or None where sysfs / rocm-smi do not say."""
+    import glob
+    import re
+    import subprocess
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+    if cards:
+        try:
+            for line in open(cards[min(index, len(cards) - 1)]):
+                if line.rstrip().endswith("*"):
+                    return int(re.search(r"(\d+)\s*[Mm][Hh]z", line).group(1))
+        except (OSError, AttributeError, ValueError):
+            pass
+    try:
+        txt = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+        m = re.search(r"sclk clock level:?\s*\d+:?\s*\(?(\d+)\s*[Mm][Hh]z", txt)
+        return int(m.group(1)) if m else None
+    except Exception:  # noqa: BLE001
+        return None
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-        args.gpus = world
 
-    from lfd_amd import synth
-    lsst = args.workload == "lsst"
+def host_cores(world):
+    """(threads the CPU legs may use, cores the process may run on): this rank's share of the node -- an MI355X node has 8
+    GPUs, so 1/8 of its cores per rank (256 / 8 = 32 on the pool's hosts; $LFD_CORES_PER_GPU overrides)."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        avail = os.cpu_count() or 1
+    per_gpu = int(os.environ.get("LFD_CORES_PER_GPU", 0)) or max(1, (os.cpu_count() or avail) // 8)
+    return max(1, min(avail, per_gpu * max(1, world))), avail
+
+
+def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True, sustained_s=0.0):
+    """One workload on this rank's GPU: generation, upload, warm-up, the timed region, the per-kernel table.  Returns
+    (out dict for rank 0 or None, state for the follow-up legs)."""
+    import torch
+    import torch.distributed as dist
+    from lfd_amd import _native, synth
+    from lfd_amd.batch import BatchDetector
+    from lfd_amd.detecttrails import default_params
+    rank, world, dev, dev_index, use_dist, red_dev, share = (env[k] for k in ("rank", "world", "dev", "dev_index", "use_dist", "red_dev", "share"))
+    lsst = workload == "lsst"
     shape = synth.LSST_SHAPE if lsst else synth.SDSS_SHAPE
-    n = args.frames_per_gpu or 256
     inflight = args.inflight or n
-    cpu_sample = args.cpu_sample if args.cpu_sample is not None else (2 if lsst else 40)
     k0 = rank * n
     workers = args.gen_workers
     if workers < 0:
-        workers = max(1, min(16, (os.cpu_count() or 8) // max(1, world)))
+        workers = max(1, min(32, host_cores(world)[0] // max(1, world)))
     t0 = time.time()
     # child processes (never forks of this one: safe under a profiler's preloaded library), frames into shared memory
-    host, cats = synth.make_frames(k0, n, shape, workers, with_catalog=not lsst)
+    nd = min(n, distinct or n)
+    host, cats = synth.make_frames(k0 if nd == n else 0, nd, shape, workers, with_catalog=not lsst)
     t_gen = time.time() - t0
-
-    import torch
-    import torch.distributed as dist
-    from lfd_amd import _native
-    from lfd_amd.batch import BatchDetector
-    from lfd_amd.detecttrails import default_params
-
-    # One rank per GPU.  Rehearsal on a box with fewer GPUs than ranks (LFD_BENCH_SHARE_GPU=1): ranks share devices round-robin
-    # and synchronise over gloo (RCCL refuses two ranks on one device) -- the sharding, timing and reduction code is the same.
-    share = os.environ.get("LFD_BENCH_SHARE_GPU") == "1"
-    dev_index = local_rank % max(1, torch.cuda.device_count()) if share else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    use_dist = world > 1 or os.environ.get("LFD_BENCH_FORCE_DIST") == "1"  # the env switch lets a 1-GPU box rehearse the RCCL path
-    red_dev = torch.device("cpu") if share else dev
-    if use_dist:
-        if share:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
 
     pb, pd, prs = default_params()
     rs = _native.make_rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
@@ -167,6 +200,10 @@ def main():
     if lsst:
         pd = dict(pd, erodeKernel=np.ones((9, 9), np.uint8))
     dframes = torch.from_numpy(host).to(dev)
+    if nd < n:                                     # frame i of the batch is distinct frame i % nd (said in config.workload)
+        idx = torch.arange(n, device=dev) % nd
+        dframes = dframes[idx].contiguous()
+        cats = [cats[i % nd] for i in range(n)]
     cat = packed = None
     if not lsst and not args.no_removestars:
         packed = synth.pack_catalogs(cats)
@@ -187,7 +224,8 @@ def main():
     def step_host():
         return run(host, None if (lsst or args.no_removestars) else packed)
 
-    step = step_host if args.host_frames else step_dev
+    host_ok = nd == n
+    step = step_host if (args.host_frames and host_ok) else step_dev
 
     def fence():
         torch.cuda.synchronize()
@@ -202,7 +240,7 @@ def main():
     # fully bracketed step AFTER the timed region.
     res = None
     det.enable_timing(not args.no_kernel_timing)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         res = step()
     torch.cuda.synchronize()
     warm = det.get_timing()
@@ -211,7 +249,7 @@ def main():
     det.enable_timing(not args.no_kernel_timing)  # (re-arms and clears the sums)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         res = step()
     fence()
     elapsed = time.perf_counter() - t0
@@ -222,35 +260,52 @@ def main():
     torch.cuda.synchronize()
     table = det.get_timing()
     det.enable_timing(False)
-    host_leg = None
-    if not args.host_frames and not args.no_host_leg:  # secondary: frames handed over as host buffers (PCIe-inclusive; never `value`)
+    cnt = det.get_counters()[:n]  # last pass of every slot: Hough cost is 180 votes per non-zero pixel
+    sustained = None
+    if sustained_s > 0:                           # the same step back to back for >= sustained_s seconds: the clock the chip holds
+        c0 = gpu_clock_mhz(dev_index)
+        fence()
+        t0 = time.perf_counter()
+        m = 0
+        while time.perf_counter() - t0 < sustained_s:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            m += 10
+        dt = time.perf_counter() - t0
+        c1 = gpu_clock_mhz(dev_index)
+        sustained = {"value": round(world * n * m / dt, 2), "unit": "frames/s", "steps": m, "seconds": round(dt, 2),
+                     "ms_per_step": round(1e3 * dt / m, 3), "sclk_mhz_before": c0, "sclk_mhz_after": c1,
+                     "note": "the timed step repeated back to back (this rank); sclk read from pp_dpm_sclk right before / after"}
+    host_res = None
+    if host_leg and host_ok and not args.host_frames and not args.no_host_leg:  # secondary: frames handed over as host buffers (PCIe-inclusive; never `value`)
         step_host()
         fence()
         t0 = time.perf_counter()
-        m = max(1, min(args.steps, 3))
+        m = max(1, min(steps, 3))
         for _ in range(m):
             step_host()
         fence()
-        host_leg = time.perf_counter() - t0
+        host_res = time.perf_counter() - t0
         if use_dist:
-            t = torch.tensor([host_leg], dtype=torch.float64, device=red_dev)
+            t = torch.tensor([host_res], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            host_leg = float(t.item())
-        host_leg = (world * n * m / host_leg, m)
+            host_res = float(t.item())
+        host_res = (world * n * m / host_res, m)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    cnt = det.get_counters()[:n]  # last pass of every slot: Hough cost is 180 votes per non-zero pixel
-    nnz_equ, nnz_box = cnt[:, 15][cnt[:, 8] > 0], cnt[:, 16][cnt[:, 8] > 0]
-    res0 = res[0] if lsst else res       # lsst: [scale, frame]
-    found_b = int((res0["found"] == 1).sum())
-    found_d = int((res0["found"] == 2).sum())
-    errors = int((res["status"] != 0).sum())
-
+    state = {"host": host, "cats": cats, "res": res, "pb": pb, "pd": pd, "prs": prs, "rhos": rhos, "lsst": lsst, "n": n, "nd": nd}
+    out = None
     if rank == 0:
-        total_frames = world * n * args.steps
+        nnz_equ, nnz_box = cnt[:, 15][cnt[:, 8] > 0], cnt[:, 16][cnt[:, 8] > 0]
+        res0 = res[0] if lsst else res       # lsst: [scale, frame]
+        found_b = int((res0["found"] == 1).sum())
+        found_d = int((res0["found"] == 2).sum())
+        errors = int((res["status"] != 0).sum())
+        total_frames = world * n * steps
         value = total_frames / elapsed
         N = h * w
         # dominant kernel by device time inside the timed region
@@ -265,43 +320,68 @@ def main():
         bytes_per_frame = bpp_dom * N
         achieved = (bytes_per_frame * units) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         avg_ms = ms / max(1, launches)
-        traffic, traffic_src = load_traffic(name, (args.workload, n, inflight, args.lanes, [h, w]))
+        traffic, traffic_src = load_traffic(name, (workload, n, inflight, args.lanes, [h, w]))
         kern = {k: {"ms_per_step": round(v[0], 4), "launches_per_step": v[1], "frames_per_step": v[2]}
                 for k, v in table.items() if v[1]}  # one fully bracketed step after the timed region
         # per-stage view of that step: every stage's algorithmic bytes once, over the summed time of its kernels
         stages = {}
         for sname, (bpp, ks) in STAGES.items():
-            t_ms = sum(table[k][0] * share for k, share in ks.items() if k in table and table[k][1])
+            t_ms = sum(table[k][0] * sh for k, sh in ks.items() if k in table and table[k][1])
             if t_ms <= 0:
                 continue
             lead = max((k for k in ks if k in table and table[k][1]), key=lambda k: table[k][0] * ks[k])
             frames_st = table[lead][2]  # (Hough: frames with a rectangle, summed over the launches of every scale)
             gb = (dual_bpp if bpp is None else bpp) * N * frames_st / 1e9
+            frac = gb / (t_ms * 1e-3) / HBM_PEAK_GBPS
             stages[sname] = {"ms_per_step": round(t_ms, 4), "algorithmic_GB": round(gb, 4), "GBps": round(gb / (t_ms * 1e-3), 1),
-                             "frac_of_peak": round(gb / (t_ms * 1e-3) / HBM_PEAK_GBPS, 4)}
+                             "frac_of_peak": round(min(frac, 1.0), 4)}
+            if frac > 1.0:  # the stage's kernels skip empty tiles / bands: the algorithmic bytes were never moved, so this is no bandwidth figure
+                stages[sname]["sparse"] = "algorithmic bytes not moved (activity-driven kernels skip empty regions): uncapped %.2f" % frac
         ch = None
         if "canny" in stages and "hough" in stages:  # what north_star asks for: Canny (2N) + Hough (1N per image) over their kernels
             gb = stages["canny"]["algorithmic_GB"] + stages["hough"]["algorithmic_GB"]
             t_ms = stages["canny"]["ms_per_step"] + stages["hough"]["ms_per_step"]
-            t_lo = t_ms + sum(table[k][0] * 0.55 for k in ("k_dilate_canny",) if k in table)  # the whole fused tile kernel charged to Canny
+            t_lo = t_ms + sum(table[k][0] * DC_DILATE for k in ("k_dilate_canny",) if k in table)  # the whole fused tile kernel charged to Canny
             ch = {"algorithmic_GB": round(gb, 4), "ms_per_step": round(t_ms, 4), "GBps": round(gb / (t_ms * 1e-3), 1),
                   "frac": round(gb / (t_ms * 1e-3) / HBM_PEAK_GBPS, 4),
                   "frac_if_fused_tile_kernel_is_all_canny": round(gb / (t_lo * 1e-3) / HBM_PEAK_GBPS, 4),
+                  "fused_tile_kernel_split": {"dilate": round(DC_DILATE, 3), "canny": round(DC_CANNY, 3), "source": DC_SRC},
                   "target": 0.5}
+        hv = None
+        if "k_hough_vote" in table and table["k_hough_vote"][1]:
+            # SURVEY 8(d)'s secondary bound: 180 votes per non-zero pixel of each image against the LDS-atomic / vector-issue peaks.
+            # The counters hold the LAST pass of every slot, so the votes are priced over the vote launches of that pass only:
+            # scale the time by the share of the launches' frames the counted frames make up.
+            numangle = 180
+            votes = float(numangle) * float(nnz_equ.sum() + nnz_box.sum()) * (len(rhos) if lsst else 1)
+            t_all, _, fr_all = table["k_hough_vote"]
+            per_scale = max(1, len(nnz_equ))
+            t_cnt = t_all * min(1.0, per_scale * (len(rhos) if lsst else 1) / max(1.0, float(fr_all)))
+            if votes > 0 and t_cnt > 0:
+                vps = votes / (t_cnt * 1e-3)
+                hv = {"votes_per_s": float("%.4g" % vps), "votes": int(votes), "ms": round(t_cnt, 4),
+                      "lds_atomic_peak_votes_per_s": LDS_ATOMIC_VOTES_PER_S, "frac_of_lds_atomic_peak": round(vps / LDS_ATOMIC_VOTES_PER_S, 4),
+                      "valu_peak_votes_per_s": VALU_VOTES_PER_S, "frac_of_valu_peak": round(vps / VALU_VOTES_PER_S, 4),
+                      "note": "180 votes per non-zero pixel of equ and box_img (frames whose LAST pass reached HoughLines) over k_hough_vote's "
+                              "time for those frames; peaks: one ds_add per vote at 16 per clock per CU, >= 4 vector lane-operations per vote on "
+                              "4 x SIMD-32 per CU, 256 CUs at 2.4 GHz.  The kernel votes per run of pixels (two adds per run and angle), which is "
+                              "how it can exceed the per-vote LDS bound"}
         if lsst:
             metric = "LSST-scale frames/sec (4096x4096) dim pass, 9x9 erosion, multi-scale Hough"
-            workload = ("configs[4]: dim pass with 9x9 erosion + HoughLines at rho 20/10/5, batch=%d synthetic 4096x4096 float32 frames "
-                        "per GPU, %s" % (n, "HOST-resident (PCIe-inclusive)" if args.host_frames else "device-resident"))
+            workload_s = ("configs[4]: dim pass with 9x9 erosion + HoughLines at rho 20/10/5, batch=%d synthetic 4096x4096 float32 frames "
+                          "per GPU%s, %s" % (n, "" if nd == n else " (%d distinct frames, each %d times)" % (nd, n // nd),
+                                             "HOST-resident (PCIe-inclusive)" if args.host_frames else "device-resident"))
         else:
             metric = "SDSS frames/sec (2048x1489) full detecttrails pipe"
-            workload = ("configs[2]: full removestars+bright+dim pipe, batch=%d synthetic SDSS 2048x1489 float32 frames per GPU, %s"
-                        % (n, "HOST-resident (PCIe-inclusive)" if args.host_frames else "device-resident"))
+            workload_s = ("configs[2]: full removestars+bright+dim pipe, batch=%d synthetic SDSS 2048x1489 float32 frames per GPU%s, %s"
+                          % (n, "" if nd == n else " (%d distinct frames, each %d times)" % (nd, n // nd),
+                             "HOST-resident (PCIe-inclusive)" if args.host_frames else "device-resident"))
         out = {
             "metric": metric, "value": round(value, 2),
-            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload,
+            "config": {"workload": workload_s,
                        "frames_per_gpu": n, "inflight": inflight, "lanes": args.lanes, "shape": [h, w],
                        "removestars": (not lsst) and not args.no_removestars, "parallelism": "frame-parallel x%d" % world + (" (rehearsal: ranks share %d GPU(s), gloo)" % torch.cuda.device_count() if share else ""),
                        "found_bright": found_b, "found_dim": found_d, "frame_errors": errors,
@@ -311,7 +391,9 @@ def main():
                        "workspace_GB": round(det.workspace_bytes() / 1e9, 2), "frames_spilled_to_worst_case_workspace": det.spill_count(),
                        "gen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                         "frac_kind": "ALGORITHMIC bytes (SURVEY 8d) / kernel time / peak -- not HBM utilisation; see measured_traffic_frac",
+                         "traffic": traffic,
                          "traffic_source": traffic_src,
                          "measured_traffic_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if traffic and avg_ms > 0 else None,
                          "frac_of_measured_copy_6290": round(achieved / 6290.0, 5),
@@ -320,54 +402,219 @@ def main():
                          "algorithmic_bytes_per_frame": bytes_per_frame,
                          "algorithmic_bytes_per_px": round(bpp_dom, 3),
                          "canny_hough": ch,
+                         "hough_votes": hv,
                          "note": "algorithmic bytes as SURVEY 8(d) prescribes, each stage charged once across its kernels; "
                                  "measured_traffic_frac = PMC HBM bytes per launch / launch time / peak: a kernel whose measured "
                                  "fraction is far below 1 is limited by vector-unit issue / LDS round trips, not by HBM"},
             "stages": stages,
             "kernels": kern,
         }
-        if host_leg:
-            out["host_resident"] = {"value": round(host_leg[0], 2), "unit": "frames/s", "steps": host_leg[1],
+        if host_res:
+            out["host_resident"] = {"value": round(host_res[0], 2), "unit": "frames/s", "steps": host_res[1],
                                     "note": "same step with the frames handed over as host buffers (PCIe-inclusive); never `value`"}
+        if sustained:
+            out["sustained"] = sustained
+    det.close()
+    del dframes
+    torch.cuda.empty_cache()
+    return out, state
+
+
+def cpu_baseline(state, args, world):
+    """The oracle (kind "port") on a bounded sample of rank 0's frames: one thread, all of the rank's cores; plus the
+    reference's own cv2 call sequence where OpenCV can be imported."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import cv2_path, lfd_oracle as O
+    host, cats, res, pb, pd, prs, rhos, lsst, n = (state[k] for k in ("host", "cats", "res", "pb", "pd", "prs", "rhos", "lsst", "n"))
+    n = min(n, state["nd"])
+    cpu_sample = args.cpu_sample if args.cpu_sample is not None else (2 if lsst else 24)
+    if cpu_sample <= 0:
+        return None
+    rs_o = O.rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
+
+    def cpu_frame(i):
+        if lsst:
+            rec = [O.process_dim(host[i].copy(), dict(pd, houghMethod=r), flip=True) for r in rhos]
+            return all(all(rr[k] == res[s][i][k].item() for k in rr) for s, rr in enumerate(rec))
+        r = O.detect_frame(host[i].copy(), pb, pd, None if args.no_removestars else cats[i], rs_o)
+        return all(r[k] == res[i][k].item() for k in r)
+
+    m = min(cpu_sample, n)
+    t0 = time.perf_counter()
+    agree = sum(cpu_frame(i) for i in range(m))
+    dt = time.perf_counter() - t0
+    cores, avail = host_cores(world)
+    cores = max(1, min(cores, n))
+    what = "3 x process_dim (rho 20/10/5)" if lsst else "detect_frame"
+    out = {"value": round(m / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "first %d frames of rank 0's batch through oracle/ (C, -O2, 1 thread; %s), "
+                     "%d/%d identical to the GPU records" % (m, what, agree, m),
+           "host_cores_available": avail}
+    # all of the rank's cores: one oracle call per thread (ctypes releases the GIL), a bounded sample again
+    per = max(1, int(round(m / dt * 8.0)))               # ~8 s of work per core
+    ma = min(n, cores * per)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        agree_a = sum(ex.map(cpu_frame, range(ma)))
+    dta = time.perf_counter() - t0
+    out["all_cores"] = {"value": round(ma / dta, 3), "unit": "frames/s", "cores": cores,
+                        "sample": "%d frames on %d threads (this rank's share of the host: 1/8 of its cores per GPU), "
+                                  "%d/%d identical to the GPU records" % (ma, cores, agree_a, ma)}
+    # the reference's own OpenCV path (BASELINE.md section 3), where OpenCV exists
+    cv2 = cv2_path.load()
+    if cv2 is None or lsst:
+        out["opencv"] = "unavailable" if cv2 is None else "not timed for this workload"
+        if cv2 is None:
+            out["opencv_note"] = "`import cv2` fails on this host (tried at run time): the reference's OpenCV path cannot be timed; kind stays 'port'"
+    else:
+        from lfd_amd.detecttrails import check_theta
+        mo = min(8, n)
+        t0 = time.perf_counter()
+        same = 0
+        for i in range(mo):
+            found, rho, theta = cv2_path.detect_frame(cv2, host[i].copy(), pb, pd, None if args.no_removestars else cats[i], rs_o,
+                                                      O.remove_stars, check_theta)
+            same += int(found == res[i]["found"].item() and np.float32(rho) == res[i]["rho"] and np.float32(theta) == res[i]["theta"])
+        dto = time.perf_counter() - t0
+        out["opencv"] = {"value": round(mo / dto, 3), "unit": "frames/s", "kind": "reference-equivalent cv2 call sequence (oracle/cv2_path.py)",
+                         "version": cv2.__version__, "threads": int(cv2.getNumThreads()),
+                         "sample": "%d frames, %d/%d with the GPU's (found, rho, theta)" % (mo, same, mo)}
+    return out
+
+
+def dropin_leg(state, args, dev_index):
+    """DetectTrails(run=...).process(batch=256) over a synthetic $BOSS tree in /dev/shm: the drop-in itself, FITS reading
+    included.  Plain .fits for every frame of the batch, then a bounded sample as .fits.bz2; rows compared with the
+    device-resident records."""
+    import shutil
+    import tempfile
+    from lfd_amd import results as results_io, synth
+    from lfd_amd.detecttrails import DetectTrails
+    host, cats, res, n = state["host"], state["cats"], state["res"], min(state["n"], state["nd"])
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    root = tempfile.mkdtemp(prefix="lfd_boss_", dir=base)
+    out = {}
+    old_env = {k: os.environ.get(k) for k in ("BOSS_PHOTOOBJ", "PHOTO_REDUX", "LFD_DEVICE")}
+    try:
+        os.environ["LFD_DEVICE"] = str(dev_index)
+        for label, count, bz in (("plain", n, False), ("bz2", min(n, args.dropin_bz2), True)):
+            if count <= 0:
+                continue
+            tree = os.path.join(root, label)
+            t0 = time.perf_counter()
+            hdr = synth.write_boss_tree(tree, host[:count], cats[:count], run=94, camcol=1, filter="r", field0=100, bz2_all=bz)
+            t_write = time.perf_counter() - t0
+            save = os.path.join(tree, "out")
+            os.makedirs(save)
+            dt = DetectTrails(run=94, camcol=1, filter="r", savepath=save)
+            if label == "plain":                   # (page cache / context warm-up on a few frames, untimed)
+                DetectTrails(run=94, camcol=1, filter="r", field=100, savepath=os.path.join(tree, "warm") if os.makedirs(os.path.join(tree, "warm")) is None else None).process(batch=1)
+            t0 = time.perf_counter()
+            dt.process(batch=256)
+            el = time.perf_counter() - t0
+            rows = [ln.strip() for ln in open(dt.results) if ln.strip()]
+            want = [results_io.format_result_row(94, 1, "r", 100 + i, hdr, res[i]) for i in range(count) if res[i]["found"]]
+            errs = open(dt.errors).read().count("\n\n")
+            out[label] = {"value": round(count / el, 1), "unit": "frames/s", "frames": count, "seconds": round(el, 3),
+                          "rows": len(rows), "rows_equal_device_resident_run": rows == want, "errors_logged": errs,
+                          "tree_write_s": round(t_write, 1)}
+            shutil.rmtree(tree, ignore_errors=True)
+    finally:
+        for k, v in old_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        shutil.rmtree(root, ignore_errors=True)
+    out["note"] = ("DetectTrails(run=94, camcol=1, filter='r').process(batch=256): frame FITS + photoObj FITS read from /dev/shm by the "
+                   "loader pool straight into pinned staging memory, big-endian floats swapped on the device; never `value`")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=("sdss", "lsst"), default="sdss")
+    ap.add_argument("--frames-per-gpu", type=int, default=None, help="default 256 (configs[2]: 256 per GPU; configs[4]: 2048 over 8 GPUs)")
+    ap.add_argument("--inflight", type=int, default=None, help="frames per launch (default: the whole batch)")
+    ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches (streams) per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="frames timed through the CPU oracle on one thread (0 = skip)")
+    ap.add_argument("--gen-workers", type=int, default=-1)
+    ap.add_argument("--no-removestars", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="developer: leave the per-launch HIP events off (no roofline entry) to see what they cost")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="developer: time ONLY the host-resident (PCIe-inclusive) path as the headline value of this run")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the secondary PCIe-inclusive measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the sustained / dropin / lsst legs of the default invocation (profiling runs)")
+    ap.add_argument("--sustained-s", type=float, default=3.0)
+    ap.add_argument("--dropin-bz2", type=int, default=32, help="frames of the .bz2 sample of the dropin leg (0 = skip)")
+    ap.add_argument("--lsst-distinct", type=int, default=64, help="distinct frames of the secondary lsst leg (each used 256 / this times)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    # One rank per GPU.  Rehearsal on a box with fewer GPUs than ranks (LFD_BENCH_SHARE_GPU=1): ranks share devices round-robin
+    # and synchronise over gloo (RCCL refuses two ranks on one device) -- the sharding, timing and reduction code is the same.
+    share = os.environ.get("LFD_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    use_dist = world > 1 or os.environ.get("LFD_BENCH_FORCE_DIST") == "1"  # the env switch lets a 1-GPU box rehearse the RCCL path
+    red_dev = torch.device("cpu") if share else dev
+    ranks_seen = None
+    if use_dist:
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+        # every rank reports (rank, device it runs on): rank 0 prints what the collective backend really connected
+        mine = torch.tensor([rank, dev_index, torch.cuda.device_count()], dtype=torch.int64, device=red_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        seen = [tuple(int(x) for x in t.cpu()) for t in allr]
+        ranks_seen = {"backend": dist.get_backend(), "world_size": world, "ranks": sorted(s[0] for s in seen),
+                      "devices": [s[1] for s in sorted(seen)], "visible_devices_per_rank": sorted({s[2] for s in seen})}
+    env = {"rank": rank, "world": world, "dev": dev, "dev_index": dev_index, "use_dist": use_dist, "red_dev": red_dev, "share": share}
+
+    n = args.frames_per_gpu or 256
+    primary = world == 1 and args.workload == "sdss" and not args.host_frames and not args.no_secondary
+    out, state = measure(args, args.workload, n, args.steps, args.warmup, env,
+                         sustained_s=args.sustained_s if primary else 0.0)
+    if rank == 0:
+        if ranks_seen:
+            out["rccl_ranks_seen" if ranks_seen["backend"] == "nccl" else "ranks_seen"] = ranks_seen
         if world > 1:
             out["cpu_baseline"] = None  # (the host baseline is timed at N = 1 only: rank 0 would keep the other ranks waiting)
-        elif cpu_sample > 0:
-            from concurrent.futures import ThreadPoolExecutor
-            from oracle import lfd_oracle as O
-            rs_o = O.rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
-
-            def cpu_frame(i):
-                if lsst:
-                    rec = [O.process_dim(host[i].copy(), dict(pd, houghMethod=r), flip=True) for r in rhos]
-                    return all(all(rr[k] == res[s][i][k].item() for k in rr) for s, rr in enumerate(rec))
-                r = O.detect_frame(host[i].copy(), pb, pd, None if args.no_removestars else cats[i], rs_o)
-                return all(r[k] == res[i][k].item() for k in r)
-
-            m = min(cpu_sample, n)
-            t0 = time.perf_counter()
-            agree = sum(cpu_frame(i) for i in range(m))
-            dt = time.perf_counter() - t0
+        else:
+            out["cpu_baseline"] = cpu_baseline(state, args, world)
+        if primary:
             try:
-                avail = len(os.sched_getaffinity(0))
-            except (AttributeError, OSError):
-                avail = os.cpu_count() or 1
-            cores = max(1, min(avail, 16 * max(1, world), n))     # this process's share of the host (16 cores per GPU on the pool)
-            what = "3 x process_dim (rho 20/10/5)" if lsst else "detect_frame"
-            out["cpu_baseline"] = {"value": round(m / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": "first %d frames of rank 0's batch through oracle/ (C, -O2, 1 thread; %s), "
-                                             "%d/%d identical to the GPU records" % (m, what, agree, m),
-                                   "host_cores_available": avail}
-            # all host cores: one oracle call per thread (ctypes releases the GIL), a bounded sample again
-            per = max(1, int(round(m / dt * 12.0)))               # ~12 s of work per core
-            ma = min(n, cores * per)
-            t0 = time.perf_counter()
-            with ThreadPoolExecutor(cores) as ex:
-                agree_a = sum(ex.map(cpu_frame, range(ma)))
-            dta = time.perf_counter() - t0
-            out["cpu_baseline"]["all_cores"] = {"value": round(ma / dta, 3), "unit": "frames/s", "cores": cores,
-                                                "sample": "%d frames on %d threads, %d/%d identical to the GPU records" % (ma, cores, agree_a, ma)}
+                out["dropin"] = dropin_leg(state, args, dev_index)
+            except Exception as e:  # noqa: BLE001 - a secondary leg must not cost the headline line
+                out["dropin"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            del state
+            try:
+                a2 = argparse.Namespace(**vars(args))
+                a2.inflight = None
+                a2.cpu_sample = 0
+                nl = 256
+                sec, _ = measure(a2, "lsst", nl, max(1, min(args.steps, 5)), 1, env, distinct=max(1, min(nl, args.lsst_distinct)), host_leg=False)
+                out["lsst"] = {k: sec[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "stages", "kernels")}
+            except Exception as e:  # noqa: BLE001
+                out["lsst"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
-    det.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LFDMI_VERSION 201
+#define LFDMI_VERSION 300
 
 enum lfdmi_status {
     LFDMI_OK = 0,
@@ -251,6 +251,10 @@ const char *lfdmi_timing_name(int slot);
 /* developer tool (LFDMI_FRAME_PROFILE=1 in the environment when the context is created): per-phase clocks
  * (8 x int64 per slot, 10 ns ticks) of the last per-frame contour kernel launch, slots 0 .. n-1 */
 int lfdmi_debug_frame_profile(lfdmi_ctx *ctx, int n, long long *dst);
+/* developer hook for tests of the error path: the NEXT lfdmi_detect_batch call on this context returns LFDMI_ERR_ARG at the
+ * top of its chunk number `chunk` (0-based; a chunk is the feed's unit for host frames, max_inflight frames otherwise),
+ * after the earlier chunks ran normally; -1 disarms.  The context stays usable. */
+int lfdmi_debug_fail_chunk(lfdmi_ctx *ctx, int chunk);
 /* developer check: the device's float32 results of the three libm calls on minAreaRect's accept / reject path (angle in
  * degrees of atan2(y, x) as cv::minAreaRect rounds it; cos / sin of that angle times 0.5 as RotatedRect::points does), for
  * n host operand pairs -- compared with the host libm by tests/test_gpu_stages.py */

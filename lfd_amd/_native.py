@@ -27,7 +27,7 @@ ERR_ARG, ERR_DTYPE, ERR_HIP, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_NOLINES = -1, -2
 # every symbol include/lfdmi.h declares (checked by the CPU test-suite)
 SYMBOLS = (
     "lfdmi_version", "lfdmi_default_caps", "lfdmi_ctx_create", "lfdmi_ctx_create_sized", "lfdmi_ctx_bytes", "lfdmi_spill_count",
-    "lfdmi_ctx_destroy", "lfdmi_last_error", "lfdmi_set_stream", "lfdmi_process_multiscale", "lfdmi_debug_frame_profile", "lfdmi_debug_trig",
+    "lfdmi_ctx_destroy", "lfdmi_last_error", "lfdmi_set_stream", "lfdmi_process_multiscale", "lfdmi_debug_frame_profile", "lfdmi_debug_trig", "lfdmi_debug_fail_chunk",
     "lfdmi_max_inflight", "lfdmi_prep_u8", "lfdmi_equalize_hist", "lfdmi_dilate", "lfdmi_erode",
     "lfdmi_canny", "lfdmi_gaussian_blur", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
     "lfdmi_hough_dims", "lfdmi_remove_stars", "lfdmi_process_bright", "lfdmi_process_dim",
@@ -232,6 +232,10 @@ class Context:
         out = [np.zeros(n, np.float32) for _ in range(3)]
         self._chk(self._lib.lfdmi_debug_trig(self._h, n, _ptr(y), _ptr(x), *[_ptr(o) for o in out]))
         return out
+
+    def debug_fail_chunk(self, chunk):
+        """Developer hook: the next detect_batch fails (ERR_ARG) at the top of chunk ``chunk`` (tests of the error path)."""
+        self._chk(self._lib.lfdmi_debug_fail_chunk(self._h, int(chunk)))
 
     def set_stage_images(self, mode):
         """Which calls keep the 8-bit stage images for get_stage: -1 the per-pass calls do and detect_batch does not

@@ -9,9 +9,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <time.h>
+#include <pthread.h>
+#include <sched.h>
 #include <string.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <string>
 #include <thread>
 #include <mutex>
@@ -120,6 +123,8 @@ struct lfdmi_ctx {
     hipEvent_t feed_up[2] = {nullptr, nullptr};
     int feed_threads = 4;              // host threads copying a chunk into the pinned buffer (LFDMI_FEED_THREADS)
     size_t feed_chunk_bytes = 800u << 20; // largest feed chunk (LFDMI_FEED_MB): 64 SDSS frames, 11 frames of 4096 x 4096
+    std::vector<int> feed_cpus;        // CPUs local to the GPU (numa_cpus): feed / blot threads and the pinned buffers are bound to them
+    int fail_chunk = -1;               // lfdmi_debug_fail_chunk: the next lfdmi_detect_batch call fails at the top of this chunk (tests)
     int4 *rs_boxes = nullptr;          // remove_stars squares of the chunk (host-frame path)
     size_t rs_boxes_cap = 0;
     void *stage = nullptr;
@@ -150,6 +155,8 @@ struct lfdmi_ctx {
     int stage_mode = -1;               // lfdmi_set_stage_images: -1 the per-pass entry points keep the 8-bit stage images, lfdmi_detect_batch
                                        // does not; 0 never; 1 always
     bool stages_valid = false;         // the last call kept them (lfdmi_get_stage)
+    bool eroded_valid = false;         // the last dim front end wrote its whole eroded plane (LFDMI_STAGE_ERODED readable even without
+                                       // the other stage images: the parity tests of lfdmi_detect_batch's bit-plane front end)
     int vote_split = 4;                // pieces a frame's Hough list is cut into at most
     int pe_rows = 12;                  // rows per band of k_prep_erode
     bool fuse_prep_erode = true;       // dim pass: prep + histogram + erosion in one kernel (LFDMI_FUSE_PREP_ERODE=0: separate)
@@ -510,9 +517,10 @@ extern "C" const char *lfdmi_timing_name(int i) { return (i >= 0 && i < TG_COUNT
 static int check_shape(lfdmi_ctx *ctx, int n, int h, int w) {
     if (!ctx) return LFDMI_ERR_ARG;
     if (n < 0 || h <= 0 || w <= 0) return fail(ctx, LFDMI_ERR_ARG, "bad shape");
-    if ((size_t)h * w > ctx->N || h > 8191 || w > 8191 || LFD_WQ(w) * (size_t)h > (size_t)ctx->wq * ctx->H ||
-        (LFD_WQ(w) * (size_t)h + 63) / 64 > SCAN_MAX_SEG)
-        return fail(ctx, LFDMI_ERR_CAPACITY, "frame larger than the context was created for");
+    // both sides, not only the area: the band / tile tables (cellbm, candmask, fullbits, tile_list) are sized by max_h and
+    // max_w separately, so a taller-but-narrower frame of the same area would index past them
+    if (h > ctx->H || w > ctx->W || h > 8191 || w > 8191 || (LFD_WQ(w) * (size_t)h + 63) / 64 > SCAN_MAX_SEG)
+        return fail(ctx, LFDMI_ERR_CAPACITY, "frame larger than the context was created for (height and width must both fit)");
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, LFDMI_ERR_HIP, "hipSetDevice");
     (void)hipGetLastError(); // a failed earlier call must not poison this one
     ctx->last_h = h; ctx->last_w = w;
@@ -1138,6 +1146,7 @@ static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, 
                      const lfdmi_params *p, const int *active, const lfdmi_params *dual_dim = nullptr) {
     const uint8_t *dil_src = ctx->gray;
     const u64 *bm = ctx->cellbm;
+    ctx->eroded_valid = dim;
     if (dim && ctx->delta_state == 2) {
         // the bright pass left this pass's values (gray + one bit per pixel) and their histogram: no second sweep over the floats
         HIPCHK(hipMemsetAsync(ctx->zero_block + ctx->zero_counters_off, 0, ctx->zero_bytes - ctx->zero_counters_off, ctx->stream));
@@ -1181,6 +1190,7 @@ static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, 
                                     (w + CANNY_TW - 1) / CANNY_TW <= 128 && (h + DCW_TH - 1) / DCW_TH <= DCT_MAXBANDS; // (the tile-list path)
             RET(run_morph(ctx, ctx->gray, ctx->tmp, nullptr, nullptr, p->erodeKernel, p->erode_kh, p->erode_kw, 1, nc, h, w, active,
                           wide ? ctx->fullbits : nullptr, ctx->cellbm2, &marked, only_tiles));
+            if (only_tiles) ctx->eroded_valid = false; // (zero-filled only where the tile kernel reads it)
             dil_src = ctx->tmp;
             if (marked) bm = ctx->cellbm2;
         }
@@ -1537,9 +1547,12 @@ static int run_removestars(lfdmi_ctx *ctx, float *frames_dev, int f0, int nc, in
 // remove_stars on the caller's HOST frames: the squares the device computed (and zero-filled in its copy) are
 // zero-filled in the caller's array by host threads, while the GPU runs the rest of the pipe -- the blotted
 // frames are not copied back (24.4 MB over PCIe per frame instead of 12.2 MB halves the host-fed rate)
-static void blot_host_frames(float *frames, int nc, int h, int w, const lfdmi_catalog *cat, int f0, const std::vector<int4> &boxes) {
+static void bind_thread(const std::vector<int> &cpus);
+static void blot_host_frames(float *frames, int nc, int h, int w, const lfdmi_catalog *cat, int f0, const std::vector<int4> &boxes,
+                             const std::vector<int> &cpus) {
     size_t N = (size_t)h * w;
     auto work = [&](int a, int b) {
+        bind_thread(cpus);
         for (int f = a; f < b; f++) {
             int n_obj = cat->count[f0 + f];
             float *img = frames + (size_t)f * N;
@@ -1708,45 +1721,100 @@ extern "C" int lfdmi_process_multiscale(lfdmi_ctx *ctx, const void *img, int dty
 // synchronously); pinning the caller's array costs 40 ms per GB.  So the library stages itself: `feed_threads` host
 // threads copy chunk k+1 of the caller's frames into a pinned buffer (~100 GB/s with 8 threads) while the DMA engine
 // moves chunk k (57 GB/s, the link's rate) and the GPU processes chunk k-1: the frames cross PCIe once, back to back.
+// One feeder thread per call walks the chunks IN ORDER: host threads copy a piece (32 MB) of the caller's frames into the
+// pinned buffer of the chunk's slot, the piece is sent on its way at once (copy stream), and after the chunk's last piece an
+// event is recorded.  The DMA engine therefore starts after the first piece (< 1 ms) and never sees two chunks interleaved.
+// Chunk j reuses the buffers of chunk j - 2: the feeder waits until the main thread has finished that chunk (`done`).
+// All waiting is on one condition variable (no spinning: eight ranks on one host would burn 40 cores), the workers look at
+// `stop` before every piece, and the first HIP error of an upload ends the feed and is handed to the caller by feed_wait.
+#define FEED_PIECE (32u << 20)
+struct FeedState {
+    std::mutex mu;
+    std::condition_variable cv;
+    int issued = 0, done = 0;          // chunks whose upload has been enqueued / that the main thread has finished (guarded by mu)
+    bool stop = false;
+    hipError_t err = hipSuccess;       // first failure of an upload
+    std::thread th;
+};
+
+// CPUs next to the GPU (its PCI function's local_cpulist) that this process may run on; empty when unknown or LFDMI_NUMA_PIN=0.
+// Feed / blot threads and the pinned staging buffers are bound to them: with one rank per GPU on a two-socket host a rank's
+// 50 GB/s of staging copies otherwise cross the socket link at the scheduler's whim.
+static std::vector<int> numa_cpus(int device) {
+    std::vector<int> out;
+    if (const char *e = getenv("LFDMI_NUMA_PIN")) if (!atoi(e)) return out;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return out;
+    for (char *c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return out;
+    char line[4096] = {0};
+    const bool got = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    if (!got) return out;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
+    for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) { // "0-15,128-143"
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k < 1) continue;
+        if (k == 1) b = a;
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++) if (c >= 0 && CPU_ISSET(c, &allowed)) out.push_back(c);
+    }
+    return out;
+}
+static void bind_thread(const std::vector<int> &cpus) { // the calling thread; no-op for an empty list
+    if (cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus) CPU_SET(c, &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+}
+
 static int feed_prepare(lfdmi_ctx *ctx, size_t bytes) {
     if (!ctx->feed_copy) {
         HIPCHK(hipStreamCreateWithFlags(&ctx->feed_copy, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&ctx->feed_copy2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&ctx->feed_mid, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&ctx->feed_up[i], hipEventDisableTiming));
+        ctx->feed_cpus = numa_cpus(ctx->device);
     }
     if (ctx->feed_bytes >= bytes) return 0;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->feed_copy));
+    HIPCHK(hipStreamSynchronize(ctx->feed_copy2));
     for (int i = 0; i < 2; i++) {
         if (ctx->feed_pin[i]) { HIPCHK(hipHostFree(ctx->feed_pin[i])); ctx->feed_pin[i] = nullptr; }
         if (ctx->feed_dev[i]) { HIPCHK(hipFree(ctx->feed_dev[i])); ctx->feed_dev[i] = nullptr; }
     }
     ctx->feed_bytes = 0;
-    for (int i = 0; i < 2; i++) {
-        HIPCHK(hipHostMalloc(&ctx->feed_pin[i], bytes, hipHostMallocDefault));
-        HIPCHK(hipMalloc(&ctx->feed_dev[i], bytes));
-    }
+    // the pinned buffers are allocated (and first touched) by a thread bound to the GPU's CPUs: their pages land on that node
+    hipError_t herr = hipSuccess;
+    std::thread alloc([&] {
+        bind_thread(ctx->feed_cpus);
+        herr = hipSetDevice(ctx->device);
+        for (int i = 0; i < 2 && herr == hipSuccess; i++) {
+            herr = hipHostMalloc(&ctx->feed_pin[i], bytes, hipHostMallocDefault);
+            if (herr == hipSuccess && !ctx->feed_cpus.empty())
+                for (size_t o = 0; o < bytes; o += 4096) ((volatile char *)ctx->feed_pin[i])[o] = 0;
+        }
+    });
+    alloc.join();
+    HIPCHK(herr);
+    for (int i = 0; i < 2; i++) HIPCHK(hipMalloc(&ctx->feed_dev[i], bytes));
     ctx->feed_bytes = bytes;
     return 0;
 }
 
-// One feeder thread per call walks the chunks IN ORDER: host threads copy a piece (32 MB) of the caller's frames into the
-// pinned buffer of the chunk's slot, the piece is sent on its way at once (copy stream), and after the chunk's last piece an
-// event is recorded.  The DMA engine therefore starts after the first piece (< 1 ms) and never sees two chunks interleaved.
-// Chunk j reuses the buffers of chunk j - 2: the feeder waits until the main thread has finished that chunk (`done`).
-#define FEED_PIECE (32u << 20)
-struct FeedState {
-    std::atomic<int> issued{0}, done{0};
-    std::atomic<bool> stop{false};
-    std::thread th;
-};
 static void feed_start(lfdmi_ctx *ctx, FeedState *fs, const char *src, size_t frame_bytes, int n, int per) {
     char *pin[2] = {(char *)ctx->feed_pin[0], (char *)ctx->feed_pin[1]}, *dev[2] = {(char *)ctx->feed_dev[0], (char *)ctx->feed_dev[1]};
     hipEvent_t up[2] = {ctx->feed_up[0], ctx->feed_up[1]};
     const int T = ctx->feed_threads, device = ctx->device;
     hipStream_t copy = ctx->feed_copy, copy2 = ctx->feed_streams == 2 ? ctx->feed_copy2 : ctx->feed_copy;
     hipEvent_t mid = ctx->feed_mid;
+    const std::vector<int> cpus = ctx->feed_cpus;
     fs->th = std::thread([=] {
         // The call's pieces in order; T workers (this thread is one of them) live for the whole call and copy their slice
         // of every piece (threads started per piece cost as much as the copy itself); whoever completes a piece sends it
@@ -1764,32 +1832,50 @@ static void feed_start(lfdmi_ctx *ctx, FeedState *fs, const char *src, size_t fr
         const int P = (int)pieces.size();
         std::unique_ptr<std::atomic<int>[]> copied(new std::atomic<int>[P]);
         for (int k = 0; k < P; k++) copied[k].store(0);
-        std::mutex mu;
-        int next_issue = 0;
+        int next_issue = 0; // (guarded by fs->mu)
         auto worker = [&](int t) {
-            hipSetDevice(device);
+            bind_thread(cpus);
+            if (hipSetDevice(device) != hipSuccess) {
+                std::lock_guard<std::mutex> lk(fs->mu);
+                if (fs->err == hipSuccess) fs->err = hipErrorInvalidDevice;
+                fs->stop = true;
+                fs->cv.notify_all();
+                return;
+            }
             for (int k = 0; k < P; k++) {
                 const Piece &pc = pieces[k];
-                while (fs->done.load(std::memory_order_acquire) < pc.chunk - 1) { // buffers of chunk j - 2 still in use
-                    if (fs->stop.load()) return;
-                    std::this_thread::yield();
+                {   // buffers of chunk j - 2 still in use?  `stop` is looked at before every piece, not only while waiting
+                    std::unique_lock<std::mutex> lk(fs->mu);
+                    fs->cv.wait(lk, [&] { return fs->stop || fs->done >= pc.chunk - 1; });
+                    if (fs->stop) return;
                 }
                 const int slot = pc.chunk & 1;
                 const size_t a = (pc.bytes * t / T) & ~(size_t)63, b = t == T - 1 ? pc.bytes : ((pc.bytes * (t + 1) / T) & ~(size_t)63);
                 if (b > a) memcpy(pin[slot] + pc.off + a, src + pc.src_off + pc.off + a, b - a);
                 if (copied[k].fetch_add(1, std::memory_order_acq_rel) + 1 == T) {
-                    std::lock_guard<std::mutex> lk(mu);
-                    while (next_issue < P && copied[next_issue].load(std::memory_order_acquire) == T) {
+                    std::lock_guard<std::mutex> lk(fs->mu);
+                    bool published = false;
+                    while (!fs->stop && next_issue < P && copied[next_issue].load(std::memory_order_acquire) == T) {
                         const Piece &q = pieces[next_issue];
                         const int qs = q.chunk & 1;
-                        hipMemcpyAsync(dev[qs] + q.off, pin[qs] + q.off, q.bytes, hipMemcpyHostToDevice, (next_issue & 1) ? copy2 : copy);
-                        if (q.last) {
-                            if (copy2 != copy) { hipEventRecord(mid, copy2); hipStreamWaitEvent(copy, mid, 0); }
-                            hipEventRecord(up[qs], copy);
-                            fs->issued.store(q.chunk + 1, std::memory_order_release);
+                        hipError_t e = hipMemcpyAsync(dev[qs] + q.off, pin[qs] + q.off, q.bytes, hipMemcpyHostToDevice, (next_issue & 1) ? copy2 : copy);
+                        if (e == hipSuccess && q.last) {
+                            if (copy2 != copy) {
+                                e = hipEventRecord(mid, copy2);
+                                if (e == hipSuccess) e = hipStreamWaitEvent(copy, mid, 0);
+                            }
+                            if (e == hipSuccess) e = hipEventRecord(up[qs], copy);
+                            if (e == hipSuccess) { fs->issued = q.chunk + 1; published = true; }
+                        }
+                        if (e != hipSuccess) { // the caller gets LFDMI_ERR_HIP from feed_wait; nothing further is uploaded
+                            fs->err = e;
+                            fs->stop = true;
+                            published = true;
+                            break;
                         }
                         next_issue++;
                     }
+                    if (published) fs->cv.notify_all();
                 }
             }
         };
@@ -1807,9 +1893,21 @@ static double feed_now() {
 }
 // the launch stream waits for chunk j's upload
 static int feed_wait(lfdmi_ctx *ctx, FeedState *fs, int j) {
-    while (fs->issued.load(std::memory_order_acquire) <= j) std::this_thread::yield();
+    {
+        std::unique_lock<std::mutex> lk(fs->mu);
+        fs->cv.wait(lk, [&] { return fs->issued > j || fs->stop; });
+        if (fs->issued <= j) {
+            const hipError_t e = fs->err;
+            return fail(ctx, LFDMI_ERR_HIP, std::string("host-frame feed: ") + (e != hipSuccess ? hipGetErrorString(e) : "stopped"));
+        }
+    }
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->feed_up[j & 1], 0));
     return 0;
+}
+static void feed_done(FeedState *fs, int chunks_done) { // chunk (chunks_done - 1)'s buffers are free again
+    std::lock_guard<std::mutex> lk(fs->mu);
+    fs->done = chunks_done;
+    fs->cv.notify_all();
 }
 
 extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w, const lfdmi_catalog *cat,
@@ -1845,12 +1943,23 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
     }
     FeedState fs;
     std::thread blotter; // remove_stars on the caller's host array (see blot_host_frames)
-    struct FeedJoin { FeedState *f; std::thread *b; ~FeedJoin() { f->stop.store(true); f->done.store(1 << 30); if (f->th.joinable()) f->th.join(); if (b->joinable()) b->join(); } }
-        feed_join{&fs, &blotter}; // (every exit path)
+    struct FeedJoin { // every exit path: the feeder stops before its next piece, uploads still in flight are drained (they read the
+                      // pinned buffers the next call refills), the blotter is joined
+        lfdmi_ctx *c; FeedState *f; std::thread *b; bool feed;
+        ~FeedJoin() {
+            { std::lock_guard<std::mutex> lk(f->mu); f->stop = true; f->cv.notify_all(); }
+            if (f->th.joinable()) f->th.join();
+            if (feed) { (void)hipStreamSynchronize(c->feed_copy); (void)hipStreamSynchronize(c->feed_copy2); }
+            if (b->joinable()) b->join();
+        }
+    } feed_join{ctx, &fs, &blotter, feed};
     if (feed) feed_start(ctx, &fs, (const char *)frames, N * 4, n, per);
+    const int fail_chunk = ctx->fail_chunk;
+    ctx->fail_chunk = -1;
     for (int c0 = 0, kc = 0; c0 < n; c0 += per, kc++) {
         int nc = n - c0 < per ? n - c0 : per;
         const void *d;
+        if (kc == fail_chunk) return fail(ctx, LFDMI_ERR_ARG, "lfdmi_debug_fail_chunk: injected failure");
         if (feed) {
             d = ctx->feed_dev[kc & 1];
             RET(feed_wait(ctx, &fs, kc)); // the launch stream waits for chunk kc's upload (chunk kc + 1 follows it back to back)
@@ -1877,7 +1986,10 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
         // (dim value = bright value + bit, for 0 <= addFlux <= 1 and minFlux <= 0.5) together with that image's histogram
         // (small erosion kernels only: k_bits_erode fetches kh x kw values per surviving pixel, which is nothing on sky frames but
         // would be slow on a dense image with a large kernel; those keep the band kernel)
-        const bool delta = !dual && ctx->delta_dim && (w % 32) == 0 && dim->addFlux >= 0.0 && dim->addFlux <= 1.0 && dim->minFlux <= 0.5 &&
+        // (addFlux must stay clear of 1: x = 0.5 gives bright rne(0.5) = 0 but dim rne(1.5) = 2, and an addFlux within half an ulp
+        // of 1 rounds x + addFlux up to the same tie; up to 0.999 the float sum of an even k + 0.5 < 256 stays below k + 1.5)
+        const bool delta = !dual && ctx->delta_dim && (w % 32) == 0 && (float)dim->addFlux >= 0.0f && (float)dim->addFlux <= 0.999f &&
+                           (float)dim->minFlux <= 0.5f &&
                            dim->erode_kh * dim->erode_kw <= 25 &&
                            can_fuse_prep_erode(ctx, LFDMI_F32, w, dim->erodeKernel, dim->erode_kh, dim->erode_kw);
         struct DeltaState { lfdmi_ctx *c; ~DeltaState() { c->delta_state = 0; } } delta_guard{ctx};
@@ -1894,7 +2006,7 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
         ctx->delta_state = 0;
         if (host_blot && !blotted) { // host threads zero-fill the caller's frames in the background (joined below / at the end)
             if (blotter.joinable()) blotter.join();
-            blotter = std::thread([=, bx = boxes] { blot_host_frames(frames + (size_t)c0 * N, nc, h, w, cat, c0, bx); });
+            blotter = std::thread([=, bx = boxes, cpus = ctx->feed_cpus] { blot_host_frames(frames + (size_t)c0 * N, nc, h, w, cat, c0, bx, cpus); });
             blotted = true;
         }
         HIPCHK(hipMemcpyAsync(host.data(), ctx->res_dev, (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
@@ -1909,7 +2021,7 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
             for (int i = 0; i < nc; i++) { nd[0] += flags[i] & 1; na[1] += (flags[i] >> 1) & 1; nd[1] += (flags[i] >> 2) & 1; }
             RET(sync(ctx, nc, na, nd));
         }
-        if (feed) fs.done.store(kc + 1, std::memory_order_release); // this chunk's two buffers are free again: chunk kc + 2 may start
+        if (feed) feed_done(&fs, kc + 1); // this chunk's two buffers are free again: chunk kc + 2 may start
         for (int i = 0; i < nc; i++) {
             if (host[i].status == LFDMI_ERR_CAPACITY) {
                 // a table of this workspace was too small for the frame: once more, alone, in the worst-case workspace.
@@ -1939,7 +2051,15 @@ extern "C" int lfdmi_get_counters(lfdmi_ctx *ctx, int slot0, int n, int32_t *dst
     return 0;
 }
 
-// developer tool, not part of include/lfdmi.h: phase clocks of the last k_frame_contours launch
+// developer hook (tests of the error path): the next lfdmi_detect_batch call on this context returns LFDMI_ERR_ARG at the top
+// of chunk `chunk` (chunks are feed-sized for host frames, max_inflight frames otherwise); -1 disarms
+extern "C" int lfdmi_debug_fail_chunk(lfdmi_ctx *ctx, int chunk) {
+    if (!ctx) return LFDMI_ERR_ARG;
+    ctx->fail_chunk = chunk;
+    return 0;
+}
+
+// developer tool: phase clocks of the last k_frame_contours launch
 extern "C" int lfdmi_debug_frame_profile(lfdmi_ctx *ctx, int n, long long *dst) {
     if (!ctx || !ctx->prof || n < 0 || n > ctx->G) return LFDMI_ERR_ARG;
     HIPCHK(hipMemcpyAsync(dst, ctx->prof, (size_t)n * 8 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -1978,7 +2098,7 @@ extern "C" int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, int h, int w
     size_t N = (size_t)h * w, BW = (size_t)h * LFD_WQ(w);
     HIPCHK(hipSetDevice(ctx->device));
     const uint8_t *src = nullptr;
-    if (which != LFDMI_STAGE_CANNY && which != LFDMI_STAGE_BOX && !ctx->stages_valid)
+    if (which != LFDMI_STAGE_CANNY && which != LFDMI_STAGE_BOX && !ctx->stages_valid && !(which == LFDMI_STAGE_ERODED && ctx->eroded_valid))
         return fail(ctx, LFDMI_ERR_ARG, "lfdmi_get_stage: the last call did not keep the 8-bit stage images (lfdmi_set_stage_images)");
     if (which == LFDMI_STAGE_GRAY) src = ctx->gray + slot * N;
     else if (which == LFDMI_STAGE_EQU) src = ctx->equ + slot * N;

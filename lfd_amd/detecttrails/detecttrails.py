@@ -20,7 +20,7 @@ import numpy as _np
 
 from .. import _native
 from . import fitslite, sdssfiles
-from .processfield import get_context, setup_debug, check_theta, dictify_hough  # noqa: F401
+from .processfield import get_context, use_context, setup_debug, check_theta, dictify_hough  # noqa: F401
 from .removestars import read_photoObj_arrays
 
 # values of the cv2 constants the reference re-exports (detecttrails.py:14-18)
@@ -60,7 +60,6 @@ def process_frame_arrays(img, cat, filter, params_bright, params_dim, params_rem
     """
     if img.dtype != _np.float32 or not img.flags.c_contiguous:
         raise TypeError("process_frame_arrays needs a C-contiguous float32 frame")
-    ctx = get_context(*img.shape)
     packed = rs = None
     if cat is not None and len(cat["NOBSERVE"]):
         from .removestars import _check_finite
@@ -72,7 +71,8 @@ def process_frame_arrays(img, cat, filter, params_bright, params_dim, params_rem
         for key in ("NOBSERVE", "NDETECT"):
             packed[key] = _np.ascontiguousarray(cat[key], _np.int32).reshape(1, n)
         rs = _rs_struct(filter, params_removestars)
-    rec = ctx.detect_batch(img, params_bright, params_dim, packed, rs)[0]
+    with use_context(*img.shape) as ctx:
+        rec = ctx.detect_batch(img, params_bright, params_dim, packed, rs)[0]
     status = int(rec["status"])
     if status == _native.ERR_NOLINES:
         raise TypeError("'NoneType' object is not subscriptable")  # HoughLines gave None
@@ -148,13 +148,13 @@ def process_fields_batched(results, errors, ids, params_bright, params_dim, para
             rows[key] = e
             continue
         groups.setdefault((key[2], img.shape), []).append(item)
-    from .. import synth
+    from ..catalogs import pack_catalogs
     for (flt, shape), group in groups.items():
         try:
             frames = _np.stack([it[1] for it in group])
-            packed = synth.pack_catalogs([it[3] for it in group])
-            ctx = get_context(*shape, inflight=min(32, len(group)))
-            recs = ctx.detect_batch(frames, params_bright, params_dim, packed, _rs_struct(flt, params_removestars))
+            packed = pack_catalogs([it[3] for it in group])
+            with use_context(*shape, inflight=min(32, len(group))) as ctx:
+                recs = ctx.detect_batch(frames, params_bright, params_dim, packed, _rs_struct(flt, params_removestars))
             for it, rec in zip(group, recs):
                 rows[it[0]] = rec
         except Exception:  # noqa: BLE001 - a call-level failure: every frame of the group on its own, under its own try

@@ -9,7 +9,9 @@ only the two scalar tails the reference itself evaluates in numpy, ``check_theta
 (processfield.py:36-150) and ``dictify_hough`` (:266-288), are evaluated here in numpy.
 There is no CPU fallback for the image operations.
 """
+import contextlib
 import os
+import threading
 
 import numpy as np
 
@@ -22,6 +24,7 @@ pathBright = None
 pathDim = None
 
 _ctx = None
+_ctx_lock = threading.RLock()   # the process-wide context below is shared by every single-image entry point of this package
 
 
 def setup_debug():
@@ -41,17 +44,28 @@ def _device_index():
 
 
 def get_context(h, w, inflight=None):
-    """Process-wide GPU context, grown when a larger image arrives."""
+    """Process-wide GPU context, grown (never shrunk) when a larger image or batch arrives.
+
+    A ``lfdmi_ctx`` is not thread-safe (include/lfdmi.h) and growing replaces it, so callers that may run on several
+    threads go through ``use_context``, which holds the module lock for the duration of their device calls; this
+    function alone only serialises the creation."""
     global _ctx
-    want = int(inflight or os.environ.get("LFD_INFLIGHT", 4))
-    if _ctx is None or _ctx.max_h * _ctx.max_w < h * w or _ctx.max_h < h or _ctx.max_w < w \
-            or _ctx.max_inflight < want:
-        if _ctx is not None:
-            want = max(want, _ctx.max_inflight)
-            h, w = max(h, _ctx.max_h), max(w, _ctx.max_w)
-            _ctx.close()
-        _ctx = _native.Context(_device_index(), h, w, want)
-    return _ctx
+    with _ctx_lock:
+        want = int(inflight or os.environ.get("LFD_INFLIGHT", 4))
+        if _ctx is None or _ctx.max_h < h or _ctx.max_w < w or _ctx.max_inflight < want:
+            if _ctx is not None:
+                want = max(want, _ctx.max_inflight)
+                h, w = max(h, _ctx.max_h), max(w, _ctx.max_w)
+                _ctx.close()
+            _ctx = _native.Context(_device_index(), h, w, want)
+        return _ctx
+
+
+@contextlib.contextmanager
+def use_context(h, w, inflight=None):
+    """``with use_context(h, w) as ctx:`` -- the shared context, exclusively, until the block ends."""
+    with _ctx_lock:
+        yield get_context(h, w, inflight)
 
 
 def check_theta(hough1, hough2, navg, dro, thetaTresh, lineSetTresh, debug):
@@ -117,9 +131,9 @@ def fit_minAreaRect(img, contoursMode, contoursMethod, minAreaRectMinLen, lwTres
     """Canny(0, 255) -> contours -> minimum-area rectangles -> (detection, box image)
     (reference: processfield.py:201-263)."""
     img = np.ascontiguousarray(img, dtype=np.uint8)
-    ctx = get_context(*img.shape)
-    detection, box_img, _ = ctx.fit_min_area_rect(img, contoursMode, contoursMethod,
-                                                  minAreaRectMinLen, lwTresh)
+    with use_context(*img.shape) as ctx:
+        detection, box_img, _ = ctx.fit_min_area_rect(img, contoursMode, contoursMethod,
+                                                      minAreaRectMinLen, lwTresh)
     return detection, box_img
 
 
@@ -192,18 +206,26 @@ def process_field_bright(img, lwTresh, thetaTresh, dilateKernel, contoursMode, c
 
     ``gaussKernel`` / ``gaussSigma`` are not reference parameters: an optional Gaussian smoothing of Canny's input
     (odd kernel size, 0 = off = the reference's behaviour; cv2.Canny has no smoothing stage).
+
+    ``contoursMode``: ``RETR_EXTERNAL`` / ``RETR_LIST`` (default) / ``RETR_CCOMP`` / ``RETR_TREE`` (the last three yield
+    the same contour set; only the hierarchy, which the reference discards, differs).  ``contoursMethod``:
+    ``CHAIN_APPROX_NONE`` (default) and ``CHAIN_APPROX_SIMPLE`` (drops collinear interior points: same convex hull, same
+    rectangles).  ``CHAIN_APPROX_TC89_L1`` / ``CHAIN_APPROX_TC89_KCOS`` are NOT supported: the Teh-Chin approximations
+    drop curvature-dependent subsets of the border that need not keep the hull's vertices, so minAreaRect of the
+    approximated contour can differ from that of the full one; they raise ``NativeError`` (``LFDMI_ERR_UNSUPPORTED``)
+    instead of returning rectangles the reference would not produce.
     """
     img[img < 0] = 0
     dev_img = _as_native_image(img)
-    ctx = get_context(*tuple(dev_img.shape))
     params = dict(lwTresh=lwTresh, thetaTresh=thetaTresh, dilateKernel=dilateKernel,
                   contoursMode=contoursMode, contoursMethod=contoursMethod,
                   minAreaRectMinLen=minAreaRectMinLen, houghMethod=houghMethod,
                   nlinesInSet=nlinesInSet, lineSetTresh=lineSetTresh, dro=dro,
                   gaussKernel=gaussKernel, gaussSigma=gaussSigma)
-    res, le, lb = ctx.process_bright(dev_img, params)
-    return _finish(ctx, res, le, lb, tuple(dev_img.shape), nlinesInSet, dro, thetaTresh, lineSetTresh, debug,
-                   "BRIGHT", pathBright)
+    with use_context(*tuple(dev_img.shape)) as ctx:   # (the debug dumps of _finish read this call's device buffers)
+        res, le, lb = ctx.process_bright(dev_img, params)
+        return _finish(ctx, res, le, lb, tuple(dev_img.shape), nlinesInSet, dro, thetaTresh, lineSetTresh, debug,
+                       "BRIGHT", pathBright)
 
 
 def process_field_dim(img, minFlux, addFlux, lwTresh, thetaTresh, erodeKernel, dilateKernel,
@@ -225,13 +247,13 @@ def process_field_dim(img, minFlux, addFlux, lwTresh, thetaTresh, erodeKernel, d
     img[img > 0] += addFlux  # raises numpy's casting error for integer images, as the reference
     if gpu_src is None:  # pragma: no cover - unreachable: the line above raised
         raise TypeError("dim pass needs a floating-point image")
-    ctx = get_context(*tuple(gpu_src.shape))
     params = dict(minFlux=minFlux, addFlux=addFlux, lwTresh=lwTresh, thetaTresh=thetaTresh,
                   erodeKernel=erodeKernel, dilateKernel=dilateKernel, contoursMode=contoursMode,
                   contoursMethod=contoursMethod, minAreaRectMinLen=minAreaRectMinLen,
                   houghMethod=houghMethod, nlinesInSet=nlinesInSet, lineSetTresh=lineSetTresh, dro=dro,
                   gaussKernel=gaussKernel, gaussSigma=gaussSigma)
     # the device applies the same masking to the untouched copy (PREP_DIM)
-    res, le, lb = ctx.process_dim(gpu_src, params, after_bright=False)
-    return _finish(ctx, res, le, lb, tuple(gpu_src.shape), nlinesInSet, dro, thetaTresh, lineSetTresh, debug,
-                   "DIM", pathDim)
+    with use_context(*tuple(gpu_src.shape)) as ctx:
+        res, le, lb = ctx.process_dim(gpu_src, params, after_bright=False)
+        return _finish(ctx, res, le, lb, tuple(gpu_src.shape), nlinesInSet, dro, thetaTresh, lineSetTresh, debug,
+                       "DIM", pathDim)

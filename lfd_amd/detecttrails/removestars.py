@@ -11,7 +11,7 @@ import numpy as np
 
 from .. import _native
 from . import fitslite, sdssfiles
-from .processfield import get_context
+from .processfield import use_context
 
 __all__ = ["read_photoObj", "read_photoObj_arrays", "remove_stars", "remove_stars_arrays"]
 
@@ -61,17 +61,19 @@ def remove_stars_arrays(img, cat, _filter, defaultxy, filter_caps, maxxy, pixsca
         packed[key] = np.ascontiguousarray(cat[key], np.int32).reshape(1, n)
     rs = _native.make_rs_params(_filter, defaultxy, filter_caps, maxxy, pixscale, magcount, maxmagdiff)
     if _native._is_dev(img):
-        ctx = get_context(*tuple(img.shape))
-        ctx.remove_stars(img, packed, rs)
+        with use_context(*tuple(img.shape)) as ctx:
+            ctx.remove_stars(img, packed, rs)
         return img
     if img.dtype != np.float32 or not img.flags.c_contiguous:
         # other dtypes / strided views: let the device blot a float32 plane of ones and zero
         # the same pixels here (ndarray.fill(0.0) is dtype-agnostic in the reference)
         work = np.ones(img.shape, np.float32)
-        get_context(*work.shape).remove_stars(work, packed, rs)
+        with use_context(*work.shape) as ctx:
+            ctx.remove_stars(work, packed, rs)
         img[work == 0] = 0
         return img
-    get_context(*img.shape).remove_stars(img, packed, rs)
+    with use_context(*img.shape) as ctx:
+        ctx.remove_stars(img, packed, rs)
     return img
 
 

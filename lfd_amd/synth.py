@@ -110,20 +110,7 @@ def make_config1_frame(shape=SDSS_SHAPE):
     return img
 
 
-def pack_catalogs(cats, filter_index=None):
-    """Stack per-frame catalogues into padded arrays [n_frames, max_obj, ...] + counts."""
-    n = len(cats)
-    m = max(len(c["NOBSERVE"]) for c in cats)
-    out = {"ROWC": np.zeros((n, m, 5), np.float32), "COLC": np.zeros((n, m, 5), np.float32),
-           "PSFMAG": np.zeros((n, m, 5), np.float32), "PETROTH90": np.zeros((n, m, 5), np.float32),
-           "NOBSERVE": np.zeros((n, m), np.int32), "NDETECT": np.ones((n, m), np.int32),
-           "count": np.zeros(n, np.int32)}
-    for i, c in enumerate(cats):
-        k = len(c["NOBSERVE"])
-        out["count"][i] = k
-        for key in ("ROWC", "COLC", "PSFMAG", "PETROTH90", "NOBSERVE", "NDETECT"):
-            out[key][i, :k] = c[key]
-    return out
+from .catalogs import pack_catalogs  # noqa: E402,F401  (kept importable from here: tests and tools use synth.pack_catalogs)
 
 
 def make_portable_frame(k, shape=(512, 768), n_star=40, with_catalog=True):

@@ -20,18 +20,51 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def run_ranks(tmp_path, world, n, extra=(), timeout=600):
+    """Start ``world`` rank programs on device 0, wait for all of them, return the array rank 0 gathered.  Whatever
+    happens -- a rank failing, a timeout -- no rank outlives this function (a rank left blocked in the gloo gather would
+    keep the GPU), and a failure reports every rank's stderr."""
+    port = _free_port()
+    out = str(tmp_path / "gathered.npy")
+    logs = [open(tmp_path / f"rank{r}.err", "w+") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_rank_worker.py"), str(r), str(world), str(port),
+                               str(n), "0", out, *[str(x) for x in extra]], env=dict(os.environ), cwd=ROOT, stderr=logs[r])
+             for r in range(world)]
+    try:
+        codes = []
+        for p in procs:
+            try:
+                codes.append(p.wait(timeout=timeout))
+            except subprocess.TimeoutExpired:
+                codes.append("timeout")
+                break                                                 # (the others are stuck behind it: killed below)
+        if codes != [0] * world:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+            tails = []
+            for r, f in enumerate(logs):
+                f.flush()
+                f.seek(0)
+                tails.append(f"--- rank {r} ---\n" + f.read()[-3000:])
+            pytest.fail(f"rank exit codes {codes}\n" + "\n".join(tails))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+        for f in logs:
+            f.close()
+    return np.load(out)
+
+
 def test_two_ranks_on_one_device(tmp_path, oracle):
     from lfd_amd import _native, batch, synth
     from lfd_amd.detecttrails import default_params
     n, world = 11, 2                                                  # ragged: 6 + 5 frames
-    port = _free_port()
-    out = str(tmp_path / "gathered.npy")
-    env = dict(os.environ)
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_rank_worker.py"), str(r), str(world), str(port),
-                               str(n), "0", out], env=env, cwd=ROOT) for r in range(world)]
-    for p in procs:
-        assert p.wait(timeout=600) == 0
-    got = np.load(out)
+    got = run_ranks(tmp_path, world, n)
     assert got.dtype == _native.RESULT_DTYPE and len(got) == n
     assert batch.shard_bounds(n, world) == [(0, 6), (6, 11)]
     pb, pd, prs = default_params()

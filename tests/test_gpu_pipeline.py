@@ -429,3 +429,82 @@ def test_host_feed_ring_keeps_rows_order_and_blotting(oracle, monkeypatch):
         assert np.array_equal(batch, blotted), feed_mb
     for i in (0, 4, 8):
         assert same(ref[i], oracle.detect_frame(frames[i].copy(), pb, pd, cats[i], rs_o))
+
+
+@pytest.mark.parametrize("add_flux", [0.5, 0.999, 0.9995, 1.0])
+def test_exact_ties_through_the_bit_plane_dim_front_end(oracle, add_flux):
+    """Integer and half-integer pixel values (BZERO/BSCALE-like data): x = k + 0.5 with k even rounds to k in the bright pass
+    and, for addFlux = 1, to k + 2 in the dim pass -- a difference the one-bit-per-pixel front end of lfdmi_detect_batch cannot
+    hold, so such knob values must take the second float sweep.  The ERODED stage image (the plane rebuilt from bright byte +
+    bit) is compared with the oracle's, not only the records."""
+    from lfd_amd import _native
+    pb, pd, _ = params()
+    pd = dict(pd, addFlux=add_flux, minFlux=0.02)
+    h, w = 256, 512
+    rng = np.random.default_rng(17)
+    base = rng.integers(0, 3, (h, w)).astype(np.float32)                 # 0, 1, 2
+    base += np.where(rng.random((h, w)) < 0.5, np.float32(0.5), np.float32(0.0))   # ... and k + 0.5 ties
+    yy, xx = np.mgrid[0:h, 0:w]
+    frames = np.stack([base, base * np.float32(0.5), base + np.float32(253.0)])     # (last: ties next to the saturation at 255)
+    frames[0][np.abs(yy - (0.25 * xx + 40)) < 3.0] = np.float32(6.5)
+    frames[1][np.abs(yy - (200 - 0.3 * xx)) < 3.0] = np.float32(2.5)
+    pb_never = dict(pb, lwTresh=1e9)                                     # the bright pass finds nothing: every frame reaches the dim pass
+    with _native.Context(0, h, w, 4) as ctx:
+        res = ctx.detect_batch(frames.copy(), pb_never, pd)
+        for i in range(3):
+            flipped = frames[i][::-1].copy()
+            flipped[flipped < 0] = 0
+            gray = oracle.prep(flipped, oracle.PREP_DIM, minFlux=pd["minFlux"], addFlux=pd["addFlux"])
+            want_eroded = oracle.erode(oracle.equalize_hist(gray), pd["erodeKernel"])
+            got = ctx.get_stage(i, _native.STAGE_ERODED, h, w)
+            assert np.array_equal(got, want_eroded), (add_flux, i, int((got != want_eroded).sum()))
+    for i in range(3):
+        want = oracle.detect_frame(frames[i].copy(), pb_never, pd)
+        assert same(res[i], want), (add_flux, i, want, res[i])
+
+
+def test_frame_must_fit_the_context_in_both_dimensions():
+    """A taller, narrower frame of smaller area than the context's: the band / tile tables are sized by max_h and max_w
+    separately, so the call is refused (LFDMI_ERR_CAPACITY) instead of running past them; the context stays usable."""
+    from lfd_amd import _native
+    pb, pd, _ = params()
+    with _native.Context(0, 256, 512, 2) as ctx:
+        tall = np.zeros((1, 320, 256), np.float32)
+        for call in (lambda: ctx.detect_batch(tall, pb, pd), lambda: ctx.process_bright(tall[0], pb),
+                     lambda: ctx.canny(np.zeros((320, 256), np.uint8)), lambda: ctx.prep_u8(tall[0], _native.PREP_BRIGHT)):
+            with pytest.raises(_native.NativeError) as e:
+                call()
+            assert e.value.code == _native.ERR_CAPACITY
+        wide = np.zeros((1, 128, 576), np.float32)
+        with pytest.raises(_native.NativeError) as e:
+            ctx.detect_batch(wide, pb, pd)
+        assert e.value.code == _native.ERR_CAPACITY
+        ok = ctx.detect_batch(np.zeros((1, 256, 512), np.float32), pb, pd)
+        assert ok[0]["status"] == 0 and ok[0]["found"] == 0
+
+
+def test_host_feed_error_path_returns_promptly_and_leaves_the_context_usable(oracle, monkeypatch):
+    """A host-frame batch large enough for the pinned double-buffer feed (>= 64 MB, several chunks) whose second chunk fails:
+    the call returns its error without uploading the rest of the batch, and the same context then processes the batch
+    correctly."""
+    import time
+    from lfd_amd import _native, synth
+    monkeypatch.setenv("LFDMI_FEED_MB", "32")                           # chunks of two SDSS-size frames
+    pb, pd, prs = params()
+    rs_g, rs_o = rs_pair(oracle, prs)
+    frames, cats = zip(*[synth.make_frame(k)[:2] for k in range(8)])
+    batch = np.stack(frames)
+    packed = synth.pack_catalogs(list(cats))
+    with _native.Context(0, 1489, 2048, 4) as ctx:
+        good = ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g)     # warm: buffers, streams
+        ctx.debug_fail_chunk(1)
+        t0 = time.perf_counter()
+        with pytest.raises(_native.NativeError) as e:
+            ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g)
+        dt = time.perf_counter() - t0
+        assert e.value.code == _native.ERR_ARG and "injected" in str(e.value)
+        assert dt < 2.0, dt
+        again = ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g)
+        assert again.tobytes() == good.tobytes()
+    for i in (0, 1, 5):
+        assert same(good[i], oracle.detect_frame(frames[i].copy(), pb, pd, cats[i], rs_o))

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(_native.SYMBOLS) == declared
-    assert lib.lfdmi_version() == 201
+    assert lib.lfdmi_version() == 300
     # nothing is exported that the header does not declare
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
