@@ -13,6 +13,7 @@
  *   - images are row-major, C-contiguous, `n` images of h x w back to back.
  *   - `loc` says where caller buffers live: LFDMI_HOST (the library stages them) or
  *     LFDMI_DEVICE (hipMalloc'd / torch CUDA memory on ctx's device, used in place).
+ *   - a frame must fit the ctx in BOTH dimensions (h <= max_h and w <= max_w), not only in area.
  *   - a ctx is bound to one device, is not thread-safe, and runs everything on one HIP
  *     stream (its own, or the caller's via lfdmi_set_stream).  Calls return after the
  *     stream has drained (synchronous at the ABI).
@@ -40,8 +41,12 @@ enum lfdmi_status {
                                    fit_minAreaRect detected (reference: TypeError, logged) */
 };
 
-enum { LFDMI_HOST = 0, LFDMI_DEVICE = 1 };
-enum { LFDMI_U8 = 0, LFDMI_F32 = 1, LFDMI_F64 = 2 };
+/* LFDMI_HOST_PINNED (lfdmi_detect_batch / _raw only): host memory obtained from lfdmi_host_alloc -- the DMA engines read it in
+ * place, without the staging copy ordinary host frames take */
+enum { LFDMI_HOST = 0, LFDMI_DEVICE = 1, LFDMI_HOST_PINNED = 2 };
+/* LFDMI_F32_BE (lfdmi_detect_batch_raw only): big-endian float32, the raw data unit of a BITPIX = -32 FITS image (what
+ * fitsio hands the reference after its own byte swap, detecttrails.py:113); swapped on the device after the upload */
+enum { LFDMI_U8 = 0, LFDMI_F32 = 1, LFDMI_F64 = 2, LFDMI_F32_BE = 3 };
 /* numpy masking done before cv2.convertScaleAbs */
 enum { LFDMI_PREP_NONE = 0, LFDMI_PREP_BRIGHT = 1, LFDMI_PREP_DIM = 2, LFDMI_PREP_BRIGHT_THEN_DIM = 3 };
 /* cv2 constants re-exported by lfd/detecttrails/detecttrails.py:14-18 */
@@ -121,7 +126,7 @@ typedef struct {
     int32_t run_cap;   /* runs per bit image (Canny candidates / background of the edge image); default N/16 */
     int32_t key_cap;   /* contours (edge components + holes); default N/256 */
     int32_t slot_cap;  /* contour rows (one (xmin,xmax) slot per row of every contour); default N/16 */
-    int32_t list_cap;  /* Hough input chunks (runs of <= 16 px) per image; default N/16 */
+    int32_t list_cap;  /* Hough input chunks (pieces of pixel runs, <= 64 px) per image and list; default N/16 */
     int32_t peak_cap;  /* Hough local maxima per image (rounded up to a power of two); default 65536 */
     double min_rho;    /* HoughLines accumulators are sized for rho >= min_rho (theta >= pi/180); default 5;
                           a call with a finer rho runs through the worst-case workspace */
@@ -218,6 +223,19 @@ int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w,
                        const lfdmi_catalog *cat, const lfdmi_rs_params *rs,
                        const lfdmi_params *bright, const lfdmi_params *dim, lfdmi_result *results,
                        int loc);
+/* lfdmi_detect_batch with the frames' element type given: LFDMI_F32, or LFDMI_F32_BE for HOST / HOST_PINNED frames holding the
+ * big-endian data unit of a FITS image as read from the file (DetectTrails.process reads frame files straight into pinned
+ * memory and leaves the byte swap to the device: detecttrails.py:73-117 is a read + swap + copy per frame in the reference).
+ * remove_stars' zero fill of the caller's frames is byte-order neutral. */
+int lfdmi_detect_batch_raw(lfdmi_ctx *ctx, void *frames, int dtype, int n, int h, int w,
+                           const lfdmi_catalog *cat, const lfdmi_rs_params *rs,
+                           const lfdmi_params *bright, const lfdmi_params *dim, lfdmi_result *results,
+                           int loc);
+/* page-locked host memory for LFDMI_HOST_PINNED frames, placed on the NUMA node next to ctx's GPU (the allocating thread
+ * is bound to the GPU's local CPUs; LFDMI_NUMA_PIN=0 in the environment disables the binding).  Free with lfdmi_host_free
+ * (any live ctx of the same device, or NULL). */
+int lfdmi_host_alloc(lfdmi_ctx *ctx, uint64_t bytes, void **out);
+int lfdmi_host_free(lfdmi_ctx *ctx, void *p);
 /* Which calls keep the 8-bit stage images (gray, eroded, equalised+dilated: what the reference's debug PNGs show) for
  * lfdmi_get_stage.  mode -1 (default): the per-pass entry points (lfdmi_process_bright / _dim / _multiscale) do,
  * lfdmi_detect_batch does not; 0: no call does (batches through the per-pass entry points: an image per frame less to
@@ -231,7 +249,7 @@ int lfdmi_get_stage(lfdmi_ctx *ctx, int slot, int which, int h, int w, uint8_t *
  * (LFDMI_COUNTERS int32 values per slot; order: keys, row slots, rectangles, equ list entries, box
  * list entries (pixel chunks the Hough kernels vote with), equ peaks, box peaks, overflow flag,
  * detection, tall keys, candidate words, background words, candidate runs, background runs, medium
- * keys, non-zero pixels of equ, of box_img, reserved x3) */
+ * keys, non-zero pixels of equ, of box_img, active 64 x 16 tiles, entries of the second (longer-chunk) Hough lists of equ / box) */
 #define LFDMI_COUNTERS 20
 int lfdmi_get_counters(lfdmi_ctx *ctx, int slot0, int n, int32_t *dst);
 /* per-kernel timing for bench.py's roofline entry: when enabled, every kernel launch is

@@ -13,8 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblfdmi.so")
 
-HOST, DEVICE = 0, 1
-U8, F32, F64 = 0, 1, 2
+HOST, DEVICE, HOST_PINNED = 0, 1, 2
+U8, F32, F64, F32_BE = 0, 1, 2, 3
 PREP_NONE, PREP_BRIGHT, PREP_DIM, PREP_BRIGHT_THEN_DIM = 0, 1, 2, 3
 STAGE_GRAY, STAGE_EQU, STAGE_CANNY, STAGE_BOX, STAGE_ERODED, STAGE_EQUALIZED = 0, 1, 2, 3, 4, 5
 MAX_SCALES = 4
@@ -31,7 +31,7 @@ SYMBOLS = (
     "lfdmi_max_inflight", "lfdmi_prep_u8", "lfdmi_equalize_hist", "lfdmi_dilate", "lfdmi_erode",
     "lfdmi_canny", "lfdmi_gaussian_blur", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
     "lfdmi_hough_dims", "lfdmi_remove_stars", "lfdmi_process_bright", "lfdmi_process_dim",
-    "lfdmi_detect_batch", "lfdmi_set_stage_images", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_timing_select", "lfdmi_get_timing",
+    "lfdmi_detect_batch", "lfdmi_detect_batch_raw", "lfdmi_host_alloc", "lfdmi_host_free", "lfdmi_set_stage_images", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_timing_select", "lfdmi_get_timing",
     "lfdmi_timing_slots", "lfdmi_timing_name",
 )
 
@@ -165,6 +165,28 @@ def make_params(d, dim=False):
 def make_rs_params(filter, defaultxy, filter_caps, maxxy, pixscale, magcount, maxmagdiff, **_):
     return RsParams(int(defaultxy), int(maxxy), int(magcount), float(pixscale), float(maxmagdiff),
                     float(filter_caps[filter]), "ugriz".index(filter))
+
+
+class PinnedBuffer:
+    """``nbytes`` of page-locked host memory from lfdmi_host_alloc; ``.array`` is a uint8 numpy view (take ``.view('>f4')``
+    slices of it for frames).  Freed by ``close()`` / garbage collection; the views must not be used afterwards."""
+
+    def __init__(self, ctx, nbytes):
+        self._lib = ctx._lib
+        self._p = C.c_void_p()
+        self.nbytes = int(nbytes)
+        self._lib.lfdmi_host_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        ctx._chk(self._lib.lfdmi_host_alloc(ctx._h, C.c_uint64(self.nbytes), C.byref(self._p)))
+        self.array = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self._p.value))
+
+    def close(self):
+        p, self._p = getattr(self, "_p", None), None
+        if p:
+            self.array = None
+            self._lib.lfdmi_host_free.argtypes = [C.c_void_p, C.c_void_p]
+            self._lib.lfdmi_host_free(None, p)
+
+    __del__ = close
 
 
 class Context:
@@ -465,21 +487,38 @@ class Context:
                                                      int(after_bright), C.byref(p), len(rhos), rh, _ptr(res), loc))
         return res[:, 0] if sq else res
 
-    def detect_batch(self, frames, params_bright, params_dim, cat=None, rs=None):
-        """frames: float32 (n,h,w) numpy or torch-CUDA; returns a structured array of n results."""
-        frames, n, h, w, sq = self._batch(frames)
-        if _dtype_code(frames) != F32:
-            raise TypeError("detect_batch needs float32 frames")
+    def detect_batch(self, frames, params_bright, params_dim, cat=None, rs=None, pinned=False):
+        """frames: float32 (n,h,w) numpy or torch-CUDA; returns a structured array of n results.
+
+        numpy frames of dtype '>f4' (the raw data unit of a FITS image) are accepted as they are and byte-swapped on the
+        device.  ``pinned=True``: the array lives in memory from ``PinnedBuffer`` (DMA'd in place, no staging copy)."""
+        if not _is_dev(frames) and isinstance(frames, np.ndarray) and frames.dtype == np.dtype(">f4"):
+            if not frames.flags.c_contiguous:
+                raise ValueError("big-endian frames must be C-contiguous")
+            shp = frames.shape
+            n, h, w = (1, *shp) if len(shp) == 2 else shp
+            code = F32_BE
+        else:
+            frames, n, h, w, sq = self._batch(frames)
+            code = _dtype_code(frames)
+            if code != F32:
+                raise TypeError("detect_batch needs float32 frames")
+        if pinned and _is_dev(frames):
+            raise ValueError("pinned=True is for host arrays")
         pb, k1 = make_params(params_bright)
         pd, k2 = make_params(params_dim, dim=True)
         c, k3 = self._catalog(cat)
         res = np.zeros(n, RESULT_DTYPE)
-        self._chk(self._lib.lfdmi_detect_batch(self._h, _ptr(frames), n, h, w,
-                                               C.byref(c) if c is not None else None,
-                                               C.byref(rs) if rs is not None else None,
-                                               C.byref(pb), C.byref(pd), _ptr(res),
-                                               DEVICE if _is_dev(frames) else HOST))
+        loc = DEVICE if _is_dev(frames) else (HOST_PINNED if pinned else HOST)
+        self._chk(self._lib.lfdmi_detect_batch_raw(self._h, _ptr(frames), code, n, h, w,
+                                                   C.byref(c) if c is not None else None,
+                                                   C.byref(rs) if rs is not None else None,
+                                                   C.byref(pb), C.byref(pd), _ptr(res), loc))
         return res
+
+    def pinned_buffer(self, nbytes):
+        """Page-locked host memory next to this context's GPU (lfdmi_host_alloc) as a ``PinnedBuffer``."""
+        return PinnedBuffer(self, nbytes)
 
     def get_counters(self, slot0=0, n=None):
         """Work counters ([n, 20] int32, see LFDMI_COUNTERS) the last pass left for in-flight slots slot0 .. slot0+n-1."""

@@ -25,6 +25,8 @@ enum {
     C_NNZ_EQU = 15,  // non-zero pixels of equ (180 Hough votes each)
     C_NNZ_BOX = 16,  // non-zero pixels of box_img
     C_NTILES = 17,   // 64 x 16 tiles of the pass image with anything in reach (work list of k_dilate_canny_t)
+    C_NPIXB_EQU = 18, // entries of equ's class-B list (longer chunks for the angle slabs away from the horizontal, see k_pixlist)
+    C_NPIXB_BOX = 19,
     C_COUNT = 20
 };
 

@@ -11,24 +11,29 @@
 #include "common.h"
 #include "../../include/lfdmi.h"
 
-// bit rows -> list of horizontal pixel CHUNKS, order irrelevant (votes commute):
-//   entry = (len - 1) << 26 | y << 13 | x0,   1 <= len <= 16, the pixels (y, x0 .. x0 + len - 1) all set.
-// The Hough inputs are dilated blobs and filled rectangles: runs of 10-100 pixels, so a frame's list is
-// ~12x shorter than its pixel count, and the vote kernel handles a chunk with two accumulator updates
-// per angle instead of one per pixel (see k_hough_vote).  Image sides up to 8191 (13 bits).
+// bit rows -> lists of horizontal pixel CHUNKS, order irrelevant (votes commute):
+//   entry = (len - 1) << 26 | y << 13 | x0,   1 <= len <= 64, the pixels (y, x0 .. x0 + len - 1) all set (one 64-pixel word).
+// The Hough inputs are dilated blobs and filled rectangles: runs of 10-100 pixels, so a frame's list is many times shorter
+// than its pixel count, and the vote kernel handles a chunk with two accumulator updates per angle instead of one per
+// pixel (see k_hough_vote).  Image sides up to 8191 (13 bits).
+// A chunk must span less than one rho bin at every angle that votes with it: (len - 1) |cos| / rho < 1.  That bound depends
+// on the angle: 20 pixels at rho = 20 for the angles near 0 / 180 degrees, 45 for a slab of angles 64 .. 127 degrees.  So the
+// runs are cut TWICE: list A with the chunk length every angle slab can take, list B (longer chunks, fewer entries) for the
+// slabs whose angles all stay away from the horizontal (host: vote_classes); a slab votes with the list of its class.
 #define PIXLIST_WORDS 8 // words per thread of k_pixlist
-#define CHUNK_MAX 16 // (4 bits; the host passes min(CHUNK_MAX, floor(rho)) so that a chunk spans less than one bin)
+#define CHUNK_MAX 64 // a chunk lies inside one 64-pixel word (6-bit length field)
 __device__ __forceinline__ uint32_t chunk_entry(int y, int x0, int len) {
     return ((uint32_t)(len - 1) << 26) | ((uint32_t)y << 13) | (uint32_t)x0;
 }
 
+// lists: [slot][class A / B][list_cap] per image; counters C_NPIX_* (class A) and C_NPIXB_* (class B); cm_b == 0: no class B
 __global__ void __launch_bounds__(256)
-k_pixlist(const u64 *bits0, const u64 *bits1, uint32_t *list0, uint32_t *list1, int *counters, int chunk_max, int h, int w,
+k_pixlist(const u64 *bits0, const u64 *bits1, uint32_t *list0, uint32_t *list1, int *counters, int cm_a, int cm_b, int h, int w,
           size_t list_cap, int *accum_clear, int acc_n, size_t acc_stride, const int *active, int need_detect) {
     int g = blockIdx.y, im = blockIdx.z; // image 0: equ, image 1: box_img
     const u64 *bits = im ? bits1 : bits0;
     uint32_t *list = im ? list1 : list0;
-    const int cidx = im ? C_NPIX_BOX : C_NPIX_EQU, nnz_idx = im ? C_NNZ_BOX : C_NNZ_EQU;
+    const int cidx = im ? C_NPIX_BOX : C_NPIX_EQU, cidx_b = im ? C_NPIXB_BOX : C_NPIXB_EQU, nnz_idx = im ? C_NNZ_BOX : C_NNZ_EQU;
     if (accum_clear) accum_clear += (size_t)im * acc_stride;
     if (slot_off(active, counters, g)) return;
     int *cnt = counters + g * C_COUNT;
@@ -41,7 +46,7 @@ k_pixlist(const u64 *bits0, const u64 *bits1, uint32_t *list0, uint32_t *list1, 
     // PIXLIST_WORDS words per thread: a workgroup per 256 words spent its life on the two dependent loads in front
     // of the work (active flag, detection counter) -- 95 000 workgroups per launch, most of them with nothing to do
     const int nw = h * wq;
-    uint32_t *lg = list + (size_t)g * list_cap;
+    uint32_t *lga = list + (size_t)g * 2 * list_cap, *lgb = lga + list_cap;
     const int lane = lfd_lane();
     u64 cw[PIXLIST_WORDS]; // all of a thread's words first: independent loads in flight together
 #pragma unroll
@@ -68,6 +73,8 @@ k_pixlist(const u64 *bits0, const u64 *bits1, uint32_t *list0, uint32_t *list1, 
         nloc += __popcll(bal);
     }
     __builtin_amdgcn_wave_barrier();
+    // pieces of a run of `len` pixels cut every cm: ceil(len / cm) without an integer division (len, cm <= 64)
+    const float inv_a = (1.0f / (float)cm_a) * 1.000001f, inv_b = cm_b > 0 ? (1.0f / (float)cm_b) * 1.000001f : 0.0f;
     for (int kb = 0; kb < nloc; kb += 64) {
         u64 c = 0;
         int y = 0, q = 0;
@@ -77,38 +84,45 @@ k_pixlist(const u64 *bits0, const u64 *bits1, uint32_t *list0, uint32_t *list1, 
             c = sw[wv][kb + lane] & valid_mask(q, w);
         }
         if (__ballot(c != 0) == 0ull) continue;
-        // chunks of this word: every maximal stretch of set bits, cut every chunk_max pixels
-        int n = 0;
+        // chunks of this word: every maximal stretch of set bits, cut every cm_a (list A) / cm_b (list B) pixels
+        int na = 0, nb = 0;
         for (u64 r = c; r;) {
             int b = __ffsll((long long)r) - 1;
             u64 inv = ~(r >> b);
             int len = inv ? (__ffsll((long long)inv) - 1) : (64 - b);
             r &= ~((len >= 64 ? ~0ull : ((1ull << len) - 1)) << b);
-            n += (len + chunk_max - 1) / chunk_max;
+            na += (int)((float)(len + cm_a - 1) * inv_a);
+            nb += (int)((float)(len + cm_b - 1) * inv_b);
         }
-        // wave-aggregated allocation: inclusive scan of n, one atomic per wave
-        int incl = n, px = __popcll(c);
+        // wave-aggregated allocation: inclusive scans of the counts, one atomic per wave and list
+        int incl_a = na, incl_b = nb, px = __popcll(c);
         for (int off = 1; off < 64; off <<= 1) {
-            int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
+            int ta = __shfl_up(incl_a, off), tb = __shfl_up(incl_b, off);
+            if (lane >= off) { incl_a += ta; incl_b += tb; }
         }
         for (int off = 32; off > 0; off >>= 1) px += __shfl_down(px, off);
-        int total = __shfl(incl, 63);
-        int base = 0;
-        if (lane == 63 && total) base = atomicAdd(&cnt[cidx], total);
+        const int total_a = __shfl(incl_a, 63), total_b = __shfl(incl_b, 63);
+        int base_a = 0, base_b = 0;
+        if (lane == 63 && total_a) base_a = atomicAdd(&cnt[cidx], total_a);
+        if (lane == 63 && total_b) base_b = atomicAdd(&cnt[cidx_b], total_b);
         if (lane == 0 && px) atomicAdd(&cnt[nnz_idx], px);
-        base = __shfl(base, 63);
-        if ((size_t)base + (size_t)total > list_cap) { // list full: the frame is run again through the worst-case workspace
+        base_a = __shfl(base_a, 63);
+        base_b = __shfl(base_b, 63);
+        if ((size_t)base_a + (size_t)total_a > list_cap || (size_t)base_b + (size_t)total_b > list_cap) {
+            // list full: the frame is run again through the worst-case workspace
             if (lane == 0) cnt[C_OVERFLOW] = 1;
             continue;
         }
-        int o = base + incl - n;
+        int oa = base_a + incl_a - na, ob = base_b + incl_b - nb;
         for (u64 r = c; r;) {
             int b = __ffsll((long long)r) - 1;
             u64 inv = ~(r >> b);
             int len = inv ? (__ffsll((long long)inv) - 1) : (64 - b);
             r &= ~((len >= 64 ? ~0ull : ((1ull << len) - 1)) << b);
-            for (int x0 = (q << 6) + b; len > 0; x0 += chunk_max, len -= chunk_max) lg[o++] = chunk_entry(y, x0, min(len, chunk_max));
+            const int xr = (q << 6) + b;
+            for (int x0 = xr, l = len; l > 0; x0 += cm_a, l -= cm_a) lga[oa++] = chunk_entry(y, x0, min(l, cm_a));
+            if (cm_b > 0)
+                for (int x0 = xr, l = len; l > 0; x0 += cm_b, l -= cm_b) lgb[ob++] = chunk_entry(y, x0, min(l, cm_b));
         }
     }
 }
@@ -118,7 +132,7 @@ k_pixlist(const u64 *bits0, const u64 *bits1, uint32_t *list0, uint32_t *list1, 
 // (numrho) accumulator rows -- 0 .. 127 of 356 for angles 0 - 63 deg of an SDSS frame -- so a workgroup's LDS slab
 // holds rows lo .. hi only (host: vote_ranges): less than half the LDS, two to three workgroups per CU.
 #define VOTE_MAX_SLABS 32
-struct VoteRanges { int lo[VOTE_MAX_SLABS], hi[VOTE_MAX_SLABS]; }; // centred bin index r (0 = rho 0), inclusive
+struct VoteRanges { int lo[VOTE_MAX_SLABS], hi[VOTE_MAX_SLABS]; unsigned cls_b; }; // centred bin index r (0 = rho 0), inclusive; bit sl of cls_b: slab sl votes with list B
 
 // Accumulator layouts.  OpenCV indexes accum[(n+1)*(numrho+2) + r+1] ("base"); that value is
 // still what orders equal-vote lines.  In memory the accumulator is kept TRANSPOSED,
@@ -148,14 +162,15 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     int na = min(AW, numangle - a0);
     const int lo = slab < VOTE_MAX_SLABS ? rng.lo[slab] : -((numrho - 1) / 2);
     const int nb = (slab < VOTE_MAX_SLABS ? rng.hi[slab] : numrho - 1 - (numrho - 1) / 2) - lo + 1;
-    int n = cnt[im ? C_NPIX_BOX : C_NPIX_EQU];
+    const int cls = (slab < VOTE_MAX_SLABS) ? (int)((rng.cls_b >> slab) & 1u) : 0; // the chunk list this slab's angles may vote with
+    int n = cnt[cls ? (im ? C_NPIXB_BOX : C_NPIXB_EQU) : (im ? C_NPIX_BOX : C_NPIX_EQU)];
     if ((size_t)n > list_cap) n = (int)list_cap;
     int per = ((n + nsplit - 1) / nsplit + 63) / 64 * 64;
     int begin = min(n, split * per), end = min(n, begin + per);
     if (nsplit > 1 && begin >= end) return; // nothing to add
     for (int k = threadIdx.x; k < nb * AW + 64; k += VOTE_THREADS) acc[k] = 0;
     __syncthreads();
-    const uint32_t *list = (im ? list1 : list0) + (size_t)g * list_cap;
+    const uint32_t *list = (im ? list1 : list0) + ((size_t)g * 2 + cls) * list_cap;
     int lane = threadIdx.x & 63;
     int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // lane = (chunk slot, angle): a slab of AW < 64 angles (large accumulators: the slab's rows x AW must fit in LDS) lets
@@ -176,7 +191,7 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     const unsigned cell = act ? (unsigned)((-lo) * AW + ang) : (unsigned)(nb * AW + lane);
     const unsigned lanebase = (cell << 2) - (0x4B400000u << (aw_log2 + 2));
     char *accb = (char *)acc;
-    // A list entry is a chunk of horizontal neighbours (y, x0 .. x0 + len - 1), len <= min(16, rho) (k_pixlist).
+    // A list entry is a chunk of horizontal neighbours (y, x0 .. x0 + len - 1), (len - 1) |c| < 1 for every angle of this slab (k_pixlist).
     // Along a chunk the vote value w(x) = fl(fl(x c) + y s) is monotone in x and moves by less than one bin
     // (|c| = |cos| / rho per pixel), so the chunk's pixels fall into at most two adjacent bins: the first t
     // into bin(x0), the rest into bin(x0 + len - 1).  Per angle:
@@ -553,7 +568,8 @@ __global__ void k_hough_reset(int *counters, int G) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     int *cnt = counters + g * C_COUNT;
-    cnt[C_NPIX_EQU] = 0; cnt[C_NPIX_BOX] = 0; cnt[C_NPEAK_EQU] = 0; cnt[C_NPEAK_BOX] = 0; cnt[C_NNZ_EQU] = 0; cnt[C_NNZ_BOX] = 0;
+    cnt[C_NPIX_EQU] = 0; cnt[C_NPIX_BOX] = 0; cnt[C_NPIXB_EQU] = 0; cnt[C_NPIXB_BOX] = 0; cnt[C_NPEAK_EQU] = 0; cnt[C_NPEAK_BOX] = 0;
+    cnt[C_NNZ_EQU] = 0; cnt[C_NNZ_BOX] = 0;
 }
 
 __global__ void k_init_results(lfdmi_result *res, int *pass_flags, int G) {

@@ -172,7 +172,8 @@ __global__ void __launch_bounds__(256)
 k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double minFlux,
             double addFlux, uint8_t *gray, int *hist, u64 *cellbm, int bm_bands, const int *active, u64 *fullbits,
             int prep_rows, // rows per workgroup: a divisor of CELLBM_ROWS (a workgroup's rows lie in one band)
-            u64 *dbits = nullptr, int *hist2 = nullptr, float mf2 = 0.f, float af2 = 0.f, u64 *nzd = nullptr) {
+            u64 *dbits = nullptr, int *hist2 = nullptr, float mf2 = 0.f, float af2 = 0.f, u64 *nzd = nullptr,
+            int sky_fast = 0) { // DELTA + MFPOS with fl(mf2 + af2) > 0.5 (host-checked): the all-sky shortcut below is exact
     int g = blockIdx.y;
     if (active && !active[g]) return;
     __shared__ int sh[DELTA ? 8 : 4][256];
@@ -203,6 +204,35 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
                     int r = rb + k;
                     if (k >= prep_rows || r >= h) break;
                     constexpr int M = MODE >= 0 ? MODE : 0;
+                    if constexpr (DELTA && MFPOS && M == 1) {
+                        // Sky: when every pixel of the wave's 256 is below 0.5 (NaN compares false) the bright values are all 0
+                        // (x <= 0.5 rounds to 0, negatives are clamped) and the dim value of a pixel is 1 where x >= mf2 and 0
+                        // elsewhere: with fl(mf2 + af2) > 0.5 (sky_fast, checked on the host) and af2 <= 0.999 (the DELTA
+                        // precondition) mf2 <= x < 0.5 gives 0.5 < fl(x + af2) < 1.5, which rounds to 1.  Nine in ten wave-rows of
+                        // a sky frame take this branch: four compares instead of two full conversions per pixel.
+                        if (sky_fast) {
+                            const float4 q = v[k];
+                            const bool sky = (q.x < 0.5f) & (q.y < 0.5f) & (q.z < 0.5f) & (q.w < 0.5f);
+                            if (__ballot(!sky) == 0ull) {
+                                ((uint32_t *)(gout + (size_t)r * w))[x4] = 0u;
+                                if (fullbits && lfd_lane() == 0) fullbits[((size_t)g * h + r) * ((w + 255) >> 8) + (x4 >> 6)] = 0ull;
+                                acc.n01 += 1;
+                                const uint32_t nib = (q.x >= mf2 ? 1u : 0u) | (q.y >= mf2 ? 2u : 0u) | (q.z >= mf2 ? 4u : 0u) | (q.w >= mf2 ? 8u : 0u);
+                                acc2.n01 += 1;
+                                acc2.ones01 += __popc(nib);
+                                uint32_t bw = nib << (4 * (threadIdx.x & 7));
+                                bw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bw, 0x111, 0xf, 0xf, true); // row_shr:1
+                                bw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bw, 0x112, 0xf, 0xf, true); // row_shr:2
+                                bw |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bw, 0x114, 0xf, 0xf, true); // row_shr:4
+                                if ((threadIdx.x & 7) == 7) { // dim value = bright value (0) + bit, and non-zero exactly where the bit is set
+                                    const size_t o = ((size_t)g * h + r) * LFD_WQ(w);
+                                    ((uint32_t *)(dbits + o))[x4 >> 3] = bw;
+                                    ((uint32_t *)(nzd + o))[x4 >> 3] = bw;
+                                }
+                                continue;
+                            }
+                        }
+                    }
                     const uint32_t word = prep_word_m<M>(v[k], mf, af);
                     ((uint32_t *)(gout + (size_t)r * w))[x4] = word;
                     if (word) nzpos |= 1u << i;

@@ -116,7 +116,8 @@ struct lfdmi_ctx {
     // host-frame feed of lfdmi_detect_batch: two pinned staging buffers filled by host threads, two device buffers, a copy
     // stream; chunk k+1 crosses PCIe while chunk k is being processed
     void *feed_pin[2] = {nullptr, nullptr}, *feed_dev[2] = {nullptr, nullptr};
-    size_t feed_bytes = 0;
+    size_t feed_bytes = 0, feed_pin_bytes = 0; // capacity of each of the two device / pinned host buffers
+    bool feed_cpus_known = false;
     hipStream_t feed_copy = nullptr, feed_copy2 = nullptr; // (LFDMI_FEED_STREAMS=2: pieces alternate between two copy streams)
     hipEvent_t feed_mid = nullptr;
     int feed_streams = 2;
@@ -369,8 +370,8 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     RET(dmalloc(ctx, &ctx->wl_bg, G * BW));
     RET(dmalloc(ctx, &ctx->rowext, G * ctx->slot_cap));
     RET(dmalloc(ctx, &ctx->quads, G * ctx->key_cap * 8));
-    RET(dmalloc(ctx, &ctx->pix_equ, G * ctx->list_cap));
-    RET(dmalloc(ctx, &ctx->pix_box, G * ctx->list_cap));
+    RET(dmalloc(ctx, &ctx->pix_equ, G * 2 * ctx->list_cap)); // two chunk lists per image (k_pixlist: class A / class B)
+    RET(dmalloc(ctx, &ctx->pix_box, G * 2 * ctx->list_cap));
     RET(dmalloc(ctx, &ctx->accum, G * 2 * ctx->acc_cap));
     RET(dmalloc(ctx, &ctx->peaks, G * 2 * ctx->peak_cap));
     RET(dmalloc(ctx, &ctx->lines, G * 2 * LFDMI_MAX_SET_LINES * 2));
@@ -544,7 +545,7 @@ static int ensure_stage(lfdmi_ctx *ctx, size_t bytes) {
     return 0;
 }
 
-static size_t dtype_size(int dtype) { return dtype == LFDMI_U8 ? 1 : (dtype == LFDMI_F32 ? 4 : 8); }
+static size_t dtype_size(int dtype) { return dtype == LFDMI_U8 ? 1 : ((dtype == LFDMI_F32 || dtype == LFDMI_F32_BE) ? 4 : 8); }
 
 // returns a device pointer for `count` input bytes starting at src (+ offset), staging if needed
 static int in_ptr(lfdmi_ctx *ctx, const void *src, size_t offset, size_t bytes, int loc, const void **out) {
@@ -597,7 +598,11 @@ static int run_prep(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, i
 #define LFD_PREP_DELTA(P_)                                                                                                            \
     k_prep_hist<1, true, P_><<<pgrid, 256, 0, ctx->stream>>>(src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist,     \
                                                               ctx->cellbm, ctx->bm_bands, active, fullbits, prep_rows, ctx->dbits,    \
-                                                              ctx->hist2, (float)delta_dim->minFlux, (float)delta_dim->addFlux, ctx->nzd)
+                                                              ctx->hist2, (float)delta_dim->minFlux, (float)delta_dim->addFlux, ctx->nzd, sky_fast)
+            // (all-sky shortcut of the sweep: exact when the smallest kept value already rounds to 1, see k_prep_hist)
+            static const bool sky_on = getenv("LFDMI_SKY_FAST") ? atoi(getenv("LFDMI_SKY_FAST")) != 0 : true; // developer switch
+            const float mfa = (float)delta_dim->minFlux + (float)delta_dim->addFlux;
+            const int sky_fast = (sky_on && mode == LFDMI_PREP_BRIGHT && mfa > 0.5f) ? 1 : 0;
             if ((float)delta_dim->minFlux > 0.f) LFD_PREP_DELTA(true);
             else LFD_PREP_DELTA(false);
 #undef LFD_PREP_DELTA
@@ -1013,6 +1018,30 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         if (((size_t)nbmax << aw_log2) * 4 + 256 <= 152 * 1024 || aw_log2 == 0) break;
     }
     if (((size_t)nbmax << aw_log2) * 4 + 256 > 152 * 1024) return fail(ctx, LFDMI_ERR_CAPACITY, "numrho too large for LDS");
+    // Chunk length per slab: (len - 1) * max |cos / rho| over the slab's angles stays below one bin (k_hough_vote's two-bin
+    // split; its exact checks do not depend on this bound, only its speed does).  Class A: the length every slab can take;
+    // class B: the slabs that can take at least twice that (angles away from the horizontal), with their own, longer cut.
+    int cm_a = CHUNK_MAX, cm_b = 0;
+    rng.cls_b = 0u;
+    {
+        const int AW = 1 << aw_log2;
+        int lmax[VOTE_MAX_SLABS];
+        const bool per_slab = nslabs <= VOTE_MAX_SLABS && (int)tab_host.size() == 2 * na;
+        for (int sl = 0; sl < (per_slab ? nslabs : 1); sl++) {
+            double cmax = 0;
+            for (int n = per_slab ? sl * AW : 0; n < na && (!per_slab || n < (sl + 1) * AW); n++) cmax = std::max(cmax, (double)fabsf(tab_host[n]));
+            double l = cmax > 0 ? floor(0.999 / cmax) + 1 : CHUNK_MAX;
+            lmax[sl] = (int)std::min<double>(CHUNK_MAX, std::max<double>(1, l));
+            cm_a = std::min(cm_a, lmax[sl]);
+        }
+        static const bool use_b = getenv("LFDMI_VOTE_CLASSES") ? atoi(getenv("LFDMI_VOTE_CLASSES")) != 0 : true; // developer switch
+        if (per_slab && use_b) {
+            int mb = CHUNK_MAX + 1;
+            for (int sl = 0; sl < nslabs; sl++)
+                if (lmax[sl] >= 2 * cm_a) { rng.cls_b |= 1u << sl; mb = std::min(mb, lmax[sl]); }
+            if (rng.cls_b) cm_b = mb;
+        }
+    }
     dim3 wg = word_grid(h, w, nc);
     {
         // cut each pixel list into pieces so that a launch carries several workgroups per CU
@@ -1022,9 +1051,7 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         int acc_n = (na + 2) * (nr + 2);
         { Span sp(ctx, KID_PIXLIST, need_detect);
         // per-slot accumulator pairs are 2 * acc_cap apart; the kernel indexes by slot itself
-        // a chunk must span less than one rho bin: |cos| / rho per pixel
-        int chunk_max = rho >= CHUNK_MAX ? CHUNK_MAX : (rho >= 1 ? (int)rho : 1);
-        k_pixlist<<<dim3((wg.x + PIXLIST_WORDS - 1) / PIXLIST_WORDS, wg.y, n_img), 256, 0, ctx->stream>>>(ctx->equb, ctx->boxb, ctx->pix_equ, ctx->pix_box, ctx->counters, chunk_max,
+        k_pixlist<<<dim3((wg.x + PIXLIST_WORDS - 1) / PIXLIST_WORDS, wg.y, n_img), 256, 0, ctx->stream>>>(ctx->equb, ctx->boxb, ctx->pix_equ, ctx->pix_box, ctx->counters, cm_a, cm_b,
                                                                     h, w, ctx->list_cap, nsplit > 1 ? ctx->accum : nullptr, acc_n, ctx->acc_cap,
                                                                     active, need_detect);
         KCHK("k_pixlist"); }
@@ -1773,38 +1800,44 @@ static void bind_thread(const std::vector<int> &cpus) { // the calling thread; n
     (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
 }
 
-static int feed_prepare(lfdmi_ctx *ctx, size_t bytes) {
+static int feed_prepare(lfdmi_ctx *ctx, size_t bytes, bool need_pin) {
     if (!ctx->feed_copy) {
         HIPCHK(hipStreamCreateWithFlags(&ctx->feed_copy, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&ctx->feed_copy2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&ctx->feed_mid, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&ctx->feed_up[i], hipEventDisableTiming));
-        ctx->feed_cpus = numa_cpus(ctx->device);
     }
-    if (ctx->feed_bytes >= bytes) return 0;
+    if (!ctx->feed_cpus_known) { ctx->feed_cpus = numa_cpus(ctx->device); ctx->feed_cpus_known = true; }
+    if (ctx->feed_bytes >= bytes && (!need_pin || ctx->feed_pin_bytes >= bytes)) return 0;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->feed_copy));
     HIPCHK(hipStreamSynchronize(ctx->feed_copy2));
-    for (int i = 0; i < 2; i++) {
-        if (ctx->feed_pin[i]) { HIPCHK(hipHostFree(ctx->feed_pin[i])); ctx->feed_pin[i] = nullptr; }
-        if (ctx->feed_dev[i]) { HIPCHK(hipFree(ctx->feed_dev[i])); ctx->feed_dev[i] = nullptr; }
+    if (ctx->feed_bytes < bytes) {
+        for (int i = 0; i < 2; i++)
+            if (ctx->feed_dev[i]) { HIPCHK(hipFree(ctx->feed_dev[i])); ctx->feed_dev[i] = nullptr; }
+        ctx->feed_bytes = 0;
+        for (int i = 0; i < 2; i++) HIPCHK(hipMalloc(&ctx->feed_dev[i], bytes));
+        ctx->feed_bytes = bytes;
     }
-    ctx->feed_bytes = 0;
-    // the pinned buffers are allocated (and first touched) by a thread bound to the GPU's CPUs: their pages land on that node
-    hipError_t herr = hipSuccess;
-    std::thread alloc([&] {
-        bind_thread(ctx->feed_cpus);
-        herr = hipSetDevice(ctx->device);
-        for (int i = 0; i < 2 && herr == hipSuccess; i++) {
-            herr = hipHostMalloc(&ctx->feed_pin[i], bytes, hipHostMallocDefault);
-            if (herr == hipSuccess && !ctx->feed_cpus.empty())
-                for (size_t o = 0; o < bytes; o += 4096) ((volatile char *)ctx->feed_pin[i])[o] = 0;
-        }
-    });
-    alloc.join();
-    HIPCHK(herr);
-    for (int i = 0; i < 2; i++) HIPCHK(hipMalloc(&ctx->feed_dev[i], bytes));
-    ctx->feed_bytes = bytes;
+    if (need_pin && ctx->feed_pin_bytes < bytes) {
+        for (int i = 0; i < 2; i++)
+            if (ctx->feed_pin[i]) { HIPCHK(hipHostFree(ctx->feed_pin[i])); ctx->feed_pin[i] = nullptr; }
+        ctx->feed_pin_bytes = 0;
+        // the pinned buffers are allocated (and first touched) by a thread bound to the GPU's CPUs: their pages land on that node
+        hipError_t herr = hipSuccess;
+        std::thread alloc([&] {
+            bind_thread(ctx->feed_cpus);
+            herr = hipSetDevice(ctx->device);
+            for (int i = 0; i < 2 && herr == hipSuccess; i++) {
+                herr = hipHostMalloc(&ctx->feed_pin[i], bytes, hipHostMallocDefault);
+                if (herr == hipSuccess && !ctx->feed_cpus.empty())
+                    for (size_t o = 0; o < bytes; o += 4096) ((volatile char *)ctx->feed_pin[i])[o] = 0;
+            }
+        });
+        alloc.join();
+        HIPCHK(herr);
+        ctx->feed_pin_bytes = bytes;
+    }
     return 0;
 }
 
@@ -1910,18 +1943,68 @@ static void feed_done(FeedState *fs, int chunks_done) { // chunk (chunks_done - 
     fs->cv.notify_all();
 }
 
-extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w, const lfdmi_catalog *cat,
-                                  const lfdmi_rs_params *rs, const lfdmi_params *bright, const lfdmi_params *dim,
-                                  lfdmi_result *results, int loc) {
+// big-endian float32 -> native, in place (the raw data unit of a BITPIX = -32 FITS image, detecttrails.py:113): 16 bytes per lane
+__global__ void __launch_bounds__(256) k_bswap32(uint4 *p, size_t n16) {
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)gridDim.x * 256) {
+        uint4 v = p[k];
+        v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y); v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
+        p[k] = v;
+    }
+}
+static int run_bswap(lfdmi_ctx *ctx, void *dev, size_t bytes) { // bytes % 16 == 0 is not required: the tail is swapped by one more wave
+    Span sp(ctx, KID_MISC);
+    const size_t n16 = bytes / 16;
+    if (n16) {
+        k_bswap32<<<(unsigned)std::min<size_t>((n16 + 255) / 256, 16384), 256, 0, ctx->stream>>>((uint4 *)dev, n16);
+        KCHK("k_bswap32");
+    }
+    if (bytes % 16) { // (frames of h * w floats: only when h * w is not a multiple of 4)
+        std::vector<uint32_t> tail((bytes % 16) / 4);
+        char *q = (char *)dev + n16 * 16;
+        HIPCHK(hipMemcpyAsync(tail.data(), q, tail.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (auto &v : tail) v = __builtin_bswap32(v);
+        HIPCHK(hipMemcpyAsync(q, tail.data(), tail.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+// pinned frames (LFDMI_HOST_PINNED): chunk kc's bytes go from the caller's buffer to the device in 32 MB pieces alternating
+// between the two copy streams, no staging copy; the event of the chunk's slot is recorded behind the last piece
+static int pinned_upload(lfdmi_ctx *ctx, const char *src, size_t bytes, int kc) {
+    char *dst = (char *)ctx->feed_dev[kc & 1];
+    hipStream_t copy = ctx->feed_copy, copy2 = ctx->feed_streams == 2 ? ctx->feed_copy2 : ctx->feed_copy;
+    int k = 0;
+    for (size_t o = 0; o < bytes; o += FEED_PIECE, k++)
+        HIPCHK(hipMemcpyAsync(dst + o, src + o, std::min<size_t>(FEED_PIECE, bytes - o), hipMemcpyHostToDevice, (k & 1) ? copy2 : copy));
+    if (copy2 != copy) {
+        HIPCHK(hipEventRecord(ctx->feed_mid, copy2));
+        HIPCHK(hipStreamWaitEvent(copy, ctx->feed_mid, 0));
+    }
+    HIPCHK(hipEventRecord(ctx->feed_up[kc & 1], copy));
+    return 0;
+}
+
+static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, int w, const lfdmi_catalog *cat,
+                       const lfdmi_rs_params *rs, const lfdmi_params *bright, const lfdmi_params *dim,
+                       lfdmi_result *results, int loc) {
     RET(check_shape(ctx, n, h, w));
     RET(check_params(ctx, bright, false));
     RET(check_params(ctx, dim, true));
+    float *frames = (float *)frames_v;
     if (!frames || !results) return fail(ctx, LFDMI_ERR_ARG, "NULL argument");
+    if (dtype != LFDMI_F32 && dtype != LFDMI_F32_BE) return fail(ctx, LFDMI_ERR_DTYPE, "lfdmi_detect_batch_raw: frames must be LFDMI_F32 or LFDMI_F32_BE");
+    if (loc != LFDMI_HOST && loc != LFDMI_DEVICE && loc != LFDMI_HOST_PINNED) return fail(ctx, LFDMI_ERR_ARG, "bad loc");
+    const bool be = dtype == LFDMI_F32_BE;
+    if (be && loc == LFDMI_DEVICE) return fail(ctx, LFDMI_ERR_ARG, "big-endian frames must be host frames (they are swapped in the library's device copy)");
+    const bool pinned = loc == LFDMI_HOST_PINNED;
+    if (pinned) loc = LFDMI_HOST; // (everything below but the upload treats them as host frames)
     if (!hough_fits(ctx, h, w, bright->houghMethod, LFD_PI / 180) || !hough_fits(ctx, h, w, dim->houghMethod, LFD_PI / 180)) {
         lfdmi_ctx *sp = get_spill(ctx); // rho finer than this workspace's accumulators: the worst-case one takes the call
         if (!sp || !hough_fits(sp, h, w, bright->houghMethod, LFD_PI / 180) || !hough_fits(sp, h, w, dim->houghMethod, LFD_PI / 180))
             return fail(ctx, LFDMI_ERR_CAPACITY, "Hough accumulator larger than the workspace (rho < 1 px)");
-        int rc = lfdmi_detect_batch(sp, frames, n, h, w, cat, rs, bright, dim, results, loc);
+        int rc = detect_impl(sp, frames, dtype, n, h, w, cat, rs, bright, dim, results, pinned ? LFDMI_HOST_PINNED : loc);
         if (rc) ctx->err = sp->err;
         return rc;
     }
@@ -1935,11 +2018,11 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
     // (feed_* above), chunk k+1 uploading while chunk k is processed.  Device frames (LFDMI_FEED_MB=0, tiny batches):
     // chunks of G frames, used in place / staged by the runtime.
     int per = ctx->G;
-    const bool feed = loc == LFDMI_HOST && ctx->feed_chunk_bytes > 0 && (size_t)n * N * 4 >= (64u << 20);
-    if (feed) {
-        size_t fpc = ctx->feed_chunk_bytes / (N * 4);
+    const bool feed = !pinned && loc == LFDMI_HOST && ctx->feed_chunk_bytes > 0 && (size_t)n * N * 4 >= (64u << 20);
+    if (feed || pinned) {
+        size_t fpc = (ctx->feed_chunk_bytes ? ctx->feed_chunk_bytes : (size_t)(800u << 20)) / (N * 4);
         per = (int)std::min<size_t>((size_t)ctx->G, std::max<size_t>(1, fpc));
-        RET(feed_prepare(ctx, (size_t)std::min(per, n) * N * 4));
+        RET(feed_prepare(ctx, (size_t)std::min(per, n) * N * 4, feed));
     }
     FeedState fs;
     std::thread blotter; // remove_stars on the caller's host array (see blot_host_frames)
@@ -1952,8 +2035,9 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
             if (feed) { (void)hipStreamSynchronize(c->feed_copy); (void)hipStreamSynchronize(c->feed_copy2); }
             if (b->joinable()) b->join();
         }
-    } feed_join{ctx, &fs, &blotter, feed};
+    } feed_join{ctx, &fs, &blotter, feed || pinned};
     if (feed) feed_start(ctx, &fs, (const char *)frames, N * 4, n, per);
+    if (pinned && n > 0) RET(pinned_upload(ctx, (const char *)frames, (size_t)std::min(per, n) * N * 4, 0));
     const int fail_chunk = ctx->fail_chunk;
     ctx->fail_chunk = -1;
     for (int c0 = 0, kc = 0; c0 < n; c0 += per, kc++) {
@@ -1963,7 +2047,15 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
         if (feed) {
             d = ctx->feed_dev[kc & 1];
             RET(feed_wait(ctx, &fs, kc)); // the launch stream waits for chunk kc's upload (chunk kc + 1 follows it back to back)
+        } else if (pinned) {
+            // chunk kc + 1 goes on its way before chunk kc's kernels are enqueued (its device buffer was chunk kc - 1's, whose
+            // passes have been synchronised), so the DMA engines and the compute units overlap
+            d = ctx->feed_dev[kc & 1];
+            if (c0 + per < n)
+                RET(pinned_upload(ctx, (const char *)frames + (size_t)(c0 + per) * N * 4, (size_t)std::min(per, n - c0 - per) * N * 4, kc + 1));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->feed_up[kc & 1], 0));
         } else RET(in_ptr(ctx, frames, (size_t)c0 * N * 4, (size_t)nc * N * 4, loc, &d));
+        if (be) RET(run_bswap(ctx, (void *)d, (size_t)nc * N * 4));
         const bool host_blot = cat && loc == LFDMI_HOST && cat->loc == LFDMI_HOST;
         if (cat) {
             RET(run_removestars(ctx, (float *)d, c0, nc, h, w, cat, rs, host_blot ? &boxes : nullptr));
@@ -2029,7 +2121,7 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
                 lfdmi_ctx *sp = get_spill(ctx);
                 if (sp) {
                     if (blotter.joinable()) blotter.join(); // (a host frame is read again below: its blotting must be complete)
-                    int rc = lfdmi_detect_batch(sp, frames + (size_t)(c0 + i) * N, 1, h, w, nullptr, nullptr, bright, dim, &results[c0 + i], loc);
+                    int rc = detect_impl(sp, frames + (size_t)(c0 + i) * N, dtype, 1, h, w, nullptr, nullptr, bright, dim, &results[c0 + i], loc);
                     if (rc) { ctx->err = sp->err; return rc; }
                     ctx->n_spilled++;
                     continue;
@@ -2039,6 +2131,44 @@ extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, i
             results[c0 + i] = host[i];
         }
     }
+    return 0;
+}
+
+extern "C" int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w, const lfdmi_catalog *cat,
+                                  const lfdmi_rs_params *rs, const lfdmi_params *bright, const lfdmi_params *dim,
+                                  lfdmi_result *results, int loc) {
+    return detect_impl(ctx, frames, LFDMI_F32, n, h, w, cat, rs, bright, dim, results, loc);
+}
+extern "C" int lfdmi_detect_batch_raw(lfdmi_ctx *ctx, void *frames, int dtype, int n, int h, int w, const lfdmi_catalog *cat,
+                                      const lfdmi_rs_params *rs, const lfdmi_params *bright, const lfdmi_params *dim,
+                                      lfdmi_result *results, int loc) {
+    return detect_impl(ctx, frames, dtype, n, h, w, cat, rs, bright, dim, results, loc);
+}
+
+// pinned host memory for LFDMI_HOST_PINNED frames: allocated (and first touched) by a thread bound to the CPUs next to the GPU
+extern "C" int lfdmi_host_alloc(lfdmi_ctx *ctx, uint64_t bytes, void **out) {
+    if (!ctx || !out || bytes == 0) return fail(ctx, LFDMI_ERR_ARG, "lfdmi_host_alloc: bad argument");
+    *out = nullptr;
+    if (!ctx->feed_cpus_known) { ctx->feed_cpus = numa_cpus(ctx->device); ctx->feed_cpus_known = true; }
+    hipError_t herr = hipSuccess;
+    void *p = nullptr;
+    std::thread alloc([&] {
+        bind_thread(ctx->feed_cpus);
+        herr = hipSetDevice(ctx->device);
+        if (herr == hipSuccess) herr = hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault);
+        if (herr == hipSuccess && !ctx->feed_cpus.empty())
+            for (size_t o = 0; o < (size_t)bytes; o += 4096) ((volatile char *)p)[o] = 0;
+    });
+    alloc.join();
+    HIPCHK(herr);
+    *out = p;
+    return 0;
+}
+extern "C" int lfdmi_host_free(lfdmi_ctx *ctx, void *p) {
+    if (!p) return 0;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) return fail(ctx, LFDMI_ERR_HIP, std::string("hipHostFree: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -195,6 +195,105 @@ def _load_many(ids):
     return out
 
 
+def _frame_shape(keys):
+    """(h, w) of the first frame of the selection that can be opened (SDSS frames are all 1489 x 2048; a selection none of
+    whose files exists gets the SDSS shape and one errors entry per frame)."""
+    from .loader import card_value, header_end
+    for key in keys[:64]:
+        run, camcol, flt, field = key
+        try:
+            path = sdssfiles.filename("frame", run=run, camcol=camcol, field=field, filter=flt)
+            if os.path.exists(path):
+                with open(path, "rb") as f:
+                    head = f.read(16 * fitslite.BLOCK)
+            elif os.path.exists(path + ".bz2"):
+                with bz2.open(path + ".bz2", "rb") as f:
+                    head = f.read(16 * fitslite.BLOCK)
+            else:
+                continue
+            end = header_end(head)
+            if end > 0 and card_value(head[:end], b"NAXIS") == 2:
+                return int(card_value(head[:end], b"NAXIS2")), int(card_value(head[:end], b"NAXIS1"))
+        except Exception:  # noqa: BLE001 - the frame's own error is logged when its turn comes
+            continue
+    return 1489, 2048
+
+
+def process_loaded(results, errors, loaded, params_bright, params_dim, params_removestars):
+    """process_fields_batched for a chunk the loader pool has read (``loader.Loaded``): the frames that sit in pinned memory
+    go to the GPU as contiguous same-filter slices of that memory (no copy on the host), the others take the per-frame path;
+    rows and errors entries come out in the caller's order, each frame under its own try (detecttrails.py:119-139)."""
+    from ..catalogs import pack_catalogs
+    from .loader import header_values
+    from .removestars import _check_finite
+    debug = params_bright.get("debug") or params_dim.get("debug")
+    n = len(loaded.keys)
+    rows = [None] * n
+    by_slot = {}
+    for i in range(n):
+        if loaded.error[i] is not None:
+            rows[i] = loaded.error[i]
+            continue
+        try:
+            cat = loaded.cat[i]
+            if cat is not None and len(cat["NOBSERVE"]):
+                _check_finite(cat)                    # math.ceil(nan) in the reference: this frame's error alone
+        except Exception as e:  # noqa: BLE001
+            rows[i] = e
+            continue
+        if loaded.slot[i] >= 0:
+            by_slot[loaded.slot[i]] = i
+    # maximal runs of neighbouring slots with one filter
+    slots = sorted(by_slot)
+    runs, start = [], 0
+    for j in range(1, len(slots) + 1):
+        if j == len(slots) or slots[j] != slots[j - 1] + 1 or loaded.keys[by_slot[slots[j]]][2] != loaded.keys[by_slot[slots[start]]][2]:
+            runs.append(slots[start:j])
+            start = j
+    h, w = loaded.buffer.shape[1:] if loaded.buffer is not None else (0, 0)
+    for run_slots in runs:
+        idx = [by_slot[sl] for sl in run_slots]
+        flt = loaded.keys[idx[0]][2]
+        try:
+            packed = pack_catalogs([loaded.cat[i] for i in idx])
+            frames = loaded.buffer[run_slots[0]:run_slots[-1] + 1]
+            with use_context(h, w, inflight=min(256, len(idx))) as ctx:
+                recs = ctx.detect_batch(frames, params_bright, params_dim, packed, _rs_struct(flt, params_removestars), pinned=True)
+            for i, rec in zip(idx, recs):
+                rows[i] = rec
+        except Exception:  # noqa: BLE001 - a call-level failure: every frame of the slice on its own, under its own try
+            for sl, i in zip(run_slots, idx):
+                try:
+                    img = loaded.buffer[sl].astype(_np.float32)
+                    rows[i] = process_frame_arrays(img, loaded.cat[i], flt, params_bright, params_dim, params_removestars)[2]
+                except Exception as e:  # noqa: BLE001
+                    rows[i] = e
+    for i in range(n):
+        if rows[i] is None and loaded.array[i] is not None:      # not a plain float32 image of the chunk's shape
+            try:
+                rows[i] = process_frame_arrays(loaded.array[i], loaded.cat[i], loaded.keys[i][2], params_bright, params_dim,
+                                               params_removestars)[2]
+            except Exception as e:  # noqa: BLE001
+                rows[i] = e
+    for i, key in enumerate(loaded.keys):
+        try:
+            rec = rows[i]
+            if isinstance(rec, Exception):
+                raise rec
+            status = int(rec["status"])
+            if status == _native.ERR_NOLINES:
+                raise TypeError("'NoneType' object is not subscriptable")
+            if status:
+                raise _native.NativeError(status, "frame failed on the device")
+            if rec["found"]:
+                shape = loaded.array[i].shape if loaded.array[i] is not None else (h, w)
+                res = dictify_hough(shape, (_np.float32(rec["rho"]), _np.float32(rec["theta"])))
+                head = " ".join(str(x) for x in (*key, *header_values(loaded.hdr[i], _HEADER_KEYS)))
+                results.write(f"{head} {res['x1']} {res['y1']} {res['x2']} {res['y2']}\n")
+        except Exception as e:  # noqa: BLE001
+            _log_error(errors, key, e, debug)
+
+
 class DetectTrails:
     """Process a selection of SDSS frames.
 
@@ -303,18 +402,26 @@ class DetectTrails:
         elif pick == "field":
             yield self._run, self._camcol, self._filter, self._field
 
-    def process(self, batch=32, rank=None, world_size=None):
+    def process(self, batch=32, rank=None, world_size=None, loader_threads=None):
         """Run the selection; results and errors files are opened in append mode.
 
-        ``batch`` frames go to the GPU per call (same rows, same order as frame by frame; ``batch=1`` is the
-        reference's frame-at-a-time loop); while the GPU works on one chunk a reader thread already decodes the
-        FITS / bz2 files of the next one.  With ``world_size`` > 1 (default: $RANK / $WORLD_SIZE, i.e. one process
-        per GPU under torchrun) every rank processes one contiguous block of the selection
-        (``lfd_amd.batch.shard_bounds``: ceil(n / world_size) frames each, the same rule the batch detector and
-        bench.py use) and appends to ``<results>.rank<r>`` / ``<errors>.rank<r>`` -- the replacement for splitting
-        runs into PBS jobs (lfd/createjobs/createjobs.py:173-202)."""
+        At most ``batch`` frames go to the GPU per call (same rows, same order as frame by frame; ``batch=1`` is the
+        reference's frame-at-a-time loop).  A pool of ``loader_threads`` reader threads (default: one per core, at most 32;
+        $LFD_LOADER_THREADS) reads the FITS / .fits.bz2 files of the next chunk straight into page-locked staging memory
+        while the GPU works on the current one (``loader.FrameLoader``; chunks of min(batch, $LFD_LOADER_SLOTS = 64) frames:
+        two 0.8 GB staging buffers keep the link busy, larger ones only cost set-up time); the big-endian floats are swapped
+        on the device.  With ``world_size`` > 1 (default: $RANK / $WORLD_SIZE, i.e. one process per GPU under torchrun) every
+        rank processes one contiguous block of the selection (``lfd_amd.batch.shard_bounds``: ceil(n / world_size) frames
+        each, the same rule the batch detector and bench.py use) and appends to ``<results>.rank<r>`` / ``<errors>.rank<r>``
+        -- the replacement for splitting runs into PBS jobs (lfd/createjobs/createjobs.py:173-202).
+
+        ``self.last_stats`` afterwards: frames, total seconds, set-up seconds (context + staging buffers) and the seconds
+        after which every chunk was done."""
+        import time
         from concurrent.futures import ThreadPoolExecutor
         from ..batch import shard_range
+        from .loader import FrameLoader
+        t_start = time.perf_counter()
         rank = int(os.environ.get("RANK", 0)) if rank is None else rank
         world_size = int(os.environ.get("WORLD_SIZE", 1)) if world_size is None else world_size
         suffix = f".rank{rank}" if world_size > 1 else ""
@@ -322,16 +429,30 @@ class DetectTrails:
         if world_size > 1:
             a, b = shard_range(len(keys), rank, world_size)
             keys = keys[a:b]
+        self.last_stats = {"frames": len(keys), "chunk_frames": 0, "setup_s": 0.0, "chunk_done_s": [], "seconds": 0.0}
         with open(self.results + suffix, "a") as results, open(self.errors + suffix, "a") as errors:
             if batch <= 1:
                 for key in keys:
                     process_field(results, errors, *key, self.params_bright, self.params_dim, self.params_removestars)
+                self.last_stats["seconds"] = time.perf_counter() - t_start
                 return
-            chunks = [keys[i:i + batch] for i in range(0, len(keys), batch)]
-            with ThreadPoolExecutor(1) as reader:
-                nxt = reader.submit(_load_many, chunks[0]) if chunks else None
-                for i, chunk in enumerate(chunks):
-                    loaded = nxt.result()
-                    nxt = reader.submit(_load_many, chunks[i + 1]) if i + 1 < len(chunks) else None
-                    process_fields_batched(results, errors, chunk, self.params_bright, self.params_dim,
-                                           self.params_removestars, loaded=loaded)
+            slots = max(1, min(batch, int(os.environ.get("LFD_LOADER_SLOTS", 64)), len(keys)))
+            chunks = [keys[i:i + slots] for i in range(0, len(keys), slots)]
+            if not chunks:
+                return
+            shape = _frame_shape(keys)
+            with use_context(*shape, inflight=slots) as ctx:
+                loader = FrameLoader(ctx, shape, slots, loader_threads)
+            self.last_stats.update(chunk_frames=slots, setup_s=time.perf_counter() - t_start)
+            try:
+                with ThreadPoolExecutor(1, thread_name_prefix="lfd-chunk") as coord:
+                    nxt = coord.submit(loader.load, chunks[0], 0)
+                    for i, chunk in enumerate(chunks):
+                        loaded = nxt.result()
+                        # (buffer (i + 1) & 1 held chunk i - 1, whose GPU call has returned: it is free to be refilled)
+                        nxt = coord.submit(loader.load, chunks[i + 1], (i + 1) & 1) if i + 1 < len(chunks) else None
+                        process_loaded(results, errors, loaded, self.params_bright, self.params_dim, self.params_removestars)
+                        self.last_stats["chunk_done_s"].append(time.perf_counter() - t_start)
+            finally:
+                loader.close()
+                self.last_stats["seconds"] = time.perf_counter() - t_start

@@ -105,7 +105,11 @@ _BITPIX = {8: ">u1", 16: ">i2", 32: ">i4", 64: ">i8", -32: ">f4", -64: ">f8"}
 
 def read_image(path, with_header=True):
     """Primary-HDU image as a native-endian numpy array (float32 for SDSS frames) + header dict."""
-    buf = _load(path)
+    return read_image_bytes(_load(path), path, with_header)
+
+
+def read_image_bytes(buf, path="<bytes>", with_header=True):
+    """read_image on the (decompressed) bytes of a FITS file."""
     hdr, off = _read_header(buf, 0)
     if hdr.get("NAXIS", 0) < 2:
         raise ValueError(f"{path}: primary HDU holds no image")

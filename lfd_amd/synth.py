@@ -158,6 +158,76 @@ def make_portable_frame(k, shape=(512, 768), n_star=40, with_catalog=True):
     return img, cat, truth
 
 
+# ---- a synthetic $BOSS tree (tests, bench.py's dropin leg) ----------------------------------------------------------
+BOSS_HEADER = {"TAI": 4649973000.5, "CRPIX1": 1025.0, "CRPIX2": 745.0, "CRVAL1": 10.5, "CRVAL2": -1.25,
+               "CD1_1": 1e-4, "CD1_2": 2e-5, "CD2_1": -2e-5, "CD2_2": 1e-4}
+
+
+def write_boss_tree(root, frames, cats, run=94, camcol=1, filter="r", field0=100, bz2_all=False, bz2_fields=(), threads=None,
+                    rerun=301, link_to=None):
+    """Write ``frames[i]`` / ``cats[i]`` as field ``field0 + i`` of (run, camcol, filter) in the directory layout the
+    reference reads (docs/source/lfd/setup.rst:9-22: $BOSS_PHOTOOBJ/frames/<rerun>/<run>/<camcol>/frame-*.fits[.bz2],
+    $BOSS_PHOTOOBJ/<rerun>/<run>/<camcol>/photoObj-*.fits, $PHOTO_REDUX/runList.par), point the two environment variables
+    at it and return the header values every frame file carries.  ``cats[i] is None``: no photoObj file for that field.
+    ``link_to`` = M > len(frames): fields field0 + len(frames) .. field0 + M - 1 are hard links of the written files (field
+    field0 + i repeats frame i % len(frames)): a long run for throughput measurements without M distinct frames."""
+    import bz2
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from .detecttrails import fitslite, sdssfiles
+    root = str(root)
+    redux = os.path.join(root, "photo", "redux")
+    os.makedirs(redux, exist_ok=True)
+    n = len(frames)
+    total = max(n, int(link_to or 0))
+    with open(os.path.join(redux, "runList.par"), "w") as f:
+        f.write("typedef struct {\n int run;\n char rerun[];\n int exist;\n int done;\n int calib;\n int startfield;\n"
+                " int endfield;\n char machine[];\n char disk[];\n} RUNDATA;\n\n"
+                f"RUNDATA {run} {rerun} 1 1 1 {field0} {field0 + total} m d\n")
+    os.environ["PHOTO_REDUX"] = redux
+    os.environ["BOSS_PHOTOOBJ"] = os.path.join(root, "photoObj")
+    sdssfiles._runlist_cache.clear()
+    fdir = os.path.dirname(sdssfiles.filename("frame", run, camcol, field0, filter, rerun=rerun))
+    pdir = os.path.dirname(sdssfiles.filename("photoObj", run, camcol, field0, rerun=rerun))
+    os.makedirs(fdir, exist_ok=True)
+    os.makedirs(pdir, exist_ok=True)
+    packed = set(bz2_fields)
+
+    def one(i):
+        field = field0 + i
+        fpath = sdssfiles.filename("frame", run, camcol, field, filter, rerun=rerun)
+        if bz2_all or field in packed:
+            tmp = fpath + ".tmp"
+            fitslite.write_image(tmp, frames[i], BOSS_HEADER)
+            with open(tmp, "rb") as f, open(fpath + ".bz2", "wb") as g:
+                g.write(bz2.compress(f.read()))
+            os.remove(tmp)
+        else:
+            fitslite.write_image(fpath, frames[i], BOSS_HEADER)
+        if cats[i] is not None:
+            cols = dict(cats[i])
+            m = len(cols["NOBSERVE"])
+            cols["OBJC_TYPE"] = np.zeros(m, np.int32)
+            cols["TYPE"] = np.zeros((m, 5), np.int32)
+            fitslite.write_table(sdssfiles.filename("photoObj", run, camcol, field, rerun=rerun), cols)
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    with ThreadPoolExecutor(max(1, min(threads or cores, 32))) as ex:
+        list(ex.map(one, range(n)))
+    for j in range(n, total):
+        i = j % n
+        for kind, flt in (("frame", filter), ("photoObj", None)):
+            src = sdssfiles.filename(kind, run, camcol, field0 + i, flt, rerun=rerun)
+            dst = sdssfiles.filename(kind, run, camcol, field0 + j, flt, rerun=rerun)
+            for ext in ("", ".bz2"):
+                if os.path.exists(src + ext):
+                    os.link(src + ext, dst + ext)
+    return dict(BOSS_HEADER)
+
+
 # ---- many frames at once (bench.py, tools/) -------------------------------------------------------
 _TOOL_ENV = ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_LIBRARY")
 

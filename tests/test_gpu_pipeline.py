@@ -508,3 +508,43 @@ def test_host_feed_error_path_returns_promptly_and_leaves_the_context_usable(ora
         assert again.tobytes() == good.tobytes()
     for i in (0, 1, 5):
         assert same(good[i], oracle.detect_frame(frames[i].copy(), pb, pd, cats[i], rs_o))
+
+
+def test_big_endian_and_pinned_frames(oracle, monkeypatch):
+    """lfdmi_detect_batch_raw: the raw big-endian data unit of a FITS image (LFDMI_F32_BE), as ordinary host memory (staged:
+    the small-batch path and the pinned double-buffer feed) and in memory from lfdmi_host_alloc (LFDMI_HOST_PINNED: uploaded
+    in place, several chunks), gives the records of the native float32 frames; remove_stars blots the caller's big-endian
+    frames exactly where it blots the native ones."""
+    from lfd_amd import _native, synth
+    monkeypatch.setenv("LFDMI_FEED_MB", "40")                           # chunks of three SDSS-size frames
+    pb, pd, prs = params()
+    rs_g, rs_o = rs_pair(oracle, prs)
+    frames, cats = zip(*[synth.make_frame(k)[:2] for k in range(8)])
+    batch = np.stack(frames)
+    packed = synth.pack_catalogs(list(cats))
+    with _native.Context(0, 1489, 2048, 4) as ctx:
+        want = ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g)
+        blotted = batch.copy()
+        ctx.detect_batch(blotted, pb, pd, packed, rs_g)
+        be = batch.astype(">f4")
+        got = ctx.detect_batch(be, pb, pd, packed, rs_g)                # 97 MB: the staged feed
+        assert got.tobytes() == want.tobytes()
+        assert np.array_equal(be.astype(np.float32), blotted)           # the zero fill is byte-order neutral
+        small = batch[:2].astype(">f4")
+        assert ctx.detect_batch(small, pb, pd, {k: v[:2] for k, v in packed.items()}, rs_g).tobytes() == want[:2].tobytes()
+        pin = ctx.pinned_buffer(be.nbytes)
+        try:
+            view = pin.array.view(">f4").reshape(be.shape)
+            view[...] = batch
+            got = ctx.detect_batch(view, pb, pd, packed, rs_g, pinned=True)
+            assert got.tobytes() == want.tobytes()
+            assert np.array_equal(view.astype(np.float32), blotted)
+            one = ctx.detect_batch(view[5], pb, pd, None, None, pinned=True)   # a single pinned (blotted) frame, no catalogue
+            nat = pin.array.view(np.float32).reshape(be.shape)          # native floats in pinned memory
+            nat[...] = batch
+            assert ctx.detect_batch(nat, pb, pd, packed, rs_g, pinned=True).tobytes() == want.tobytes()
+            del view, nat
+        finally:
+            pin.close()
+    assert same(one[0], oracle.detect_frame(np.ascontiguousarray(blotted[5]), pb, pd))
+    assert same(want[3], oracle.detect_frame(frames[3].copy(), pb, pd, cats[3], rs_o))
