@@ -57,6 +57,9 @@ __device__ __forceinline__ void lds_union(int *L, int a, int b) {
     }
 }
 
+// (Taking the items four at a time -- all of a block's loads issued back to back, the next block's list entries fetched
+// meanwhile -- measured 5-7 % SLOWER for both per-frame kernels: their phases are bound by the LDS label chains and the
+// memory-side atomics of the slot updates, not by the exposed HBM round trips, and the extra live registers cost more.)
 template <class Item, class LoadF, class ProcF>
 __device__ __forceinline__ void frame_pipeline(const int *wl, int nwork, LoadF load, ProcF proc) {
     int it = threadIdx.x;
@@ -88,7 +91,7 @@ struct FgWordItem { int idx, id0; u64 c, cp, m; };
 __global__ void __launch_bounds__(FRAME_THREADS)
 k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_fg, const int *counters, int *Lf, int *YMf,
            int *FLf, int *ROWf, u64 *edge, int h, int w, int run_cap, int lds_cap, const int *active, int *fallback,
-           int *pass_flags) {
+           int *pass_flags, int lds_n) { // lds_n: entries of the label table this launch allocated (a multiple of 32, >= lds_cap)
     const int g = blockIdx.x;
     if (slot_off(active, counters, g)) {
         if (threadIdx.x == 0) fallback[g] = 0;
@@ -105,8 +108,8 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
     if (!fits) return;
     extern __shared__ int sm_frame[];
     int *L = sm_frame;
-    unsigned *FL = (unsigned *)(sm_frame + FRAME_RUNCAP); // root holds a strong pixel
-    unsigned *HB = FL + FRAME_RUNCAP / 32;               // run touches a run of the next row
+    unsigned *FL = (unsigned *)(sm_frame + lds_n);       // root holds a strong pixel
+    unsigned *HB = FL + lds_n / 32;                      // run touches a run of the next row
     int *YMg = YMf + ro, *ROWg = ROWf + ro;
     const u64 *fb = cand + fo, *mb = strong + fo;
     const int *sf = scanf + fo, *wl = wl_fg + fo;
@@ -281,7 +284,8 @@ struct ExtItem { int idx, id0, sbc, sbu, sbd; u64 e, ep, en, c, cp, u, up, d, dp
 // kept in LDS.  Same tables, same values (the order of the keys is as arbitrary as before).
 __global__ void __launch_bounds__(FRAME_THREADS)
 k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, int4 *keys, int *bigkeys, int *medkeys, int2 *rowext,
-                 int2 *rsa, int h, int w, int key_cap, int slot_cap, int lds_cap, const int *active, int *fallback, int *pass_flags, long long *prof) {
+                 int2 *rsa, int h, int w, int key_cap, int slot_cap, int lds_cap, const int *active, int *fallback, int *pass_flags, long long *prof,
+                 int lds_n) {
     // developer profile (prof != nullptr): wall-clock ticks (10 ns) at the end of every phase, per frame
     const long long t0 = prof ? wall_clock64() : 0;
     int pk = 0;
@@ -307,10 +311,10 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
     if (!fits) return;
     extern __shared__ int sm_frame[];
     int *L = sm_frame;
-    unsigned *FL = (unsigned *)(sm_frame + FRAME_RUNCAP); // root touches the frame (outside)
-    unsigned *HB = FL + FRAME_RUNCAP / 32;               // run touches a 0-run of the next row
-    unsigned *HL = HB + FRAME_RUNCAP / 32;               // run belongs to a hole
-    unsigned *HR = HL + FRAME_RUNCAP / 32;               // run is the root of a hole
+    unsigned *FL = (unsigned *)(sm_frame + lds_n);       // root touches the frame (outside)
+    unsigned *HB = FL + lds_n / 32;                      // run touches a 0-run of the next row
+    unsigned *HL = HB + lds_n / 32;                      // run belongs to a hole
+    unsigned *HR = HL + lds_n / 32;                      // run is the root of a hole
     int *YMg = YMb + ro, *ROWg = ROWb + ro;
     int *XSg = t.PAb + ro; // scratch until the hole keys are made: PAb[root] = first column of the hole
     const u64 *fb = edge + fo;
@@ -534,7 +538,16 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
         }
     }
     __syncthreads(); // rsa, the hole table, SBb / PAb of this frame are written
-    for (int i = n_outer_slots + threadIdx.x; i < min(c_slots, slot_cap); i += FRAME_THREADS) re[i] = make_int2(0x7fffffff, -1);
+    // Row extremes are min / max updates of (slot.x, slot.y), two per edge stretch and hole contact: as memory-side atomics they
+    // were 40 % of this kernel.  The label table only uses its first nrun entries, so when the frame's slots fit into the rest
+    // of it (they do on sky frames: a few thousand slots, 8 bytes each) the updates go to LDS and are copied out once at the end.
+    const int n_slots = min(c_slots, slot_cap);
+    int *SL = L + ((nrun + 1) & ~1);                       // (x, y) pairs; 8-byte aligned
+    const bool lds_slots = 2 * n_slots <= lds_n - ((nrun + 1) & ~1) && c_ovf == 0;
+    if (lds_slots) {
+        for (int i = threadIdx.x; i < n_slots; i += FRAME_THREADS) { SL[2 * i] = 0x7fffffff; SL[2 * i + 1] = -1; }
+    } else
+        for (int i = n_outer_slots + threadIdx.x; i < n_slots; i += FRAME_THREADS) re[i] = make_int2(0x7fffffff, -1);
     __syncthreads(); // every slot is initialised before the first update
     FRAME_PROF(); // 6: hole keys
     // ---- per-row extremes: every edge run widens its component's outer-border key, and the
@@ -546,7 +559,11 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
     // (the inside of their own ring); the memory-side atomics are what this phase is short of.
     struct SlotAcc { int slot, lo, hi; };
     auto acc_flush = [&](SlotAcc &a) {
-        if (a.slot >= 0) slot_update(re, a.slot, a.lo, a.hi);
+        if (a.slot >= 0) {
+            if (lds_slots) {
+                if ((unsigned)a.slot < (unsigned)n_slots) { atomicMin(&SL[2 * a.slot], a.lo); atomicMax(&SL[2 * a.slot + 1], a.hi); }
+            } else slot_update(re, a.slot, a.lo, a.hi);
+        }
         a.slot = -1;
     };
     auto acc_add = [&](SlotAcc &a, int slot, int xa, int xb) {
@@ -652,6 +669,8 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
             acc_flush(hole);
         });
     __syncthreads();
+    if (lds_slots)
+        for (int i = threadIdx.x; i < n_slots; i += FRAME_THREADS) re[i] = make_int2(SL[2 * i], SL[2 * i + 1]);
     FRAME_PROF(); // 7: extremes
     if (threadIdx.x == 0) {
         int *cnt = counters + g * C_COUNT;

@@ -7,10 +7,9 @@
 #include "../../include/lfdmi.h"
 
 // ------------------------------------------------------------------------------------------
-// remove_stars: one workgroup per catalogue object; lane 0 evaluates the catalogue tests of
-// removestars.py:213-230 (math.ceil of every column, cap test, pairwise-difference count,
-// Petrosian square size, NOBSERVE == NDETECT), all lanes zero-fill the axis-swapped,
-// Python-slice-clipped square img[x-d:x+d, y-d:y+d] (x = COLC on axis 0).
+// remove_stars: the catalogue tests of removestars.py:213-230 (math.ceil of every column, cap test,
+// pairwise-difference count, Petrosian square size, NOBSERVE == NDETECT) per object, then the zero fill of
+// the axis-swapped, Python-slice-clipped square img[x-d:x+d, y-d:y+d] (x = COLC on axis 0).
 // ------------------------------------------------------------------------------------------
 struct RsDev {
     int defaultxy, maxxy, magcount, filter_index;
@@ -23,16 +22,17 @@ __device__ __forceinline__ void py_slice(long start, long stop, long len, int *a
     *a = (int)start; *b = (int)stop;
 }
 
-// one WAVE per catalogue object (four per workgroup, no workgroup barrier): lane 0 evaluates the
-// tests, the wave zero-fills the square row by row
+// Two kernels.  k_rs_boxes: a LANE per catalogue object evaluates the tests (coalesced column loads, every lane busy) and leaves
+// the square to blot -- rows [x, y) x columns [z, w), empty for an object that stays -- in `boxes`.  k_rs_fill: a WAVE per
+// object (four per workgroup, no barrier) zero-fills its square row by row.  (One kernel doing both kept 63 lanes of every
+// wave waiting behind lane 0's chain of dependent column loads and double-precision tests before the first store.)
 __global__ void __launch_bounds__(256)
-k_removestars(float *frames, int h, int w, int max_obj, const int *count, const float *rowc,
-              const float *colc, const float *psfmag, const float *petro90, const int *nobserve,
-              const int *ndetect, RsDev p, int4 *boxes) {
-    int f = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (i >= count[f]) return;
+k_rs_boxes(int h, int w, int max_obj, const int *count, const float *rowc, const float *colc, const float *psfmag,
+           const float *petro90, const int *nobserve, const int *ndetect, RsDev p, int4 *boxes) {
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= max_obj) return;
     int r0 = 0, r1 = 0, c0 = 0, c1 = 0;
-    if (lane == 0) {
+    if (i < count[f]) {
         size_t o5 = ((size_t)f * max_obj + i) * 5, o1 = (size_t)f * max_obj + i;
         int fi = p.filter_index;
         long x = (long)ceil((double)colc[o5 + fi]);
@@ -58,10 +58,16 @@ k_removestars(float *frames, int h, int w, int max_obj, const int *count, const 
             py_slice(y - dxy, y + dxy, w, &c0, &c1);
         }
     }
-    r0 = __builtin_amdgcn_readfirstlane(r0); r1 = __builtin_amdgcn_readfirstlane(r1);
-    c0 = __builtin_amdgcn_readfirstlane(c0); c1 = __builtin_amdgcn_readfirstlane(c1);
-    // the square, for a caller whose frames live in host memory (it blots its own copy: lfdmi.hip)
-    if (boxes && lane == 0) boxes[(size_t)f * max_obj + i] = make_int4(r0, r1, c0, c1);
+    boxes[(size_t)f * max_obj + i] = make_int4(r0, r1, c0, c1);
+}
+
+__global__ void __launch_bounds__(256)
+k_rs_fill(float *frames, int h, int w, int max_obj, const int *count, const int4 *boxes) {
+    int f = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= max_obj) return;
+    const int4 bx = boxes[(size_t)f * max_obj + i]; // (one address per wave: a broadcast load)
+    const int r0 = __builtin_amdgcn_readfirstlane(bx.x), r1 = __builtin_amdgcn_readfirstlane(bx.y);
+    const int c0 = __builtin_amdgcn_readfirstlane(bx.z), c1 = __builtin_amdgcn_readfirstlane(bx.w);
     int nc = c1 - c0;
     if (r1 <= r0 || nc <= 0) return;
     float *img = frames + (size_t)f * h * w;

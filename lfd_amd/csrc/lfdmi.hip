@@ -126,7 +126,7 @@ struct lfdmi_ctx {
     size_t feed_chunk_bytes = 800u << 20; // largest feed chunk (LFDMI_FEED_MB): 64 SDSS frames, 11 frames of 4096 x 4096
     std::vector<int> feed_cpus;        // CPUs local to the GPU (numa_cpus): feed / blot threads and the pinned buffers are bound to them
     int fail_chunk = -1;               // lfdmi_debug_fail_chunk: the next lfdmi_detect_batch call fails at the top of this chunk (tests)
-    int4 *rs_boxes = nullptr;          // remove_stars squares of the chunk (host-frame path)
+    int4 *rs_boxes = nullptr;          // remove_stars squares of the chunk (k_rs_boxes -> k_rs_fill, and the host's own blotting)
     size_t rs_boxes_cap = 0;
     void *stage = nullptr;
     size_t stage_bytes = 0;
@@ -166,6 +166,8 @@ struct lfdmi_ctx {
     bool general_seen = false, general_on = true;
     bool frame_ccl = true;             // per-frame LDS connectivity kernels (k_frame.h)
     int frame_runcap = FRAME_RUNCAP;   // runs per frame they take (LFDMI_FRAME_RUNCAP lowers it: tests of the fallback path)
+    int frame_lds = FRAME_RUNCAP;      // entries of their LDS label table (LFDMI_FRAME_LDS: a smaller table leaves LDS to other kernels
+                                       // on the CU; frames with more runs take the general kernels)
     int *tile_list = nullptr;          // per slot: active 64 x 16 tiles of the pass image (k_dc_tiles -> k_dilate_canny_t)
     int tile_cap = 0;
     bool dc_specialize = true;         // LFDMI_DC_SPECIALIZE=0: the run-time-size instantiation of k_dilate_canny_t for every kernel size
@@ -299,6 +301,10 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_VOTE_SPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->vote_split = v; }
     if (const char *e = getenv("LFDMI_PE_ROWS")) { int v = atoi(e); if (v >= 2 && v <= 64) ctx->pe_rows = v; }
     if (const char *e = getenv("LFDMI_FRAME_RUNCAP")) { int v = atoi(e); if (v >= 0 && v < FRAME_RUNCAP) ctx->frame_runcap = v; }
+    if (const char *e = getenv("LFDMI_FRAME_LDS")) {
+        int v = atoi(e);
+        if (v >= 32 && v <= FRAME_RUNCAP) { ctx->frame_lds = (v + 31) & ~31; ctx->frame_runcap = std::min(ctx->frame_runcap, ctx->frame_lds); }
+    }
     if (const char *e = getenv("LFDMI_DC_SUBSTRIPS")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->dc_substrips = v; }
     if (const char *e = getenv("LFDMI_DC_STRIP")) { int v = atoi(e); if (v >= 1 && v <= DCW_MAXS) ctx->dc_strip = v; } // tuning knob
     if (const char *e = getenv("LFDMI_DC_TILELIST")) ctx->dc_tilelist = atoi(e) != 0;
@@ -717,10 +723,10 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
     }
     if (ctx->frame_ccl) { // frames that fit the LDS tables; the rest (fallback flag) take the kernels below
         Span sp(ctx, KID_FRAME_FG);
-        size_t lds = (size_t)(FRAME_RUNCAP + 2 * (FRAME_RUNCAP / 32)) * sizeof(int);
+        size_t lds = (size_t)(ctx->frame_lds + 2 * (ctx->frame_lds / 32)) * sizeof(int);
         k_frame_fg<<<nc, FRAME_THREADS, lds, ctx->stream>>>(ctx->candb, ctx->strongb, ctx->scanf_, ctx->wl_fg, ctx->counters, ctx->Lf,
                                                             ctx->YMf, ctx->FLf, ctx->ROWf, ctx->edgeb, h, w, rc, ctx->frame_runcap, active, ctx->fb_fg,
-                                                            ctx->pass_flags);
+                                                            ctx->pass_flags, ctx->frame_lds);
         KCHK("k_frame_fg");
         if (!ctx->general_on) return 0; // (a frame that did not fit raises PASS_FLAG_GENERAL: the caller runs the chunk again)
         active = ctx->fb_fg;
@@ -872,10 +878,11 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     const int *gen = active; // frames for the general run kernels
     if (ctx->frame_ccl) {
         Span sp(ctx, KID_FRAME_BG);
-        size_t lds = (size_t)(FRAME_RUNCAP + 4 * (FRAME_RUNCAP / 32)) * sizeof(int);
+        size_t lds = (size_t)(ctx->frame_lds + 4 * (ctx->frame_lds / 32)) * sizeof(int);
         k_frame_contours<<<nc, FRAME_THREADS, lds, ctx->stream>>>(rt, ctx->wl_fg, ctx->wl_bg, ctx->counters, ctx->keys, ctx->bigkeys,
                                                                   ctx->medkeys, ctx->rowext, ctx->rsa, h, w, ctx->key_cap, ctx->slot_cap,
-                                                                  ctx->frame_runcap, active, ctx->fb_bg, ctx->pass_flags, ctx->dc_profile ? nullptr : ctx->prof);
+                                                                  ctx->frame_runcap, active, ctx->fb_bg, ctx->pass_flags, ctx->dc_profile ? nullptr : ctx->prof,
+                                                                  ctx->frame_lds);
         KCHK("k_frame_contours");
         gen = ctx->fb_bg;
     }
@@ -1549,22 +1556,21 @@ static int run_removestars(lfdmi_ctx *ctx, float *frames_dev, int f0, int nc, in
     RsDev p;
     p.defaultxy = rs->defaultxy; p.maxxy = rs->maxxy; p.magcount = rs->magcount; p.filter_index = rs->filter_index;
     p.pixscale = rs->pixscale; p.maxmagdiff = rs->maxmagdiff; p.filter_cap = rs->filter_cap;
-    int4 *boxes = nullptr;
-    if (host_boxes) { // the blotted squares come back instead of the blotted frames
-        size_t need = (size_t)nc * cat->max_obj;
-        if (ctx->rs_boxes_cap < need) {
-            if (ctx->rs_boxes) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(ctx->rs_boxes)); ctx->rs_boxes = nullptr; ctx->rs_boxes_cap = 0; }
-            HIPCHK(hipMalloc(&ctx->rs_boxes, need * sizeof(int4)));
-            ctx->rs_boxes_cap = need;
-        }
-        boxes = ctx->rs_boxes;
-        host_boxes->resize(need);
+    size_t need = (size_t)nc * cat->max_obj;
+    if (ctx->rs_boxes_cap < need) {
+        if (ctx->rs_boxes) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(ctx->rs_boxes)); ctx->rs_boxes = nullptr; ctx->rs_boxes_cap = 0; }
+        HIPCHK(hipMalloc(&ctx->rs_boxes, need * sizeof(int4)));
+        ctx->rs_boxes_cap = need;
     }
+    int4 *boxes = ctx->rs_boxes;
+    if (host_boxes) host_boxes->resize(need); // the blotted squares come back instead of the blotted frames
     {
         Span sp(ctx, KID_REMOVESTARS);
-        k_removestars<<<dim3((cat->max_obj + 3) / 4, nc), 256, 0, ctx->stream>>>(frames_dev, h, w, cat->max_obj, dev.count, dev.rowc, dev.colc,
-                                                                       dev.psfmag, dev.petro90, dev.nobserve, dev.ndetect, p, boxes);
-        KCHK("k_removestars");
+        k_rs_boxes<<<dim3((cat->max_obj + 255) / 256, nc), 256, 0, ctx->stream>>>(h, w, cat->max_obj, dev.count, dev.rowc, dev.colc, dev.psfmag,
+                                                                               dev.petro90, dev.nobserve, dev.ndetect, p, boxes);
+        KCHK("k_rs_boxes");
+        k_rs_fill<<<dim3((cat->max_obj + 3) / 4, nc), 256, 0, ctx->stream>>>(frames_dev, h, w, cat->max_obj, dev.count, boxes);
+        KCHK("k_rs_fill");
     }
     if (host_boxes)
         HIPCHK(hipMemcpyAsync(host_boxes->data(), boxes, host_boxes->size() * sizeof(int4), hipMemcpyDeviceToHost, ctx->stream));

@@ -619,9 +619,9 @@ int lfo_fill_poly(uint8_t *img, int h, int w, const int32_t *v, int npts, uint8_
     poly_edge *edges = (poly_edge *)malloc((size_t)npts * sizeof(poly_edge));
     int total = 0;
     if (!edges) return -1;
-    int64_t p0x = (int64_t)v[2 * (npts - 1)] << XY_SHIFT, p0y = v[2 * (npts - 1) + 1];
+    int64_t p0x = (int64_t)v[2 * (npts - 1)] * XY_ONE, p0y = v[2 * (npts - 1) + 1]; /* (a multiplication: << of a negative value is undefined in C99) */
     for (int i = 0; i < npts; i++) {
-        int64_t p1x = (int64_t)v[2 * i] << XY_SHIFT, p1y = v[2 * i + 1];
+        int64_t p1x = (int64_t)v[2 * i] * XY_ONE, p1y = v[2 * i + 1];
         int64_t t0x = (p0x + (XY_ONE >> 1)) >> XY_SHIFT, t1x = (p1x + (XY_ONE >> 1)) >> XY_SHIFT;
         draw_line8(img, h, w, t0x, p0y, t1x, p1y, color);
         if (p0y != p1y) {

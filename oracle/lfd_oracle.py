@@ -59,8 +59,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_SO)
+        alt = os.environ.get("LFD_ORACLE_LIB")   # an instrumented build of the same source (tools/oracle_sanitize.sh)
+        if not alt:
+            build()
+        _lib = C.CDLL(alt or _SO)
         _lib.lfo_free.argtypes = [C.c_void_p]
         _lib.lfo_free.restype = None
     return _lib

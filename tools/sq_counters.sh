@@ -6,8 +6,8 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${1:-sq}
 mkdir -p $O
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/p1 -- python3 bench.py --cpu-sample 0 --steps 2 --no-host-leg > /dev/null 2> $O/p1.err
-rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/p2 -- python3 bench.py --cpu-sample 0 --steps 2 --no-host-leg > /dev/null 2> $O/p2.err
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/p1 -- python3 bench.py --cpu-sample 0 --steps 2 --no-host-leg --no-secondary > /dev/null 2> $O/p1.err
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/p2 -- python3 bench.py --cpu-sample 0 --steps 2 --no-host-leg --no-secondary > /dev/null 2> $O/p2.err
 python3 - "$O" > $O/sq_counters.txt <<'PY'
 import csv, glob, sys, collections
 O = sys.argv[1]
