@@ -226,7 +226,8 @@ int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w,
 /* lfdmi_detect_batch with the frames' element type given: LFDMI_F32, or LFDMI_F32_BE for HOST / HOST_PINNED frames holding the
  * big-endian data unit of a FITS image as read from the file (DetectTrails.process reads frame files straight into pinned
  * memory and leaves the byte swap to the device: detecttrails.py:73-117 is a read + swap + copy per frame in the reference).
- * remove_stars' zero fill of the caller's frames is byte-order neutral. */
+ * Big-endian frames are treated as a read-only input: remove_stars blots the library's device copy only (the caller's
+ * bytes are a file's data unit; LFDMI_F32 frames are blotted in place as in lfdmi_detect_batch). */
 int lfdmi_detect_batch_raw(lfdmi_ctx *ctx, void *frames, int dtype, int n, int h, int w,
                            const lfdmi_catalog *cat, const lfdmi_rs_params *rs,
                            const lfdmi_params *bright, const lfdmi_params *dim, lfdmi_result *results,
@@ -236,6 +237,23 @@ int lfdmi_detect_batch_raw(lfdmi_ctx *ctx, void *frames, int dtype, int n, int h
  * (any live ctx of the same device, or NULL). */
 int lfdmi_host_alloc(lfdmi_ctx *ctx, uint64_t bytes, void **out);
 int lfdmi_host_free(lfdmi_ctx *ctx, void *p);
+/* ---- FITS ingest on host threads (detecttrails.py:73-117 reads a frame with fitsio.read, removestars.py:96-104 the photoObj
+ * columns) -- no GPU involved; plain files only (a .fits.bz2 is decompressed by the caller) ----
+ * lfdmi_fits_read_frames: the primary-HDU data units of n files into dst (n x h x w big-endian float32 slots, e.g. memory
+ * from lfdmi_host_alloc) with `threads` reader threads.  status[i]: 0 = BITPIX -32, NAXIS 2, h x w, no BSCALE / BZERO: the data
+ * unit is in slot i as it is in the file; 1 = a FITS file of another kind (slot untouched: use a general reader); -1 = cannot
+ * be opened; -2 = truncated / malformed.  hdr (may be NULL): the raw header of file i (80-byte cards up to its padded END
+ * block) is copied to hdr + i * hdr_cap, hdr_len[i] = its full length (> hdr_cap: the copy is cut). */
+int lfdmi_fits_read_frames(const char *const *paths, int n, int h, int w, void *dst, int threads, int32_t *status, char *hdr,
+                           int hdr_cap, int32_t *hdr_len);
+/* lfdmi_fits_read_photoobj: ROWC, COLC, PSFMAG, PETROTH90 (float32[5] per object) and NOBSERVE, NDETECT (integers) of the
+ * binary table in HDU 1 of n files into the padded lfdmi_catalog arrays in host memory ([n][max_obj][5] / [n][max_obj]) and
+ * count[n].  status[i]: 0 ok; 2 / 3 = ok but a float column holds a NaN / an infinity (math.ceil raises on those in
+ * removestars.py:113-130: the caller makes it that frame's error); 1 = declined (more than max_obj rows, scaled columns,
+ * another column layout: use a general reader); -1 cannot be opened; -2 malformed; -3 a wanted column is missing. */
+int lfdmi_fits_read_photoobj(const char *const *paths, int n, int max_obj, float *rowc, float *colc, float *psfmag,
+                             float *petro90, int32_t *nobserve, int32_t *ndetect, int32_t *count, int threads,
+                             int32_t *status);
 /* Which calls keep the 8-bit stage images (gray, eroded, equalised+dilated: what the reference's debug PNGs show) for
  * lfdmi_get_stage.  mode -1 (default): the per-pass entry points (lfdmi_process_bright / _dim / _multiscale) do,
  * lfdmi_detect_batch does not; 0: no call does (batches through the per-pass entry points: an image per frame less to

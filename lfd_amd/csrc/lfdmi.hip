@@ -28,6 +28,7 @@
 #include "k_image.h"
 #include "k_rect.h"
 #include "k_frame.h"
+#include "fits_reader.h"
 
 #define LFD_PI 3.1415926535897932384626433832795
 #define MAX_ANGLES 4096 // rows of the cos/sin table (theta >= pi/4096)
@@ -2062,10 +2063,12 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->feed_up[kc & 1], 0));
         } else RET(in_ptr(ctx, frames, (size_t)c0 * N * 4, (size_t)nc * N * 4, loc, &d));
         if (be) RET(run_bswap(ctx, (void *)d, (size_t)nc * N * 4));
-        const bool host_blot = cat && loc == LFDMI_HOST && cat->loc == LFDMI_HOST;
+        // (raw big-endian frames are a file's data unit, a read-only input: only the device copy is blotted -- no squares come
+        // back, no mid-call synchronisation, no host threads)
+        const bool host_blot = cat && loc == LFDMI_HOST && cat->loc == LFDMI_HOST && !be;
         if (cat) {
             RET(run_removestars(ctx, (float *)d, c0, nc, h, w, cat, rs, host_blot ? &boxes : nullptr));
-            if (loc == LFDMI_HOST && !host_blot) RET(out_copy(ctx, frames, (size_t)c0 * N * 4, d, (size_t)nc * N * 4, loc));
+            if (loc == LFDMI_HOST && !host_blot && !be) RET(out_copy(ctx, frames, (size_t)c0 * N * 4, d, (size_t)nc * N * 4, loc));
             if (host_blot) {
                 double t0_ = feed && getenv("LFDMI_FEED_TRACE") ? feed_now() : 0;
                 HIPCHK(hipStreamSynchronize(ctx->stream)); // the squares are on the host; the passes are enqueued next

@@ -1,32 +1,37 @@
-"""Frame ingest for ``DetectTrails.process``: a pool of reader threads that puts the frames of a chunk straight into the
-library's page-locked staging memory.
+"""Frame ingest for ``DetectTrails.process``: the files of a chunk go straight into the library's page-locked staging memory,
+read by native threads.
 
 The reference reads one frame at a time with ``fitsio`` (detecttrails.py:73-117: decompress a ``.bz2`` to ``$FITS_DUMP`` if
-need be, ``fitsio.read`` -- a read, a byte swap and a copy --, then the photoObj table, removestars.py:96-104) between two
-GPU-sized pieces of work.  Here the file bytes of a ``BITPIX = -32`` image are the big-endian float32 frame, so a reader
-thread parses the header, ``readinto``s the data unit into its slot of a pinned buffer (``bz2.decompress`` + one copy for
-``.fits.bz2``) and the library uploads that memory in place and swaps the bytes on the device
-(``lfdmi_detect_batch_raw(..., LFDMI_F32_BE, ..., LFDMI_HOST_PINNED)``).  ``open`` / ``readinto`` / ``bz2`` / large numpy
-copies release the GIL, so the pool scales with the cores; what stays under the GIL per frame is a header scan and the
-column views of the photoObj table (~0.2 ms).  Two pinned buffers: chunk k + 1 is read while chunk k is on the GPU.
+need be, ``fitsio.read`` -- a read, a byte swap and a copy --, then the photoObj table and a Python loop over its rows,
+removestars.py:96-130) between two GPU-sized pieces of work.  Here the file bytes of a ``BITPIX = -32`` image ARE the
+big-endian float32 frame, so ``lfdmi_fits_read_frames`` (lfd_amd/csrc/fits_reader.h) lets a pool of C++ threads scan the
+headers and ``pread`` the data units into the slots of a pinned buffer, ``lfdmi_fits_read_photoobj`` puts the six catalogue
+columns remove_stars uses into the padded arrays the GPU call takes, and the library uploads the pinned memory in place and
+swaps the bytes on the device (``lfdmi_detect_batch_raw(..., LFDMI_F32_BE, ..., LFDMI_HOST_PINNED)``).  Two pinned buffers:
+chunk k + 1 is read while chunk k is on the GPU.  No per-frame Python runs on the fast path: an earlier version with Python
+reader threads (``readinto`` + header scans) read as fast but held the interpreter lock 0.3 ms per frame, which doubled the
+time of the thread driving the GPU.
 
-Frames this fast path cannot take (other BITPIX, BSCALE / BZERO, a different shape) are read by ``fitslite`` and returned as
-native float32 arrays for the ordinary per-frame path; a missing file is that frame's error, as in the reference.
+What the native readers decline comes back here: ``.fits.bz2`` frames (``bz2.decompress`` in a small thread pool, then the
+same slot), other BITPIX / BSCALE / BZERO / shapes and unusual photoObj layouts (``fitslite``, then the ordinary per-frame
+path); a missing file is that frame's error, as in the reference.
 """
 import bz2
+import ctypes as C
 import os
-import re
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
+from .. import _native
 from . import fitslite, sdssfiles
 
 BLOCK = fitslite.BLOCK
 _END = b"END" + b" " * 77
-_TCARD = re.compile(rb"(TFORM|TTYPE)(\d+) *= *'([^']*)'")
 _CAT5 = ("ROWC", "COLC", "PSFMAG", "PETROTH90")
 _CAT1 = ("NOBSERVE", "NDETECT")
+HDR_CAP = 8 * BLOCK          # raw header bytes kept per frame (SDSS frame headers are three to four blocks)
+MAX_OBJ = 4096               # catalogue rows per field the padded arrays hold (photoObj fields have a few hundred to ~2 000)
 
 
 def header_end(buf, start=0):
@@ -54,88 +59,30 @@ def card_value(hdr, key):
         pos = i + 1
 
 
-def read_catalog(path):
-    """The six photoObj columns remove_stars uses (removestars.py:97-104 reads eight; OBJC_TYPE and TYPE are never looked at)
-    as native arrays: ROWC / COLC / PSFMAG / PETROTH90 [n, 5] float32, NOBSERVE / NDETECT [n] int32.  One regex pass over the
-    table header instead of a card-by-card parse."""
-    with open(path, "rb", buffering=0) as f:
-        buf = f.read()
-    e0 = header_end(buf, 0)
-    if e0 < 0:
-        raise ValueError(f"{path}: truncated FITS header")
-    primary = buf[:e0]
-    naxis = card_value(primary, b"NAXIS") or 0
-    off = e0
-    if naxis:
-        n = abs(card_value(primary, b"BITPIX")) // 8
-        for i in range(1, naxis + 1):
-            n *= card_value(primary, b"NAXIS%d" % i)
-        off += (n + BLOCK - 1) // BLOCK * BLOCK
-    e1 = header_end(buf, off)
-    if e1 < 0:
-        raise ValueError(f"{path}: truncated FITS header")
-    hdr = buf[off:e1]
-    if str(card_value(hdr, b"XTENSION") or "").strip() != "BINTABLE":
-        raise ValueError(f"{path}: extension 1 is not a binary table")
-    row_bytes, nrows, nf = card_value(hdr, b"NAXIS1"), card_value(hdr, b"NAXIS2"), card_value(hdr, b"TFIELDS")
-    forms, names = [None] * (nf + 1), {}
-    for kind, idx, val in _TCARD.findall(hdr):
-        i = int(idx)
-        if i > nf:
-            continue
-        if kind == b"TFORM":
-            forms[i] = val.strip()
-        else:
-            names[val.strip().upper().decode("ascii", "replace")] = i
-    want = {names.get(c) for c in _CAT5 + _CAT1}
-    if None in want:
-        raise KeyError(f"{path}: missing columns {sorted(c for c in _CAT5 + _CAT1 if c not in names)}")
-    out, pos = {}, 0
-    inv = {i: c for c, i in names.items() if i in want}
-    for i in range(1, nf + 1):
-        form = forms[i]
-        if form is None:
-            raise ValueError(f"{path}: TFORM{i} missing")
-        j = 0
-        while j < len(form) and 48 <= form[j] <= 57:
-            j += 1
-        rep = int(form[:j]) if j else 1
-        code = chr(form[j])
-        if code in "PQ":
-            width = (8 if code == "P" else 16) * rep
-        elif code == "X":
-            width = (rep + 7) // 8
-        elif code in "CM":
-            width = (8 if code == "C" else 16) * rep
-        else:
-            dt, size = fitslite._TFORM[code]
-            width = size * rep
-            if i in inv:
-                if hdr.find(b"TSCAL%d" % i) >= 0 or hdr.find(b"TZERO%d" % i) >= 0:
-                    return None                              # scaled columns: the general reader handles them
-                name = inv[i]
-                col = np.ndarray((nrows, rep), dt, buf, e1 + pos, (row_bytes, np.dtype(dt).itemsize))
-                out[name] = col.astype(np.float32 if name in _CAT5 else np.int32)
-                if name in _CAT1:
-                    out[name] = out[name][:, 0]
-        pos += width
-    return out
+def header_values(hdr, keys):
+    """The header values of ``keys`` from raw header bytes (fast path) or a parsed dict, as fitslite would give them."""
+    if isinstance(hdr, dict):
+        return [hdr[k] for k in keys]
+    vals = []
+    for k in keys:
+        v = card_value(hdr, k.encode("ascii"))
+        if v is None:
+            raise KeyError(k)
+        vals.append(v)
+    return vals
 
 
-def _catalog(run, camcol, field):
-    path = sdssfiles.filename("photoObj", run=run, camcol=camcol, field=field)
-    cat = read_catalog(path)
-    if cat is None:
-        from .removestars import read_photoObj_arrays
-        cat = read_photoObj_arrays(path)
-    return cat
+def _paths(strings):
+    arr = (C.c_char_p * len(strings))()
+    arr[:] = [os.fsencode(s) for s in strings]
+    return arr
 
 
 class Loaded:
-    """What the pool made of one chunk: ``keys`` in the caller's order; for key i either ``slot[i]`` >= 0 (its raw
-    big-endian frame is slot ``slot[i]`` of the pinned buffer), or ``array[i]`` (a native float32 frame for the ordinary
-    path), or ``error[i]`` (the exception the reference would have logged); ``hdr[i]`` = raw header bytes (fast path) or
-    the parsed dict; ``cat[i]`` = photoObj columns."""
+    """What the loader made of one chunk: ``keys`` in the caller's order; for key i either ``slot[i]`` >= 0 (its raw
+    big-endian frame is slot ``slot[i]`` of the pinned buffer ``buffer`` and its catalogue row ``slot[i]`` of ``cats``), or
+    ``array[i]`` (a native float32 frame for the ordinary per-frame path, catalogue in ``cat[i]``), or ``error[i]`` (the
+    exception the reference would have logged); ``hdr[i]`` = raw header bytes or a parsed dict."""
 
     def __init__(self, keys):
         n = len(keys)
@@ -146,24 +93,42 @@ class Loaded:
         self.hdr = [None] * n
         self.cat = [None] * n
         self.buffer = None                                   # [slots, h, w] '>f4' view of the pinned memory
+        self.cats = None                                     # padded catalogue arrays of the buffer's slots + "count"
+
+    def cat_of(self, i):
+        """photoObj columns of key i as a dict of arrays (what the per-frame path takes)."""
+        if self.cat[i] is not None or self.slot[i] < 0:
+            return self.cat[i]
+        s = self.slot[i]
+        m = int(self.cats["count"][s])
+        return {k: self.cats[k][s, :m] for k in _CAT5 + _CAT1}
 
 
 class FrameLoader:
-    """``threads`` readers, two pinned buffers of ``slots`` frames of ``shape`` each (allocated through ``ctx``)."""
+    """``threads`` native reader threads, two pinned buffers of ``slots`` frames of ``shape`` (allocated through ``ctx``)."""
 
-    def __init__(self, ctx, shape, slots, threads=None):
+    def __init__(self, ctx, shape, slots, threads=None, max_obj=MAX_OBJ):
         self.shape = tuple(shape)
         self.slots = int(slots)
+        self.max_obj = int(max_obj)
         h, w = self.shape
         self.frame_bytes = h * w * 4
         try:
             cores = len(os.sched_getaffinity(0))
         except (AttributeError, OSError):
             cores = os.cpu_count() or 1
-        self.threads = int(threads or os.environ.get("LFD_LOADER_THREADS", 0) or max(2, min(32, cores)))
+        self.threads = int(threads or os.environ.get("LFD_LOADER_THREADS", 0) or max(2, min(16, cores)))
+        self.lib = _native.lib()
         self.pins = [ctx.pinned_buffer(self.slots * self.frame_bytes) for _ in range(2)]
         self.views = [p.array.view(">f4").reshape(self.slots, h, w) for p in self.pins]
-        self.pool = ThreadPoolExecutor(self.threads, thread_name_prefix="lfd-loader")
+        self.cats = []
+        for _ in range(2):
+            c = {k: np.zeros((self.slots, self.max_obj, 5), np.float32) for k in _CAT5}
+            c.update({k: np.zeros((self.slots, self.max_obj), np.int32) for k in _CAT1})
+            c["count"] = np.zeros(self.slots, np.int32)
+            self.cats.append(c)
+        self.hdrs = [np.zeros((self.slots, HDR_CAP), np.uint8) for _ in range(2)]
+        self.pool = ThreadPoolExecutor(max(2, min(self.threads, 16)), thread_name_prefix="lfd-bz2")   # .bz2 frames and other exceptions
 
     def close(self):
         self.pool.shutdown(wait=True)
@@ -178,105 +143,127 @@ class FrameLoader:
     def __exit__(self, *a):
         self.close()
 
-    # -- one frame ------------------------------------------------------------------------------------------------
-    def _read_frame(self, key, dst_u8):
-        """Frame ``key`` into ``dst_u8`` (this slot's bytes) when the file is a plain big-endian float32 image of the expected
-        shape: returns (True, raw header bytes).  Otherwise (False, (native float32 array, header dict))."""
-        run, camcol, flt, field = key
-        path = sdssfiles.filename("frame", run=run, camcol=camcol, field=field, filter=flt)
-        if os.path.exists(path):
-            with open(path, "rb", buffering=0) as f:
-                head = f.read(4 * BLOCK)
-                end = header_end(head)
-                while end < 0:
-                    more = f.read(4 * BLOCK)
-                    if not more:
-                        raise ValueError("truncated FITS header")
-                    head += more
-                    end = header_end(head)
-                if len(head) < end:
-                    head += f.read(end - len(head))
-                    if len(head) < end:
-                        raise ValueError("truncated FITS header")
-                hdr = head[:end]
-                if self._fast(hdr):
-                    got = len(head) - end                    # data bytes that came with the header read
-                    mv = memoryview(dst_u8)
-                    if got:
-                        k = min(got, self.frame_bytes)
-                        mv[:k] = head[end:end + k]
-                    while got < self.frame_bytes:
-                        r = f.readinto(mv[got:])
-                        if not r:
-                            raise ValueError(f"{path}: file ends inside the image")
-                        got += r
-                    return True, hdr
-            img, h = fitslite.read_image(path)
-            return False, (np.ascontiguousarray(img, dtype=np.float32), h)
-        if not os.path.exists(path + ".bz2"):
-            raise FileNotFoundError(("File {0} or its bz2 compressed version not found. "
-                                     "Are you sure they exist?").format(path))
-        with open(path + ".bz2", "rb", buffering=0) as f:
-            raw = bz2.decompress(f.read())                   # in memory; no $FITS_DUMP round trip (detecttrails.py:88-109)
-        end = header_end(raw)
-        if end < 0 or len(raw) < end:
-            raise ValueError("truncated FITS header")
-        hdr = raw[:end]
-        if self._fast(hdr):
-            if len(raw) < end + self.frame_bytes:
-                raise ValueError(f"{path}.bz2: file ends inside the image")
-            np.copyto(dst_u8, np.frombuffer(raw, np.uint8, self.frame_bytes, end))
-            return True, hdr
-        img, h = fitslite.read_image_bytes(raw, path + ".bz2")
-        return False, (np.ascontiguousarray(img, dtype=np.float32), h)
-
+    # -- exceptions to the fast path ---------------------------------------------------------------------------------
     def _fast(self, hdr):
         h, w = self.shape
         return (card_value(hdr, b"BITPIX") == -32 and card_value(hdr, b"NAXIS") == 2 and card_value(hdr, b"NAXIS1") == w
                 and card_value(hdr, b"NAXIS2") == h and card_value(hdr, b"BSCALE") in (None, 1, 1.0)
                 and card_value(hdr, b"BZERO") in (None, 0, 0.0))
 
-    def _job(self, out, i, slot, dst_u8):
+    def _slow_frame(self, out, i, slot, dst_u8, status):
+        """Frame i was not taken by the native reader (status -1: no plain file; 1: not a plain float32 image; -2: broken)."""
+        run, camcol, flt, field = out.keys[i]
+        path = sdssfiles.filename("frame", run=run, camcol=camcol, field=field, filter=flt)
         try:
-            fast, what = self._read_frame(out.keys[i], dst_u8)
-            if fast:
-                out.slot[i], out.hdr[i] = slot, what
+            if status == -1 and not os.path.exists(path):
+                if not os.path.exists(path + ".bz2"):
+                    raise FileNotFoundError(("File {0} or its bz2 compressed version not found. "
+                                             "Are you sure they exist?").format(path))
+                with open(path + ".bz2", "rb", buffering=0) as f:
+                    raw = bz2.decompress(f.read())           # in memory; no $FITS_DUMP round trip (detecttrails.py:88-109)
+                end = header_end(raw)
+                if end < 0 or len(raw) < end:
+                    raise ValueError("truncated FITS header")
+                if self._fast(raw[:end]):
+                    if len(raw) < end + self.frame_bytes:
+                        raise ValueError(f"{path}.bz2: file ends inside the image")
+                    np.copyto(dst_u8, np.frombuffer(raw, np.uint8, self.frame_bytes, end))
+                    out.slot[i], out.hdr[i] = slot, raw[:end]
+                    return
+                img, h = fitslite.read_image_bytes(raw, path + ".bz2")
             else:
-                out.array[i], out.hdr[i] = what
-            run, camcol, _, field = out.keys[i]
-            out.cat[i] = _catalog(run, camcol, field)
+                img, h = fitslite.read_image(path)           # (raises what the file's defect raises)
+            out.array[i], out.hdr[i] = np.ascontiguousarray(img, dtype=np.float32), h
         except Exception as e:  # noqa: BLE001 - this frame's errors.txt entry (detecttrails.py:133-139)
+            out.error[i] = e
+
+    def _slow_catalog(self, out, i, slot, cats, status, path):
+        try:
+            if status == 2:
+                raise ValueError("cannot convert float NaN to integer")        # math.ceil in removestars.py:113-130
+            if status == 3:
+                raise OverflowError("cannot convert float infinity to integer")
+            from .removestars import read_photoObj_arrays
+            cat = read_photoObj_arrays(path)                 # (missing file, missing columns, ...: raises as the reference's read would)
+            m = len(cat["NOBSERVE"])
+            if m <= self.max_obj and out.slot[i] >= 0:
+                for k in _CAT5 + _CAT1:
+                    cats[k][slot, :m] = cat[k]
+                cats["count"][slot] = m
+            else:                                            # more rows than the padded arrays hold: the per-frame path
+                out.cat[i] = {k: np.asarray(cat[k]) for k in _CAT5 + _CAT1}
+                if out.slot[i] >= 0:
+                    out.array[i] = out.buffer[out.slot[i]].astype(np.float32)
+                    out.slot[i] = -1
+        except Exception as e:  # noqa: BLE001
+            out.error[i] = e
             out.slot[i] = -1
             out.array[i] = None
-            out.error[i] = e
 
     # -- a chunk --------------------------------------------------------------------------------------------------
     def load(self, keys, which):
         """Read ``keys`` (at most ``slots``) into pinned buffer ``which`` (0 / 1).  Frames of one filter get neighbouring slots
         (remove_stars' magnitude cap depends on the filter, so a GPU call takes one filter's frames: a contiguous slice)."""
-        if len(keys) > self.slots:
+        n = len(keys)
+        if n > self.slots:
             raise ValueError("chunk larger than the loader's buffers")
         out = Loaded(keys)
         out.buffer = self.views[which]
+        out.cats = cats = self.cats[which]
         raw = self.pins[which].array
-        order = sorted(range(len(keys)), key=lambda i: keys[i][2])      # stable: the caller's order inside a filter
+        hdrs = self.hdrs[which]
+        order = sorted(range(n), key=lambda i: keys[i][2])          # stable: the caller's order inside a filter
+        fpaths, ppaths = [], []
+        for i in order:
+            run, camcol, flt, field = keys[i]
+            fpaths.append(sdssfiles.filename("frame", run=run, camcol=camcol, field=field, filter=flt))
+            ppaths.append(sdssfiles.filename("photoObj", run=run, camcol=camcol, field=field))
+        h, w = self.shape
+        fstat = np.zeros(n, np.int32)
+        hlen = np.zeros(n, np.int32)
+        pstat = np.zeros(n, np.int32)
+        P = _native._ptr
+        rc = self.lib.lfdmi_fits_read_frames(_paths(fpaths), n, h, w, P(raw), self.threads, P(fstat), P(hdrs), HDR_CAP, P(hlen))
+        if rc:
+            raise _native.NativeError(rc, "lfdmi_fits_read_frames")
+        rc = self.lib.lfdmi_fits_read_photoobj(_paths(ppaths), n, self.max_obj, P(cats["ROWC"]), P(cats["COLC"]), P(cats["PSFMAG"]),
+                                               P(cats["PETROTH90"]), P(cats["NOBSERVE"]), P(cats["NDETECT"]), P(cats["count"]),
+                                               self.threads, P(pstat))
+        if rc:
+            raise _native.NativeError(rc, "lfdmi_fits_read_photoobj")
         futs = []
         for slot, i in enumerate(order):
-            dst = raw[slot * self.frame_bytes:(slot + 1) * self.frame_bytes]
-            futs.append(self.pool.submit(self._job, out, i, slot, dst))
+            st = int(fstat[slot])
+            if st == 0:
+                out.slot[i] = slot
+                if hlen[slot] <= HDR_CAP:
+                    out.hdr[i] = hdrs[slot, :hlen[slot]].tobytes()
+                else:                                        # an unusually long header: read it again, whole
+                    with open(fpaths[slot], "rb") as f:
+                        out.hdr[i] = f.read(int(hlen[slot]))
+            else:
+                dst = raw[slot * self.frame_bytes:(slot + 1) * self.frame_bytes]
+                futs.append(self.pool.submit(self._slow_frame, out, i, slot, dst, st))
         for f in futs:
             f.result()
+        for slot, i in enumerate(order):                     # catalogues (after the frames: a frame error comes first, as in the reference)
+            if out.error[i] is None and pstat[slot] != 0:
+                self._slow_catalog(out, i, slot, cats, int(pstat[slot]), ppaths[slot])
+            if out.error[i] is not None:
+                out.slot[i] = -1
+                out.array[i] = None
         return out
 
 
-def header_values(hdr, keys):
-    """The header values of ``keys`` from raw header bytes (fast path) or a parsed dict, as fitslite would give them."""
-    if isinstance(hdr, dict):
-        return [hdr[k] for k in keys]
-    vals = []
-    for k in keys:
-        v = card_value(hdr, k.encode("ascii"))
-        if v is None:
-            raise KeyError(k)
-        vals.append(v)
-    return vals
+def read_catalog(path, max_obj=MAX_OBJ):
+    """One photoObj file through the native reader: dict of the six columns, or None where it declines (tests, tools)."""
+    lib = _native.lib()
+    c = {k: np.zeros((1, max_obj, 5), np.float32) for k in _CAT5}
+    c.update({k: np.zeros((1, max_obj), np.int32) for k in _CAT1})
+    cnt, st = np.zeros(1, np.int32), np.zeros(1, np.int32)
+    P = _native._ptr
+    rc = lib.lfdmi_fits_read_photoobj(_paths([str(path)]), 1, max_obj, P(c["ROWC"]), P(c["COLC"]), P(c["PSFMAG"]), P(c["PETROTH90"]),
+                                      P(c["NOBSERVE"]), P(c["NDETECT"]), P(cnt), 1, P(st))
+    if rc or st[0] not in (0, 2, 3):
+        return None
+    return {k: c[k][0, :cnt[0]].copy() for k in _CAT5 + _CAT1}

@@ -513,8 +513,8 @@ def test_host_feed_error_path_returns_promptly_and_leaves_the_context_usable(ora
 def test_big_endian_and_pinned_frames(oracle, monkeypatch):
     """lfdmi_detect_batch_raw: the raw big-endian data unit of a FITS image (LFDMI_F32_BE), as ordinary host memory (staged:
     the small-batch path and the pinned double-buffer feed) and in memory from lfdmi_host_alloc (LFDMI_HOST_PINNED: uploaded
-    in place, several chunks), gives the records of the native float32 frames; remove_stars blots the caller's big-endian
-    frames exactly where it blots the native ones."""
+    in place, several chunks), gives the records of the native float32 frames; big-endian frames are a read-only input (only
+    the device copy is blotted), native frames in pinned memory are blotted like any host frames."""
     from lfd_amd import _native, synth
     monkeypatch.setenv("LFDMI_FEED_MB", "40")                           # chunks of three SDSS-size frames
     pb, pd, prs = params()
@@ -529,7 +529,7 @@ def test_big_endian_and_pinned_frames(oracle, monkeypatch):
         be = batch.astype(">f4")
         got = ctx.detect_batch(be, pb, pd, packed, rs_g)                # 97 MB: the staged feed
         assert got.tobytes() == want.tobytes()
-        assert np.array_equal(be.astype(np.float32), blotted)           # the zero fill is byte-order neutral
+        assert np.array_equal(be.astype(np.float32), batch)             # raw file bytes stay as they are
         small = batch[:2].astype(">f4")
         assert ctx.detect_batch(small, pb, pd, {k: v[:2] for k, v in packed.items()}, rs_g).tobytes() == want[:2].tobytes()
         pin = ctx.pinned_buffer(be.nbytes)
@@ -538,11 +538,12 @@ def test_big_endian_and_pinned_frames(oracle, monkeypatch):
             view[...] = batch
             got = ctx.detect_batch(view, pb, pd, packed, rs_g, pinned=True)
             assert got.tobytes() == want.tobytes()
-            assert np.array_equal(view.astype(np.float32), blotted)
-            one = ctx.detect_batch(view[5], pb, pd, None, None, pinned=True)   # a single pinned (blotted) frame, no catalogue
+            assert np.array_equal(view.astype(np.float32), batch)
             nat = pin.array.view(np.float32).reshape(be.shape)          # native floats in pinned memory
             nat[...] = batch
             assert ctx.detect_batch(nat, pb, pd, packed, rs_g, pinned=True).tobytes() == want.tobytes()
+            assert np.array_equal(nat, blotted)                         # ... are blotted in place
+            one = ctx.detect_batch(nat[5], pb, pd, None, None, pinned=True)    # a single pinned (blotted) frame, no catalogue
             del view, nat
         finally:
             pin.close()

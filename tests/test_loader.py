@@ -1,7 +1,8 @@
-"""The frame ingest of DetectTrails.process (lfd_amd/detecttrails/loader.py) without a GPU: the reader pool fills its
-(here: ordinary numpy) staging buffers with the raw big-endian data units of the frame files, groups the frames of a filter
-into neighbouring slots, falls back to the general reader for files the fast path cannot take, and turns missing files into
-per-frame errors (reference flow: detecttrails.py:73-117, removestars.py:96-104)."""
+"""The frame ingest of DetectTrails.process (lfd_amd/detecttrails/loader.py + the native readers of lfd_amd/csrc/fits_reader.h)
+without a GPU: the reader threads fill the (here: ordinary numpy) staging buffers with the raw big-endian data units of the
+frame files and the padded catalogue arrays with the photoObj columns, frames of a filter get neighbouring slots, files the
+fast path declines go through the general reader, and missing files become per-frame errors (reference flow:
+detecttrails.py:73-117, removestars.py:96-130).  The library is only used for its host-side entry points here."""
 import bz2
 import os
 
@@ -49,8 +50,10 @@ def test_chunk_into_staging_memory(tmp_path, monkeypatch):
             assert out.slot[i] >= 0 and out.error[i] is None
             assert np.array_equal(out.buffer[out.slot[i]].astype(np.float32), frames[i])
             assert loader.header_values(out.hdr[i], ["TAI", "CD2_1"]) == [hdr["TAI"], hdr["CD2_1"]]
+            got = out.cat_of(i)
             for k in ("ROWC", "COLC", "PSFMAG", "PETROTH90", "NOBSERVE", "NDETECT"):
-                assert np.array_equal(out.cat[i][k], cats[i][k]) and out.cat[i][k].dtype == cats[i][k].dtype
+                assert np.array_equal(got[k], cats[i][k]) and got[k].dtype == cats[i][k].dtype
+            assert out.cats["count"][out.slot[i]] == len(cats[i]["NOBSERVE"])
         assert isinstance(out.error[3], FileNotFoundError) and "photoObj" in str(out.error[3])
         assert out.slot[4] < 0 and out.error[4] is None
         assert out.array[4].dtype == np.float32 and out.array[4][1, 1] == (96 + 1) * 2.0 + 3.0
@@ -80,8 +83,8 @@ def test_frames_of_one_filter_get_neighbouring_slots(tmp_path):
 
 
 def test_catalog_reader_matches_the_general_one(tmp_path):
-    """loader.read_catalog (one regex pass over the table header) against fitslite.read_table on the astropy-written photoObj
-    fixture (a variable-length column and unrelated columns before the wanted ones)."""
+    """The native photoObj reader against fitslite.read_table on the astropy-written photoObj fixture (a variable-length
+    column and unrelated columns before the wanted ones)."""
     import glob
     fix = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "fits", "photoobj*.fits")))
     assert fix, "photoObj fixture missing"
@@ -105,3 +108,42 @@ def test_header_scan_helpers():
     long = fitslite._finish_header(cards + [fitslite._card("K%d" % i, i) for i in range(40)])
     assert loader.header_end(long + b"\0" * 100) == 2 * 2880
     assert bz2.decompress(bz2.compress(long)) == long
+
+
+def test_native_reader_statuses(tmp_path):
+    """NaN / infinity in a catalogue (math.ceil raises in removestars.py:113-130), more rows than the padded arrays hold, a
+    truncated frame file, a header longer than the kept copy: each handled as the reference's flow would, frame by frame."""
+    frames, cats, hdr = _tree(tmp_path, n=6)
+    from lfd_amd.detecttrails import fitslite as F
+    def rewrite(field, cat):
+        cols = dict(cat)
+        m = len(cols["NOBSERVE"])
+        cols["OBJC_TYPE"] = np.zeros(m, np.int32)
+        cols["TYPE"] = np.zeros((m, 5), np.int32)
+        F.write_table(sdssfiles.filename("photoObj", 94, 1, field), cols)
+    bad = {k: v.copy() for k, v in cats[0].items()}
+    bad["PSFMAG"][2, 3] = np.nan
+    rewrite(100, bad)
+    bad = {k: v.copy() for k, v in cats[1].items()}
+    bad["ROWC"][0, 0] = np.inf
+    rewrite(101, bad)
+    big = {k: np.concatenate([v] * 3) for k, v in cats[2].items()}       # 21 rows > max_obj = 16 below
+    rewrite(102, big)
+    rewrite(103, cats[0])
+    p4 = sdssfiles.filename("frame", 94, 1, 104, "r")                    # truncated inside the image
+    data = open(p4, "rb").read()
+    open(p4, "wb").write(data[:len(data) // 2])
+    long_hdr = dict(hdr, **{"K%03d" % i: float(i) for i in range(300)})   # 9 header blocks > HDR_CAP
+    F.write_image(sdssfiles.filename("frame", 94, 1, 105, "r"), frames[5], long_hdr)
+    keys = [(94, 1, "r", f) for f in range(100, 106)]
+    with loader.FrameLoader(_Ctx(), (64, 96), 8, threads=2, max_obj=16) as ld:
+        out = ld.load(keys, 0)
+    assert isinstance(out.error[0], ValueError) and "NaN" in str(out.error[0])
+    assert isinstance(out.error[1], OverflowError)
+    assert out.error[2] is None and out.slot[2] < 0 and np.array_equal(out.array[2], frames[2])
+    assert len(out.cat_of(2)["NOBSERVE"]) == 21 and np.array_equal(out.cat_of(2)["ROWC"], big["ROWC"])
+    assert out.error[3] is None and out.slot[3] >= 0 and np.array_equal(out.cat_of(3)["COLC"], cats[0]["COLC"])
+    assert out.error[4] is not None and out.slot[4] < 0
+    assert out.slot[5] >= 0 and len(out.hdr[5]) > loader.HDR_CAP
+    assert loader.header_values(out.hdr[5], ["K299", "TAI"]) == [299.0, hdr["TAI"]]
+    assert np.array_equal(out.buffer[out.slot[5]].astype(np.float32), frames[5])
