@@ -489,13 +489,17 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
 // kh rows, and the wave writes zeros for its 4096 pixels with 16-byte stores.  Only for the surviving bits (objects: the
 // sky is zeros and ones at random, P(3 x 3 all non-zero) ~ 1e-6) are the window's values fetched and the minimum stored.
 // The float frames are not read again and the sky costs a few bit operations per 64 pixels.
+#define BE_REP 4
 __global__ void __launch_bounds__(256)
 k_bits_erode(const uint8_t *gsrc, const u64 *dbits, const u64 *nzd, uint8_t *dst, u64 *cellbm, int bm_bands, int h, int w, int kh, int kw,
              const int *active) {
     const int g = blockIdx.y;
     if (active && !active[g]) return;
     const int wq = LFD_WQ(w), nw = h * wq, lane = threadIdx.x & 63;
-    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; // this wave's 64 words
+    // a wave takes BE_REP groups of 64 words one after the other (a wave per 4 KB of output was bound by its own start-up:
+    // 128 000 waves per launch of which all but a few only write zeros)
+    for (int rep = 0; rep < BE_REP; rep++) {
+    const int i0 = ((blockIdx.x * 4 + (threadIdx.x >> 6)) * BE_REP + rep) * 64; // this group's 64 words
     if (i0 >= nw) return;
     const int i = i0 + lane;
     const int ay = kh / 2, ax = kw / 2;
@@ -531,7 +535,7 @@ k_bits_erode(const uint8_t *gsrc, const u64 *dbits, const u64 *nzd, uint8_t *dst
         for (int b = 0; b < nb; b++) d[(size_t)y * w + x0 + b] = 0; // (odd widths are not on the batch path: plain and slow)
     }
     u64 todo = __ballot(e != 0ull);
-    if (todo == 0ull) return;
+    if (todo == 0ull) continue;
     if (e) { // cells of the output (16 x 16 pixels: four per word)
         u64 cells = 0ull;
         for (int c = 0; c < 4; c++)
@@ -588,6 +592,7 @@ k_bits_erode(const uint8_t *gsrc, const u64 *dbits, const u64 *nzd, uint8_t *dst
         }
         __builtin_amdgcn_wave_barrier();
     }
+    } // rep
 }
 
 // histogram only (for lfdmi_equalize_hist on an existing u8 image)

@@ -1129,7 +1129,7 @@ static int run_prep_erode(lfdmi_ctx *ctx, const void *src, int nc, int h, int w,
     if (from_bits) { // the bright pass's image and bit planes instead of the float frames; histogram (hist2) taken there; marks into cellbm2
         Span sp(ctx, KID_BITS_ERODE);
         const int nwords = h * LFD_WQ(w);
-        k_bits_erode<<<dim3((nwords + 255) / 256, nc), 256, 0, ctx->stream>>>(ctx->gray, ctx->dbits, ctx->nzd, ctx->tmp, ctx->cellbm2,
+        k_bits_erode<<<dim3((nwords + 256 * BE_REP - 1) / (256 * BE_REP), nc), 256, 0, ctx->stream>>>(ctx->gray, ctx->dbits, ctx->nzd, ctx->tmp, ctx->cellbm2,
                                                                              ctx->bm_bands, h, w, kh, kw, active);
         KCHK("k_bits_erode");
         return 0;

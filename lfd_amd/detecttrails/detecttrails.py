@@ -405,7 +405,7 @@ class DetectTrails:
         elif pick == "field":
             yield self._run, self._camcol, self._filter, self._field
 
-    def process(self, batch=32, rank=None, world_size=None, loader_threads=None):
+    def process(self, batch=32, rank=None, world_size=None, loader_threads=None, resume=False):
         """Run the selection; results and errors files are opened in append mode.
 
         At most ``batch`` frames go to the GPU per call (same rows, same order as frame by frame; ``batch=1`` is the
@@ -417,6 +417,10 @@ class DetectTrails:
         rank processes one contiguous block of the selection (``lfd_amd.batch.shard_bounds``: ceil(n / world_size) frames
         each, the same rule the batch detector and bench.py use) and appends to ``<results>.rank<r>`` / ``<errors>.rank<r>``
         -- the replacement for splitting runs into PBS jobs (lfd/createjobs/createjobs.py:173-202).
+
+        ``resume=True``: frames listed in ``<results>[.rank<r>].progress`` (appended to, chunk by chunk, after the chunk's rows
+        and error entries have been flushed) are skipped, so a run that was interrupted continues where it stopped instead
+        of appending its rows twice (the reference restarts a PBS job from its first frame).
 
         ``self.last_stats`` afterwards: frames, total seconds, set-up seconds (context + staging buffers) and the seconds
         after which every chunk was done."""
@@ -432,11 +436,29 @@ class DetectTrails:
         if world_size > 1:
             a, b = shard_range(len(keys), rank, world_size)
             keys = keys[a:b]
-        self.last_stats = {"frames": len(keys), "chunk_frames": 0, "setup_s": 0.0, "chunk_done_s": [], "seconds": 0.0}
-        with open(self.results + suffix, "a") as results, open(self.errors + suffix, "a") as errors:
+        progress_path = self.results + suffix + ".progress"
+        skipped = 0
+        if resume and os.path.exists(progress_path):
+            with open(progress_path) as f:
+                done = {tuple(ln.split()) for ln in f if ln.strip()}
+            before = len(keys)
+            keys = [k for k in keys if tuple(str(x) for x in k) not in done]
+            skipped = before - len(keys)
+        self.last_stats = {"frames": len(keys), "chunk_frames": 0, "setup_s": 0.0, "chunk_done_s": [], "seconds": 0.0,
+                           "skipped_by_resume": skipped}
+        with open(self.results + suffix, "a") as results, open(self.errors + suffix, "a") as errors, \
+                open(progress_path, "a") as progress:
+
+            def mark(done_keys):                     # rows first, then the marks: a crash in between repeats a chunk, never loses one
+                results.flush()
+                errors.flush()
+                progress.write("".join("%s %s %s %s\n" % tuple(k) for k in done_keys))
+                progress.flush()
+
             if batch <= 1:
                 for key in keys:
                     process_field(results, errors, *key, self.params_bright, self.params_dim, self.params_removestars)
+                    mark([key])
                 self.last_stats["seconds"] = time.perf_counter() - t_start
                 return
             slots = max(1, min(batch, int(os.environ.get("LFD_LOADER_SLOTS", 64)), len(keys)))
@@ -458,6 +480,7 @@ class DetectTrails:
                         # (buffer (i + 1) & 1 held chunk i - 1, whose GPU call has returned: it is free to be refilled)
                         nxt = coord.submit(loader.load, chunks[i + 1], (i + 1) & 1) if i + 1 < len(chunks) else None
                         process_loaded(results, errors, loaded, self.params_bright, self.params_dim, self.params_removestars)
+                        mark(chunk)
                         self.last_stats["chunk_done_s"].append(time.perf_counter() - t_start)
                         if trace:
                             print("[loader] chunk %d: waited %.1f ms for its files, GPU call + rows %.1f ms" %

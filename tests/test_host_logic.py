@@ -200,3 +200,30 @@ def test_bench_finds_the_committed_traffic_counters():
         nbytes, src = bench.load_traffic(name, cfg)
         assert nbytes and nbytes > 1e6 and src.endswith(".json"), (name, cfg[0])
 
+
+
+def test_resume_skips_frames_already_marked_done(tmp_path, monkeypatch):
+    """process(resume=True) continues an interrupted run: the frames listed in <results>.progress are skipped, rows are not
+    appended twice (frame-at-a-time loop; the chunked loop marks its chunks the same way)."""
+    _write_runlist(tmp_path)
+    monkeypatch.setattr(detecttrails.DetectTrails, "_runInfo", lambda self: (100, 106))
+    calls = []
+
+    def fake_field(results, errors, run, camcol, flt, field, pb, pd, prs):
+        calls.append(field)
+        if field == 103 and len(calls) == 4:
+            raise KeyboardInterrupt                                   # the run is cut short inside its fourth frame
+        results.write("%d %d %s %d row\n" % (run, camcol, flt, field))
+
+    monkeypatch.setattr(detecttrails, "process_field", fake_field)
+    dt = detecttrails.DetectTrails(run=94, camcol=1, filter="r", savepath=str(tmp_path))
+    import pytest
+    with pytest.raises(KeyboardInterrupt):
+        dt.process(batch=1)
+    assert open(dt.results + ".progress").read().split("\n")[:3] == ["94 1 r 100", "94 1 r 101", "94 1 r 102"]
+    dt.process(batch=1, resume=True)
+    assert calls == [100, 101, 102, 103, 103, 104, 105] and dt.last_stats["skipped_by_resume"] == 3
+    rows = [ln.split()[3] for ln in open(dt.results)]
+    assert rows == ["100", "101", "102", "103", "104", "105"]
+    dt.process(batch=1, resume=True)                                  # nothing left
+    assert dt.last_stats["frames"] == 0 and len(calls) == 7
