@@ -22,6 +22,22 @@
 #include "k_ccl.h"
 #include "k_rect.h"
 
+// perm[0 .. na) = the slots with active[slot] != 0 in ascending order, perm[na .. n) = the others: kernels whose workgroup ->
+// frame mapping decides which XCD a frame works on (one workgroup per frame; the tile kernel's frame = f(block % 8)) index the
+// frames through it, so a pass that works on an arbitrary subset of the slots still loads the eight XCDs evenly.
+__global__ void __launch_bounds__(64) k_active_perm(const int *active, int n, int *perm) {
+    const int lane = threadIdx.x;
+    int base = 0;
+    for (int pass = 0; pass < 2; pass++)
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const bool on = i < n && ((active[i] != 0) == (pass == 0));
+            const u64 bal = __ballot(on);
+            if (on) perm[base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+            base += __popcll(bal);
+        }
+}
+
 #define PASS_FLAG_GENERAL 256 // pass_flags bit: this frame needs the general (multi-workgroup) run kernels
 #define FRAME_THREADS 1024
 #define FRAME_HOLECAP 1024 // hash slots for the holes of a frame (more holes: looked up in the global tables)
@@ -91,8 +107,8 @@ struct FgWordItem { int idx, id0; u64 c, cp, m; };
 __global__ void __launch_bounds__(FRAME_THREADS)
 k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_fg, const int *counters, int *Lf, int *YMf,
            int *FLf, int *ROWf, u64 *edge, int h, int w, int run_cap, int lds_cap, const int *active, int *fallback,
-           int *pass_flags, int lds_n) { // lds_n: entries of the label table this launch allocated (a multiple of 32, >= lds_cap)
-    const int g = blockIdx.x;
+           int *pass_flags, int lds_n, const int *perm) { // lds_n: entries of the label table this launch allocated (a multiple of 32, >= lds_cap)
+    const int g = perm ? perm[blockIdx.x] : (int)blockIdx.x; // (active frames first: one workgroup per frame, XCD = workgroup % 8)
     if (slot_off(active, counters, g)) {
         if (threadIdx.x == 0) fallback[g] = 0;
         return;
@@ -285,16 +301,17 @@ struct ExtItem { int idx, id0, sbc, sbu, sbd; u64 e, ep, en, c, cp, u, up, d, dp
 __global__ void __launch_bounds__(FRAME_THREADS)
 k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, int4 *keys, int *bigkeys, int *medkeys, int2 *rowext,
                  int2 *rsa, int h, int w, int key_cap, int slot_cap, int lds_cap, const int *active, int *fallback, int *pass_flags, long long *prof,
-                 int lds_n) {
+                 int lds_n, const int *perm) {
     // developer profile (prof != nullptr): wall-clock ticks (10 ns) at the end of every phase, per frame
     const long long t0 = prof ? wall_clock64() : 0;
     int pk = 0;
-#define FRAME_PROF() do { if (prof && threadIdx.x == 0) prof[blockIdx.x * 8 + (pk++)] = wall_clock64() - t0; } while (0)
+    const int g_prof = perm ? perm[blockIdx.x] : (int)blockIdx.x;
+#define FRAME_PROF() do { if (prof && threadIdx.x == 0) prof[g_prof * 8 + (pk++)] = wall_clock64() - t0; } while (0)
     const u64 *edge = t.edge;
     const int *scanb = t.scanb;
     int *Lb = t.Lb, *YMb = t.YMb, *FLb = t.FLb, *ROWb = t.ROWb;
     const int run_cap = t.run_cap;
-    const int g = blockIdx.x;
+    const int g = perm ? perm[blockIdx.x] : (int)blockIdx.x;
     if (slot_off(active, counters, g)) {
         if (threadIdx.x == 0) fallback[g] = 0;
         return;

@@ -489,15 +489,13 @@ k_prep_erode(const float *src, int h, int w, int flip, int mode, float mf, float
 // kh rows, and the wave writes zeros for its 4096 pixels with 16-byte stores.  Only for the surviving bits (objects: the
 // sky is zeros and ones at random, P(3 x 3 all non-zero) ~ 1e-6) are the window's values fetched and the minimum stored.
 // The float frames are not read again and the sky costs a few bit operations per 64 pixels.
-#define BE_REP 4
+#define BE_REP 1 // groups of 64 words per wave (4 measured 0.33 ms against 0.27: the zero fill wants as many waves in flight as it can get)
 __global__ void __launch_bounds__(256)
 k_bits_erode(const uint8_t *gsrc, const u64 *dbits, const u64 *nzd, uint8_t *dst, u64 *cellbm, int bm_bands, int h, int w, int kh, int kw,
              const int *active) {
     const int g = blockIdx.y;
     if (active && !active[g]) return;
     const int wq = LFD_WQ(w), nw = h * wq, lane = threadIdx.x & 63;
-    // a wave takes BE_REP groups of 64 words one after the other (a wave per 4 KB of output was bound by its own start-up:
-    // 128 000 waves per launch of which all but a few only write zeros)
     for (int rep = 0; rep < BE_REP; rep++) {
     const int i0 = ((blockIdx.x * 4 + (threadIdx.x >> 6)) * BE_REP + rep) * 64; // this group's 64 words
     if (i0 >= nw) return;
@@ -1649,9 +1647,9 @@ __device__ __forceinline__ unsigned dct_cells(const u64 *m, int b0) { // bits b0
 
 __global__ void __launch_bounds__(DCT_THREADS)
 k_dc_tiles(const u64 *cellbm, int bm_bands, const uint8_t *lut, int *tile_list, int tile_cap, int *counters, u64 *equb, u64 *cand,
-           u64 *strong, uint8_t *equ, int h, int w, const int *active) {
+           u64 *strong, uint8_t *equ, int h, int w, const int *active, const int *perm) {
     // grid (frames, fill parts): part 0 builds the frame's tile list, every part writes its share of the background
-    const int g = blockIdx.x;
+    const int g = perm ? perm[blockIdx.x] : (int)blockIdx.x; // (perm: the pass's active frames first, see k_active_perm)
     if (active && !active[g]) return;
     const int fpart = blockIdx.y, fparts = gridDim.y;
     const int tiles_x = (w + CANNY_TW - 1) / CANNY_TW, tiles_y = (h + DCW_TH - 1) / DCW_TH;
@@ -1749,10 +1747,14 @@ template <bool PROF, int KH, int KW>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
 k_dilate_canny_t(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *strong, const uint8_t *lut, int h, int w,
                  int kh, int kw, int low, int high, const int *active, int nc, int parts, const int *tile_list, int tile_cap,
-                 const int *counters, long long *prof) {
+                 const int *counters, long long *prof, const int *perm) {
     int L = blockIdx.x, xcd = L & 7, jb_ = L >> 3;
     int g = (jb_ / parts) * 8 + xcd; // frame = 8 * (j / parts) + (block & 7): a frame's tiles behind one L2
     if (g >= nc) return;
+    // Workgroups go to the eight XCDs round-robin, so frame slot f works on XCD f % 8.  A dim pass only works on the frames the
+    // bright pass left undecided, whatever slots those are (every other slot on the benchmark's frames: four XCDs idle): `perm`
+    // lists the active slots first, so the i-th ACTIVE frame works on XCD i % 8.
+    if (perm) g = perm[g];
     if (active && !active[g]) return;
     const int part = jb_ - (jb_ / parts) * parts;
     const int ntl = counters[g * C_COUNT + C_NTILES];

@@ -101,6 +101,9 @@ struct lfdmi_ctx {
     bool use_cellbm = true;
     int4 *segcnt = nullptr;            // per 64-word segment: run starts, fg / bg list entries (then their exclusive sums)
     int *fb_fg = nullptr, *fb_bg = nullptr; // per slot: frame left to the multi-workgroup run kernels (k_frame.h)
+    int *perm = nullptr;               // k_active_perm: the current pass's active slots first (XCD balance of the per-frame launches)
+    const int *perm_cur = nullptr;     // perm while a pass with an `active` mask runs, nullptr otherwise
+    bool use_perm = true;              // LFDMI_PERM=0: frame slot == workgroup index as before
     lfdmi_result *res_dev = nullptr;   // G x LFDMI_MAX_SCALES records (one block of G per Hough scale)
     // Workspace sizing (include/lfdmi.h: lfdmi_caps).  A compact context keeps a worst-case one for single frames
     // (`spill`, created on first use): a frame whose tables overflow here (per-frame LFDMI_ERR_CAPACITY) is run
@@ -366,6 +369,8 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     ctx->tile_cap = ((max_h + DCW_TH - 1) / DCW_TH) * ((max_w + CANNY_TW - 1) / CANNY_TW);
     RET(dmalloc(ctx, &ctx->tile_list, G * ctx->tile_cap));
     RET(dmalloc(ctx, &ctx->segcnt, G * SCAN_MAX_SEG));
+    RET(dmalloc(ctx, &ctx->perm, G));
+    if (const char *e = getenv("LFDMI_PERM")) ctx->use_perm = atoi(e) != 0;
     RET(dmalloc(ctx, &ctx->fb_fg, G));
     RET(dmalloc(ctx, &ctx->fb_bg, G));
     RET(dmalloc(ctx, &ctx->scanf_, G * BW));
@@ -727,7 +732,7 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
         size_t lds = (size_t)(ctx->frame_lds + 2 * (ctx->frame_lds / 32)) * sizeof(int);
         k_frame_fg<<<nc, FRAME_THREADS, lds, ctx->stream>>>(ctx->candb, ctx->strongb, ctx->scanf_, ctx->wl_fg, ctx->counters, ctx->Lf,
                                                             ctx->YMf, ctx->FLf, ctx->ROWf, ctx->edgeb, h, w, rc, ctx->frame_runcap, active, ctx->fb_fg,
-                                                            ctx->pass_flags, ctx->frame_lds);
+                                                            ctx->pass_flags, ctx->frame_lds, active ? ctx->perm_cur : nullptr);
         KCHK("k_frame_fg");
         if (!ctx->general_on) return 0; // (a frame that did not fit raises PASS_FLAG_GENERAL: the caller runs the chunk again)
         active = ctx->fb_fg;
@@ -774,7 +779,7 @@ static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, i
             if (const char *e = getenv("LFDMI_DCT_FILLPARTS")) fill_parts = std::max(1, atoi(e));
             k_dc_tiles<<<dim3(nc, fill_parts), DCT_THREADS, 0, ctx->stream>>>(cellbm, ctx->bm_bands, lut, ctx->tile_list, ctx->tile_cap,
                                                              ctx->counters, ctx->equb, ctx->candb, ctx->strongb, ctx->keep_equ ? ctx->equ : nullptr,
-                                                             h, w, active);
+                                                             h, w, active, active ? ctx->perm_cur : nullptr);
             KCHK("k_dc_tiles");
             // many short waves: the dispatcher evens out frames and regions with more occupied tiles than others (a wave gets
             // 1 / parts of the frame's list: 3-5 tiles on SDSS frames; 47 parts: 1.46 ms per step, 256: 1.29 ms)
@@ -788,7 +793,7 @@ static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, i
 #define LFD_DCT_LAUNCH(PROF_, KH_, KW_)                                                                                              \
     k_dilate_canny_t<PROF_, KH_, KW_><<<grid, 64, lds, ctx->stream>>>(src, ctx->keep_equ ? ctx->equ : nullptr, ctx->equb, ctx->candb, \
                                                                       ctx->strongb, lut, h, w, kh, kw, 0, 255, active, nc, parts,     \
-                                                                      ctx->tile_list, ctx->tile_cap, ctx->counters, prof)
+                                                                      ctx->tile_list, ctx->tile_cap, ctx->counters, prof, active ? ctx->perm_cur : nullptr)
             const bool spec = ctx->dc_specialize;
             if (prof) {
                 if (spec && kh == 4 && kw == 4) LFD_DCT_LAUNCH(true, 4, 4);
@@ -883,7 +888,7 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
         k_frame_contours<<<nc, FRAME_THREADS, lds, ctx->stream>>>(rt, ctx->wl_fg, ctx->wl_bg, ctx->counters, ctx->keys, ctx->bigkeys,
                                                                   ctx->medkeys, ctx->rowext, ctx->rsa, h, w, ctx->key_cap, ctx->slot_cap,
                                                                   ctx->frame_runcap, active, ctx->fb_bg, ctx->pass_flags, ctx->dc_profile ? nullptr : ctx->prof,
-                                                                  ctx->frame_lds);
+                                                                  ctx->frame_lds, active ? ctx->perm_cur : nullptr);
         KCHK("k_frame_contours");
         gen = ctx->fb_bg;
     }
@@ -1182,6 +1187,12 @@ static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, 
     const uint8_t *dil_src = ctx->gray;
     const u64 *bm = ctx->cellbm;
     ctx->eroded_valid = dim;
+    ctx->perm_cur = nullptr;
+    if (active && ctx->use_perm) { // the pass works on a subset of the slots: its active frames first (k_active_perm)
+        k_active_perm<<<1, 64, 0, ctx->stream>>>(active, nc, ctx->perm);
+        KCHK("k_active_perm");
+        ctx->perm_cur = ctx->perm;
+    }
     if (dim && ctx->delta_state == 2) {
         // the bright pass left this pass's values (gray + one bit per pixel) and their histogram: no second sweep over the floats
         HIPCHK(hipMemsetAsync(ctx->zero_block + ctx->zero_counters_off, 0, ctx->zero_bytes - ctx->zero_counters_off, ctx->stream));
@@ -1266,6 +1277,7 @@ static int run_tail(lfdmi_ctx *ctx, int nc, int h, int w, double rho, bool dim, 
 static int run_pass(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, int w, int flip, int prep_mode, bool dim,
                     const lfdmi_params *p, const int *active, int *need_dim, const lfdmi_params *dual_dim = nullptr) {
     RET(run_front(ctx, src, dtype, nc, h, w, flip, prep_mode, dim, p, active, dual_dim));
+    ctx->perm_cur = nullptr; // (only the front end's per-frame launches use it)
     return run_tail(ctx, nc, h, w, p->houghMethod, dim, p, active, need_dim, ctx->res_dev, false);
 }
 
