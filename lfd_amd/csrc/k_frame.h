@@ -38,6 +38,27 @@ __global__ void __launch_bounds__(64) k_active_perm(const int *active, int n, in
         }
 }
 
+// The same for the tile kernel, whose frames are pinned to an XCD each (frame i of the list -> XCD i % 8): active frames sorted
+// by their number of active tiles, most first, and dealt to the XCDs in snake order (0..7, 7..0, ...), so that the eight XCDs
+// get nearly equal sums of tiles instead of whatever 32 consecutive frames happen to hold.  n <= 1024.
+__global__ void __launch_bounds__(1024) k_tile_perm(const int *active, const int *counters, int n, int *perm) {
+    __shared__ int key[1024];
+    const int i = threadIdx.x;
+    if (i < n) key[i] = (active && !active[i]) ? -1 : counters[i * C_COUNT + C_NTILES];
+    __syncthreads();
+    if (i >= n) return;
+    const int k = key[i];
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+        const int kj = key[j];
+        rank += (kj > k || (kj == k && j < i)) ? 1 : 0;
+    }
+    const int round = rank >> 3, pos = rank & 7;
+    int c = (round << 3) + ((round & 1) ? 7 - pos : pos);
+    if (c >= n) c = rank; // (the last, incomplete round keeps its order: positions beyond n do not exist)
+    perm[c] = i;
+}
+
 #define PASS_FLAG_GENERAL 256 // pass_flags bit: this frame needs the general (multi-workgroup) run kernels
 #define FRAME_THREADS 1024
 #define FRAME_HOLECAP 1024 // hash slots for the holes of a frame (more holes: looked up in the global tables)

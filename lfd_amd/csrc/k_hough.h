@@ -149,13 +149,24 @@ template <int AWL> // log2 of the angles per workgroup
 __global__ void __launch_bounds__(VOTE_THREADS)
 k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, const float *tab,
              int *accum, int numangle, int numrho, int nsplit, size_t list_cap, size_t acc_cap,
-             const int *active, int need_detect, VoteRanges rng) {
+             const int *active, int need_detect, VoteRanges rng, int balance) {
     constexpr int aw_log2 = AWL;
     int g = blockIdx.z, im = blockIdx.y;
     int slab = blockIdx.x / nsplit, split = blockIdx.x - slab * nsplit;
     if (slot_off(active, counters, g)) return;
     const int *cnt = counters + g * C_COUNT;
     if (need_detect && !cnt[C_DETECT]) return;
+    if (balance) {
+        // gridDim.y == 1 and the nsplit pieces of a slab are shared out between the TWO images in proportion to their list
+        // lengths (equ's list is about three times box_img's): every workgroup of a frame then gets about the same number of
+        // chunks, whatever XCD it lands on, instead of half the workgroups finishing in a third of the time of the others
+        const int cls_ = (slab < VOTE_MAX_SLABS) ? (int)((rng.cls_b >> slab) & 1u) : 0;
+        const int n0 = cnt[cls_ ? C_NPIXB_EQU : C_NPIX_EQU], n1 = cnt[cls_ ? C_NPIXB_BOX : C_NPIX_BOX];
+        int s0 = (n0 + n1) > 0 ? (int)(((long long)nsplit * n0 + (n0 + n1) / 2) / (n0 + n1)) : nsplit / 2;
+        s0 = max(1, min(nsplit - 1, s0));
+        if (split < s0) { im = 0; nsplit = s0; }
+        else { im = 1; split -= s0; nsplit -= s0; }
+    }
     extern __shared__ int acc[]; // nb * AW votes (rows lo .. hi of this slab) + 64 spare words for lanes without an angle
     const int AW = 1 << aw_log2;
     int a0 = slab * AW;
@@ -167,7 +178,8 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     if ((size_t)n > list_cap) n = (int)list_cap;
     int per = ((n + nsplit - 1) / nsplit + 63) / 64 * 64;
     int begin = min(n, split * per), end = min(n, begin + per);
-    if (nsplit > 1 && begin >= end) return; // nothing to add
+    const bool merge = balance || nsplit > 1; // pieces of a list are merged with atomic adds into a zeroed accumulator
+    if (merge && begin >= end) return; // nothing to add
     for (int k = threadIdx.x; k < nb * AW + 64; k += VOTE_THREADS) acc[k] = 0;
     __syncthreads();
     const uint32_t *list = (im ? list1 : list0) + ((size_t)g * 2 + cls) * list_cap;
@@ -280,7 +292,7 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     int *ag = accum + ((size_t)g * 2 + im) * acc_cap;
     const int ts = numangle + 2; // transposed row length
     const int r0 = (numrho - 1) / 2 + lo; // accumulator row of the slab's first bin
-    if (nsplit > 1) {
+    if (merge) {
         for (int k = threadIdx.x; k < nb * AW; k += VOTE_THREADS) {
             int rr = r0 + (k >> aw_log2), al = k & (AW - 1);
             int v = acc[k];

@@ -104,6 +104,8 @@ struct lfdmi_ctx {
     int *perm = nullptr;               // k_active_perm: the current pass's active slots first (XCD balance of the per-frame launches)
     const int *perm_cur = nullptr;     // perm while a pass with an `active` mask runs, nullptr otherwise
     bool use_perm = true;              // LFDMI_PERM=0: frame slot == workgroup index as before
+    int *perm_tiles = nullptr;         // k_tile_perm: frames by active tiles, dealt to the XCDs in snake order (the tile kernel's frame list)
+    bool use_tile_perm = true;         // LFDMI_TILE_PERM=0
     lfdmi_result *res_dev = nullptr;   // G x LFDMI_MAX_SCALES records (one block of G per Hough scale)
     // Workspace sizing (include/lfdmi.h: lfdmi_caps).  A compact context keeps a worst-case one for single frames
     // (`spill`, created on first use): a frame whose tables overflow here (per-frame LFDMI_ERR_CAPACITY) is run
@@ -370,6 +372,8 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     RET(dmalloc(ctx, &ctx->tile_list, G * ctx->tile_cap));
     RET(dmalloc(ctx, &ctx->segcnt, G * SCAN_MAX_SEG));
     RET(dmalloc(ctx, &ctx->perm, G));
+    RET(dmalloc(ctx, &ctx->perm_tiles, G));
+    if (const char *e = getenv("LFDMI_TILE_PERM")) ctx->use_tile_perm = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_PERM")) ctx->use_perm = atoi(e) != 0;
     RET(dmalloc(ctx, &ctx->fb_fg, G));
     RET(dmalloc(ctx, &ctx->fb_bg, G));
@@ -781,6 +785,12 @@ static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, i
                                                              ctx->counters, ctx->equb, ctx->candb, ctx->strongb, ctx->keep_equ ? ctx->equ : nullptr,
                                                              h, w, active, active ? ctx->perm_cur : nullptr);
             KCHK("k_dc_tiles");
+            const int *tperm = active ? ctx->perm_cur : nullptr;
+            if (ctx->use_tile_perm && ctx->use_perm && nc <= 1024 && nc > 8) { // frames sorted by work, dealt evenly to the XCDs
+                k_tile_perm<<<1, 1024, 0, ctx->stream>>>(active, ctx->counters, nc, ctx->perm_tiles);
+                KCHK("k_tile_perm");
+                tperm = ctx->perm_tiles;
+            }
             // many short waves: the dispatcher evens out frames and regions with more occupied tiles than others (a wave gets
             // 1 / parts of the frame's list: 3-5 tiles on SDSS frames; 47 parts: 1.46 ms per step, 256: 1.29 ms)
             int parts = ctx->dc_parts > 0 ? ctx->dc_parts : std::max(8, std::min(256, tiles_x * tiles_y / 8));
@@ -793,7 +803,7 @@ static int run_dilate_canny(lfdmi_ctx *ctx, const uint8_t *src, int nc, int h, i
 #define LFD_DCT_LAUNCH(PROF_, KH_, KW_)                                                                                              \
     k_dilate_canny_t<PROF_, KH_, KW_><<<grid, 64, lds, ctx->stream>>>(src, ctx->keep_equ ? ctx->equ : nullptr, ctx->equb, ctx->candb, \
                                                                       ctx->strongb, lut, h, w, kh, kw, 0, 255, active, nc, parts,     \
-                                                                      ctx->tile_list, ctx->tile_cap, ctx->counters, prof, active ? ctx->perm_cur : nullptr)
+                                                                      ctx->tile_list, ctx->tile_cap, ctx->counters, prof, tperm)
             const bool spec = ctx->dc_specialize;
             if (prof) {
                 if (spec && kh == 4 && kw == 4) LFD_DCT_LAUNCH(true, 4, 4);
@@ -1061,22 +1071,26 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         int nsplit = 1;
         static const int vote_wgs = getenv("LFDMI_VOTE_WGS") ? atoi(getenv("LFDMI_VOTE_WGS")) : 6144;
         while (nsplit < ctx->vote_split && nslabs * n_img * nc * nsplit < vote_wgs) nsplit <<= 1;
+        // two images: their pieces come out of one pool per slab, shared out by list length on the device (k_hough_vote: balance)
+        static const bool vote_balance = getenv("LFDMI_VOTE_BALANCE") ? atoi(getenv("LFDMI_VOTE_BALANCE")) != 0 : true;
+        const int balance = (vote_balance && n_img == 2 && nsplit >= 2) ? 1 : 0;
         int acc_n = (na + 2) * (nr + 2);
         { Span sp(ctx, KID_PIXLIST, need_detect);
         // per-slot accumulator pairs are 2 * acc_cap apart; the kernel indexes by slot itself
         k_pixlist<<<dim3((wg.x + PIXLIST_WORDS - 1) / PIXLIST_WORDS, wg.y, n_img), 256, 0, ctx->stream>>>(ctx->equb, ctx->boxb, ctx->pix_equ, ctx->pix_box, ctx->counters, cm_a, cm_b,
-                                                                    h, w, ctx->list_cap, nsplit > 1 ? ctx->accum : nullptr, acc_n, ctx->acc_cap,
+                                                                    h, w, ctx->list_cap, (nsplit > 1 || balance) ? ctx->accum : nullptr, acc_n, ctx->acc_cap,
                                                                     active, need_detect);
         KCHK("k_pixlist"); }
         Span sp(ctx, KID_VOTE, need_detect);
-        dim3 vgrid(nslabs * nsplit, n_img, nc);
+        dim3 vgrid(nslabs * nsplit * (balance ? 2 : 1), balance ? 1 : n_img, nc);
+        const int vsplit = balance ? 2 * nsplit : nsplit;
         size_t vlds = ((size_t)nbmax << aw_log2) * 4 + 256;
 #define LFD_LAUNCH_VOTE(L)                                                                                          \
     case L:                                                                                                         \
         k_hough_vote<L><<<vgrid, VOTE_THREADS, vlds, ctx->stream>>>(ctx->pix_equ, ctx->pix_box, ctx->counters,           \
                                                                    ctx->tab + (size_t)ctx->tab_cur * 2 * MAX_ANGLES, \
-                                                                   ctx->accum, na, nr, nsplit, ctx->list_cap,       \
-                                                                   ctx->acc_cap, active, need_detect, rng);         \
+                                                                   ctx->accum, na, nr, vsplit, ctx->list_cap,       \
+                                                                   ctx->acc_cap, active, need_detect, rng, balance); \
         break;
         switch (aw_log2) {
             LFD_LAUNCH_VOTE(6) LFD_LAUNCH_VOTE(5) LFD_LAUNCH_VOTE(4) LFD_LAUNCH_VOTE(3) LFD_LAUNCH_VOTE(2)
