@@ -217,8 +217,12 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     const float half_s = c < 0.f ? -0.5f : 0.5f;
     const int sh = aw_log2 + 2;
 #define LFD_BIN(FX, YS) __builtin_bit_cast(unsigned, __fadd_rn(__fadd_rn(__fmul_rn((FX), c), (YS)), 12582912.0f))
-    for (int base = begin + wv * 64; base < end; base += nw * 64) {
-        int m = min(64, end - base);
+    // every wave takes one contiguous share of the piece (a strided walk in batches of 64 left most waves idle in the last
+    // round: 1 250 chunks over 16 waves were two batches for four waves and one for the other twelve)
+    const int share = (end - begin + nw - 1) / nw;
+    const int wbeg = begin + wv * share, wend = min(end, wbeg + share);
+    for (int base = wbeg; base < wend; base += 64) {
+        int m = min(64, wend - base);
         uint32_t pv = (lane < m) ? list[base + lane] : 0u;
         // every lane converts its own entry once; the wave then walks the entries with v_readlane (one chunk per step,
         // SUBS == 1) or fetches its slot's entry with ds_bpermute (SUBS chunks per step)

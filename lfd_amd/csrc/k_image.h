@@ -3,6 +3,7 @@
 // Reference call sites: removestars.py:212-231, detecttrails.py:124, processfield.py:342-354,
 // :453-471, :236 (Canny's first half).  All HBM-bound; algorithmic bytes in DESIGN.md.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "../../include/lfdmi.h"
 
@@ -197,18 +198,21 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
         // float rows, four pixels per lane; the loads of four rows are issued together (64 B per lane in flight: the kernel
         // lives on memory latency otherwise)
         const float *fs = (const float *)src + (size_t)g * N;
-        for (int rb = r0; rb < r0 + prep_rows && rb < h; rb += 4) {
+        // (rows are taken four at a time; a group of four whole rows -- all but a frame's last group -- runs without the per-row
+        // bounds tests: the sweep issues about as many scalar as vector instructions and both count)
+        auto rows4 = [&](auto full_tag, int rb) {
+            constexpr bool FULL = decltype(full_tag)::value;
             for (int x4 = threadIdx.x, i = 0; x4 < (w >> 2); x4 += 256, i++) {
                 float4 v[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     int r = rb + k;
-                    if (k < prep_rows && r < h) v[k] = ((const float4 *)(fs + (size_t)(flip ? (h - 1 - r) : r) * w))[x4];
+                    if (FULL || (k < prep_rows && r < h)) v[k] = ((const float4 *)(fs + (size_t)(flip ? (h - 1 - r) : r) * w))[x4];
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     int r = rb + k;
-                    if (k >= prep_rows || r >= h) break;
+                    if (!FULL && (k >= prep_rows || r >= h)) break;
                     constexpr int M = MODE >= 0 ? MODE : 0;
                     if constexpr (DELTA && MFPOS && M == 1) {
                         // Sky: when every pixel of the wave's 256 is below 0.5 (NaN compares false) the bright values are all 0
@@ -221,7 +225,7 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
                             const bool sky = (q.x < 0.5f) & (q.y < 0.5f) & (q.z < 0.5f) & (q.w < 0.5f);
                             if (__ballot(!sky) == 0ull) {
                                 ((uint32_t *)(gout + (size_t)r * w))[x4] = 0u;
-                                if (fullbits && lfd_lane() == 0) fullbits[((size_t)g * h + r) * ((w + 255) >> 8) + (x4 >> 6)] = 0ull;
+                                if (!DELTA && fullbits && lfd_lane() == 0) fullbits[((size_t)g * h + r) * ((w + 255) >> 8) + (x4 >> 6)] = 0ull;
                                 acc.n01 += 1;
                                 const uint32_t nib = (q.x >= mf2 ? 1u : 0u) | (q.y >= mf2 ? 2u : 0u) | (q.z >= mf2 ? 4u : 0u) | (q.w >= mf2 ? 8u : 0u);
                                 acc2.n01 += 1;
@@ -245,7 +249,7 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
                     // one bit per aligned word of four pixels: "all four non-zero".  Only where such words line up can a wide
                     // erosion leave anything (k_morph_rect_v decides from these bits without loading the image); a wave's 64
                     // lanes are 64 consecutive words, so the ballot is one u64 of the plane
-                    if (fullbits) {
+                    if (!DELTA && fullbits) {
                         u64 fb = __ballot(no_zero_byte(word));
                         if (lfd_lane() == 0) fullbits[((size_t)g * h + r) * ((w + 255) >> 8) + (x4 >> 6)] = fb;
                     }
@@ -278,6 +282,10 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
                     }
                 }
             }
+        };
+        for (int rb = r0; rb < r0 + prep_rows && rb < h; rb += 4) {
+            if (rb + 4 <= r0 + prep_rows && rb + 4 <= h) rows4(std::true_type{}, rb);
+            else rows4(std::false_type{}, rb);
         }
     } else
     for (int r = r0; r < r0 + prep_rows && r < h; r++) {
@@ -505,8 +513,20 @@ k_bits_erode(const uint8_t *gsrc, const u64 *dbits, const u64 *nzd, uint8_t *dst
     const u64 *nz = nzd + (size_t)g * nw;
     u64 e = 0ull;
     int y = 0, q = 0;
+    if (i < nw) { y = i / wq; q = i - y * wq; }
+    // zeros for the wave's pixels FIRST (64 words = 4096 bytes, contiguous: rows are whole words when w % 64 == 0; otherwise a
+    // word's bytes beyond the row end belong to nobody and are skipped): the stores depend on nothing, so they leave before the
+    // wave waits for its bit rows; the survivors' values follow in program order
+    uint8_t *d = dst + (size_t)g * N;
+    if ((w & 63) == 0) {
+        uint4 *dz = (uint4 *)(d + (size_t)i0 * 64);
+        const int n16 = min(64, nw - i0) * 4;
+        for (int k = lane; k < n16; k += 64) dz[k] = make_uint4(0, 0, 0, 0);
+    } else if (i < nw) {
+        const int x0 = q << 6, nb = min(64, w - x0);
+        for (int b = 0; b < nb; b++) d[(size_t)y * w + x0 + b] = 0; // (odd widths are not on the batch path: plain and slow)
+    }
     if (i < nw) {
-        y = i / wq; q = i - y * wq;
         e = valid_mask(q, w);
         for (int dy = 0; dy < kh; dy++) {
             const int yy = y + dy - ay;
@@ -520,17 +540,6 @@ k_bits_erode(const uint8_t *gsrc, const u64 *dbits, const u64 *nzd, uint8_t *dst
             for (int sft = 1; sft <= ax; sft++) ha &= (c << sft) | (p >> (64 - sft));           // columns x - sft
             e &= ha;
         }
-    }
-    // zeros for the wave's pixels (64 words = 4096 bytes, contiguous: rows are whole words when w % 64 == 0; otherwise a word's
-    // bytes beyond the row end belong to nobody and are skipped), then the survivors
-    uint8_t *d = dst + (size_t)g * N;
-    if ((w & 63) == 0) {
-        uint4 *dz = (uint4 *)(d + (size_t)i0 * 64);
-        const int n16 = min(64, nw - i0) * 4;
-        for (int k = lane; k < n16; k += 64) dz[k] = make_uint4(0, 0, 0, 0);
-    } else if (i < nw) {
-        const int x0 = q << 6, nb = min(64, w - x0);
-        for (int b = 0; b < nb; b++) d[(size_t)y * w + x0 + b] = 0; // (odd widths are not on the batch path: plain and slow)
     }
     u64 todo = __ballot(e != 0ull);
     if (todo == 0ull) continue;
