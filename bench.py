@@ -263,8 +263,18 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
     cnt = det.get_counters()[:n]  # last pass of every slot: Hough cost is 180 votes per non-zero pixel
     sustained = None
     if sustained_s > 0:                           # the same step back to back for >= sustained_s seconds: the clock the chip holds
-        c0 = gpu_clock_mhz(dev_index)
+        import threading
+        clocks, stop_sampling = [], threading.Event()
+
+        def sample():                             # (read while the loop runs: the clock falls back within milliseconds of an idle GPU)
+            while not stop_sampling.wait(0.2):
+                c = gpu_clock_mhz(dev_index)
+                if c:
+                    clocks.append(c)
+
+        sampler = threading.Thread(target=sample, daemon=True)
         fence()
+        sampler.start()
         t0 = time.perf_counter()
         m = 0
         while time.perf_counter() - t0 < sustained_s:
@@ -273,10 +283,12 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
             torch.cuda.synchronize()
             m += 10
         dt = time.perf_counter() - t0
-        c1 = gpu_clock_mhz(dev_index)
+        stop_sampling.set()
+        sampler.join()
         sustained = {"value": round(world * n * m / dt, 2), "unit": "frames/s", "steps": m, "seconds": round(dt, 2),
-                     "ms_per_step": round(1e3 * dt / m, 3), "sclk_mhz_before": c0, "sclk_mhz_after": c1,
-                     "note": "the timed step repeated back to back (this rank); sclk read from pp_dpm_sclk right before / after"}
+                     "ms_per_step": round(1e3 * dt / m, 3),
+                     "sclk_mhz_during": {"samples": len(clocks), "min": min(clocks), "median": int(np.median(clocks)), "max": max(clocks)} if clocks else None,
+                     "note": "the timed step repeated back to back (this rank); sclk = the active level of pp_dpm_sclk sampled every 0.2 s while the loop runs"}
     host_res = None
     if host_leg and host_ok and not args.host_frames and not args.no_host_leg:  # secondary: frames handed over as host buffers (PCIe-inclusive; never `value`)
         step_host()
