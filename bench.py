@@ -140,24 +140,38 @@ def load_traffic(name, cfg):
 
 
 def gpu_clock_mhz(index=0):
-    """Current shader clock of the card (the level marked '*' in pp_dpm_sclk), or None where sysfs / rocm-smi do not say."""
+    """Current shader clock of HIP device `index` in MHz: hwmon's sclk (freq1_input) of the PCI function torch reports for the
+    device -- a GPU box shows the whole node's cards in sysfs, so the card is found by its bus id, not by its position --, else
+    the active level of its pp_dpm_sclk; None where neither can be read."""
     import glob
     import re
-    import subprocess
-    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-    if cards:
-        try:
-            for line in open(cards[min(index, len(cards) - 1)]):
-                if line.rstrip().endswith("*"):
-                    return int(re.search(r"(\d+)\s*[Mm][Hh]z", line).group(1))
-        except (OSError, AttributeError, ValueError):
-            pass
+    dev_dir = None
     try:
-        txt = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks"], capture_output=True, text=True, timeout=20).stdout
-        m = re.search(r"sclk clock level:?\s*\d+:?\s*\(?(\d+)\s*[Mm][Hh]z", txt)
-        return int(m.group(1)) if m else None
+        import torch
+        p = torch.cuda.get_device_properties(index)
+        bus = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        if os.path.isdir("/sys/bus/pci/devices/" + bus):
+            dev_dir = "/sys/bus/pci/devices/" + bus
     except Exception:  # noqa: BLE001
-        return None
+        pass
+    if dev_dir is None:
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        if len(cards) != 1:
+            return None                            # several cards and no way to tell which one is ours
+        dev_dir = cards[0]
+    try:
+        for lab in glob.glob(dev_dir + "/hwmon/hwmon*/freq*_label"):
+            if open(lab).read().strip() == "sclk":
+                return int(open(lab.replace("_label", "_input")).read()) // 1000000
+    except (OSError, ValueError):
+        pass
+    try:
+        for line in open(dev_dir + "/pp_dpm_sclk"):
+            if line.rstrip().endswith("*"):
+                return int(re.search(r"(\d+)\s*[Mm][Hh]z", line).group(1))
+    except (OSError, AttributeError, ValueError):
+        pass
+    return None
 
 
 def host_cores(world):
@@ -288,7 +302,7 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
         sustained = {"value": round(world * n * m / dt, 2), "unit": "frames/s", "steps": m, "seconds": round(dt, 2),
                      "ms_per_step": round(1e3 * dt / m, 3),
                      "sclk_mhz_during": {"samples": len(clocks), "min": min(clocks), "median": int(np.median(clocks)), "max": max(clocks)} if clocks else None,
-                     "note": "the timed step repeated back to back (this rank); sclk = the active level of pp_dpm_sclk sampled every 0.2 s while the loop runs"}
+                     "note": "the timed step repeated back to back (this rank); sclk = hwmon freq1_input of this device's PCI function, sampled every 0.2 s while the loop runs"}
     host_res = None
     if host_leg and host_ok and not args.host_frames and not args.no_host_leg:  # secondary: frames handed over as host buffers (PCIe-inclusive; never `value`)
         step_host()

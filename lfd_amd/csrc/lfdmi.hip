@@ -106,6 +106,9 @@ struct lfdmi_ctx {
     bool use_perm = true;              // LFDMI_PERM=0: frame slot == workgroup index as before
     int *perm_tiles = nullptr;         // k_tile_perm: frames by active tiles, dealt to the XCDs in snake order (the tile kernel's frame list)
     bool use_tile_perm = true;         // LFDMI_TILE_PERM=0
+    bool sky_fast = true;              // LFDMI_SKY_FAST=0: the bright sweep without its all-sky shortcut
+    bool vote_classes = true;          // LFDMI_VOTE_CLASSES=0: one chunk list per image (no longer cut for the mid-angle slabs)
+    bool vote_balance = true;          // LFDMI_VOTE_BALANCE=0: a fixed number of list pieces per image in the vote kernel
     lfdmi_result *res_dev = nullptr;   // G x LFDMI_MAX_SCALES records (one block of G per Hough scale)
     // Workspace sizing (include/lfdmi.h: lfdmi_caps).  A compact context keeps a worst-case one for single frames
     // (`spill`, created on first use): a frame whose tables overflow here (per-frame LFDMI_ERR_CAPACITY) is run
@@ -374,6 +377,9 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     RET(dmalloc(ctx, &ctx->perm, G));
     RET(dmalloc(ctx, &ctx->perm_tiles, G));
     if (const char *e = getenv("LFDMI_TILE_PERM")) ctx->use_tile_perm = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_SKY_FAST")) ctx->sky_fast = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_VOTE_CLASSES")) ctx->vote_classes = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_VOTE_BALANCE")) ctx->vote_balance = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_PERM")) ctx->use_perm = atoi(e) != 0;
     RET(dmalloc(ctx, &ctx->fb_fg, G));
     RET(dmalloc(ctx, &ctx->fb_bg, G));
@@ -616,7 +622,7 @@ static int run_prep(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, i
                                                               ctx->cellbm, ctx->bm_bands, active, fullbits, prep_rows, ctx->dbits,    \
                                                               ctx->hist2, (float)delta_dim->minFlux, (float)delta_dim->addFlux, ctx->nzd, sky_fast)
             // (all-sky shortcut of the sweep: exact when the smallest kept value already rounds to 1, see k_prep_hist)
-            static const bool sky_on = getenv("LFDMI_SKY_FAST") ? atoi(getenv("LFDMI_SKY_FAST")) != 0 : true; // developer switch
+            const bool sky_on = ctx->sky_fast; // (developer switch LFDMI_SKY_FAST)
             const float mfa = (float)delta_dim->minFlux + (float)delta_dim->addFlux;
             const int sky_fast = (sky_on && mode == LFDMI_PREP_BRIGHT && mfa > 0.5f) ? 1 : 0;
             if ((float)delta_dim->minFlux > 0.f) LFD_PREP_DELTA(true);
@@ -1057,7 +1063,7 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
             lmax[sl] = (int)std::min<double>(CHUNK_MAX, std::max<double>(1, l));
             cm_a = std::min(cm_a, lmax[sl]);
         }
-        static const bool use_b = getenv("LFDMI_VOTE_CLASSES") ? atoi(getenv("LFDMI_VOTE_CLASSES")) != 0 : true; // developer switch
+        const bool use_b = ctx->vote_classes; // (developer switch LFDMI_VOTE_CLASSES)
         if (per_slab && use_b) {
             int mb = CHUNK_MAX + 1;
             for (int sl = 0; sl < nslabs; sl++)
@@ -1072,7 +1078,7 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         static const int vote_wgs = getenv("LFDMI_VOTE_WGS") ? atoi(getenv("LFDMI_VOTE_WGS")) : 6144;
         while (nsplit < ctx->vote_split && nslabs * n_img * nc * nsplit < vote_wgs) nsplit <<= 1;
         // two images: their pieces come out of one pool per slab, shared out by list length on the device (k_hough_vote: balance)
-        static const bool vote_balance = getenv("LFDMI_VOTE_BALANCE") ? atoi(getenv("LFDMI_VOTE_BALANCE")) != 0 : true;
+        const bool vote_balance = ctx->vote_balance; // (developer switch LFDMI_VOTE_BALANCE)
         const int balance = (vote_balance && n_img == 2 && nsplit >= 2) ? 1 : 0;
         int acc_n = (na + 2) * (nr + 2);
         { Span sp(ctx, KID_PIXLIST, need_detect);

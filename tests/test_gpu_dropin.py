@@ -127,3 +127,33 @@ def test_one_bad_frame_costs_only_itself_in_a_batch(tmp_path, oracle):
     assert outs[6][0] == want
     assert outs[6][1] == [f"94 1 r {fields[2]}", f"94 1 r {bad}"]
     assert outs[6][2][1] == "cannot convert float NaN to integer"
+
+
+def test_mixed_filters_in_one_chunk_and_resume(tmp_path, oracle):
+    """camcol-frame selection: one field in all five filters (detecttrails.py:400-403).  remove_stars' magnitude cap depends on
+    the filter, so the loader gives the frames of a filter neighbouring slots and the GPU gets one call per filter; rows come
+    out in the reference's order (u g r i z) and equal the oracle's with that filter's parameters.  Then the same selection
+    with resume=True appends nothing."""
+    from lfd_amd import results, synth
+    from lfd_amd.detecttrails import DetectTrails, default_params, sdssfiles
+    pb, pd, prs = default_params()
+    img, cat, _ = synth.make_portable_frame(0, (512, 768))                   # a bright streak: found in every filter
+    img2, cat2, _ = synth.make_portable_frame(1, (512, 768))
+    hdr = synth.write_boss_tree(tmp_path, [img, img2], [cat, cat2], field0=100, filter="r")
+    for flt in "ugiz":                                                       # the same pixels under the other filters' names
+        for f in (100, 101):
+            os.link(sdssfiles.filename("frame", 94, 1, f, "r"), sdssfiles.filename("frame", 94, 1, f, flt))
+    want = []
+    for flt in "ugriz":
+        rs = oracle.rs_params(flt, **{k: v for k, v in prs.items() if k != "debug"})
+        rec = oracle.detect_frame(img.copy(), pb, pd, cat, rs)
+        if rec["found"]:
+            want.append(results.format_result_row(94, 1, flt, 100, hdr, rec))
+    assert len(want) >= 3
+    dt = DetectTrails(run=94, camcol=1, field=100, savepath=str(tmp_path))
+    assert dt._pick == "camcol-frame"
+    dt.process(batch=4)                                                      # two chunks: u g r i | z
+    got = [ln.strip() for ln in open(dt.results) if ln.strip()]
+    assert got == want and open(dt.errors).read() == ""
+    dt.process(batch=4, resume=True)
+    assert dt.last_stats["skipped_by_resume"] == 5 and [ln.strip() for ln in open(dt.results) if ln.strip()] == want

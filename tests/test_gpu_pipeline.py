@@ -308,14 +308,22 @@ def test_cell_bitmap_and_general_run_kernels_do_not_change_results(monkeypatch):
     active-tile list), another split of the tile list over waves and LFDMI_DC_SPECIALIZE=0 (run-time instead of compile-time
     structuring-element sizes in the tile kernel), LFDMI_FUSE_DUAL=1 (one band-kernel sweep over the float frames feeds both
     passes) and LFDMI_DELTA_DIM=0 (the dim pass converts the float frames again instead of rebuilding its image from the
-    bright image and one bit per pixel) against the default fast paths: identical records and edge images."""
+    bright image and one bit per pixel); round 3: LFDMI_PERM=0 / LFDMI_TILE_PERM=0 (frame slot == workgroup index: no XCD
+    balancing of a pass's active frames / no sorting by tiles), LFDMI_VOTE_BALANCE=0 and LFDMI_VOTE_CLASSES=0 (fixed pieces per
+    image, one chunk list per image in the Hough vote), LFDMI_SKY_FAST=0 (the bright sweep without its all-sky shortcut),
+    LFDMI_FRAME_LDS=16384 (smaller label tables: busy frames take the general kernels) -- against the default fast paths:
+    identical records and edge images."""
     from lfd_amd import _native, synth
     pb, pd, prs = params()
     frames = np.stack([synth.make_frame(k, with_catalog=False)[0] for k in range(6)])
     outs = []
+    switches = ("LFDMI_CELLBM", "LFDMI_FRAME_CCL", "LFDMI_DC_TILELIST", "LFDMI_DC_PARTS", "LFDMI_DC_SPECIALIZE", "LFDMI_FUSE_DUAL", "LFDMI_DELTA_DIM",
+                "LFDMI_PERM", "LFDMI_TILE_PERM", "LFDMI_VOTE_BALANCE", "LFDMI_VOTE_CLASSES", "LFDMI_SKY_FAST", "LFDMI_FRAME_LDS")
     for env in ({}, {"LFDMI_CELLBM": "0"}, {"LFDMI_FRAME_CCL": "0"}, {"LFDMI_DC_TILELIST": "0"}, {"LFDMI_DC_TILELIST": "0", "LFDMI_CELLBM": "0"},
-                {"LFDMI_DC_PARTS": "7"}, {"LFDMI_DC_SPECIALIZE": "0"}, {"LFDMI_FUSE_DUAL": "1"}, {"LFDMI_DELTA_DIM": "0"}):
-        for k in ("LFDMI_CELLBM", "LFDMI_FRAME_CCL", "LFDMI_DC_TILELIST", "LFDMI_DC_PARTS", "LFDMI_DC_SPECIALIZE", "LFDMI_FUSE_DUAL", "LFDMI_DELTA_DIM"):
+                {"LFDMI_DC_PARTS": "7"}, {"LFDMI_DC_SPECIALIZE": "0"}, {"LFDMI_FUSE_DUAL": "1"}, {"LFDMI_DELTA_DIM": "0"},
+                {"LFDMI_PERM": "0"}, {"LFDMI_TILE_PERM": "0"}, {"LFDMI_VOTE_BALANCE": "0"}, {"LFDMI_VOTE_CLASSES": "0"}, {"LFDMI_SKY_FAST": "0"},
+                {"LFDMI_FRAME_LDS": "16384"}, {"LFDMI_VOTE_BALANCE": "0", "LFDMI_VOTE_CLASSES": "0", "LFDMI_PERM": "0", "LFDMI_SKY_FAST": "0"}):
+        for k in switches:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -549,3 +557,26 @@ def test_big_endian_and_pinned_frames(oracle, monkeypatch):
             pin.close()
     assert same(one[0], oracle.detect_frame(np.ascontiguousarray(blotted[5]), pb, pd))
     assert same(want[3], oracle.detect_frame(frames[3].copy(), pb, pd, cats[3], rs_o))
+
+
+def test_dim_pass_on_an_arbitrary_subset_of_the_slots(oracle):
+    """The dim pass works on the frames the bright pass left undecided, whatever slots they sit in; the launches whose frame ->
+    XCD mapping is fixed index frames through a list with the active slots first (k_active_perm / k_tile_perm).  Batches
+    whose undecided frames are a few scattered slots, all even slots, none and all of them: records equal the oracle's and
+    do not depend on where a frame sits in the batch."""
+    from lfd_amd import _native, synth
+    pb, pd, _ = params()
+    bright, _, _ = synth.make_frame(0, with_catalog=False)               # found by the bright pass
+    dim, _, _ = synth.make_frame(1, with_catalog=False)                  # needs the dim pass
+    none, _, _ = synth.make_frame(7, with_catalog=False)
+    want = {id(f): oracle.detect_frame(f.copy(), pb, pd) for f in (bright, dim, none)}
+    assert want[id(bright)]["found"] == 1 and want[id(dim)]["found"] == 2
+    n = 19
+    with _native.Context(0, 1489, 2048, n) as ctx:
+        for pattern in ([1, 2, 17], list(range(0, n, 2)), [], list(range(n))):
+            batch = [bright] * n
+            for j, i in enumerate(pattern):
+                batch[i] = dim if j % 2 == 0 else none
+            res = ctx.detect_batch(np.stack(batch), pb, pd)
+            for i in range(n):
+                assert same(res[i], want[id(batch[i])]), (pattern, i)
