@@ -1095,6 +1095,8 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         while (nsplit < ctx->vote_split && nslabs * n_img * nc * nsplit < vote_wgs) nsplit <<= 1;
         // two images: their pieces come out of one pool per slab, shared out by list length on the device (k_hough_vote: balance)
         const bool vote_balance = ctx->vote_balance; // (developer switch LFDMI_VOTE_BALANCE)
+        // (unsplit lists -- 4096 x 4096 frames at rho = 5: 12 slabs x 2 images x 256 frames fill the GPU already -- gain nothing from
+        // four pieces per slab: 2.78 vs 2.79 ms)
         const int balance = (vote_balance && n_img == 2 && nsplit >= 2) ? 1 : 0;
         int acc_n = (na + 2) * (nr + 2);
         { Span sp(ctx, KID_PIXLIST, need_detect);
@@ -1104,8 +1106,8 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
                                                                     active, need_detect);
         KCHK("k_pixlist"); }
         Span sp(ctx, KID_VOTE, need_detect);
-        dim3 vgrid(nslabs * nsplit * (balance ? 2 : 1), balance ? 1 : n_img, nc);
         const int vsplit = balance ? 2 * nsplit : nsplit;
+        dim3 vgrid(nslabs * vsplit, balance ? 1 : n_img, nc);
         size_t vlds = ((size_t)nbmax << aw_log2) * 4 + 256;
 #define LFD_LAUNCH_VOTE(L)                                                                                          \
     case L:                                                                                                         \
