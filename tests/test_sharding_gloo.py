@@ -69,3 +69,16 @@ def test_two_ranks_ragged_split():
 def test_single_process_passthrough():
     rec = _fake_records(0, 5)
     assert batch.gather_results(rec, 5) is rec
+
+
+def test_eight_ranks_config3_blocks():
+    """BASELINE configs[3]'s placement: 8 192 frames over eight ranks, 1 024 each (and a ragged 8 190), the records of all ranks
+    gathered on every rank -- eight gloo processes on the CPU (the one part of the eight-GPU run that needs no GPU)."""
+    out = _run(8, 8192)
+    assert [(a, b) for _, a, b, _ in out] == [(1024 * r, 1024 * (r + 1)) for r in range(8)]
+    want = _fake_records(0, 8192).tobytes()
+    assert all(buf == want for *_, buf in out)
+    out = _run(8, 8190)
+    assert [(a, b) for _, a, b, _ in out][-1] == (7168, 8190)
+    want = _fake_records(0, 8190).tobytes()
+    assert all(buf == want for *_, buf in out)
