@@ -2079,6 +2079,13 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
     if (feed || pinned) {
         size_t fpc = (ctx->feed_chunk_bytes ? ctx->feed_chunk_bytes : (size_t)(800u << 20)) / (N * 4);
         per = (int)std::min<size_t>((size_t)ctx->G, std::max<size_t>(1, fpc));
+        // pinned frames: at least four chunks per call, so that all but the first chunk's upload runs beside the previous chunk's
+        // passes (a 64-frame call as one chunk was 15.6 ms of upload followed by 2.5 ms of kernels)
+        if (pinned) {
+            const char *pe = getenv("LFDMI_PINNED_CHUNKS"); // developer knob (read per call)
+            const int pin_div = pe ? std::max(1, atoi(pe)) : 4;
+            per = std::max(std::min(per, 8), std::min(per, (n + pin_div - 1) / pin_div));
+        }
         RET(feed_prepare(ctx, (size_t)std::min(per, n) * N * 4, feed));
     }
     FeedState fs;
