@@ -2079,11 +2079,15 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
     if (feed || pinned) {
         size_t fpc = (ctx->feed_chunk_bytes ? ctx->feed_chunk_bytes : (size_t)(800u << 20)) / (N * 4);
         per = (int)std::min<size_t>((size_t)ctx->G, std::max<size_t>(1, fpc));
-        // pinned frames: at least four chunks per call, so that all but the first chunk's upload runs beside the previous chunk's
-        // passes (a 64-frame call as one chunk was 15.6 ms of upload followed by 2.5 ms of kernels)
+        // pinned frames: one upload per call unless asked otherwise.  Cutting a call into k upload chunks (LFDMI_PINNED_CHUNKS=k,
+        // developer knob, read per call) overlaps chunk c + 1's upload with chunk c's passes, but a 64-frame call is 14 ms of PCIe
+        // for 1.5 ms of kernels, and what the overlap buys depends on which hardware queues HIP happens to give the five streams
+        // of a context: measured 2 940 - 3 650 frames/s with k = 4 across process states (torch initialised or not, a second
+        // context alive, GPU_MAX_HW_QUEUES=8, high-priority copy streams) against 3 430 - 3 500 in all of them with k = 1
+        // (profiles/README.md, round-3 log)
         if (pinned) {
-            const char *pe = getenv("LFDMI_PINNED_CHUNKS"); // developer knob (read per call)
-            const int pin_div = pe ? std::max(1, atoi(pe)) : 4;
+            const char *pe = getenv("LFDMI_PINNED_CHUNKS");
+            const int pin_div = pe ? std::max(1, atoi(pe)) : 1;
             per = std::max(std::min(per, 8), std::min(per, (n + pin_div - 1) / pin_div));
         }
         RET(feed_prepare(ctx, (size_t)std::min(per, n) * N * 4, feed));
