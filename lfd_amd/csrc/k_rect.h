@@ -204,25 +204,16 @@ __device__ __forceinline__ void hv_vect(const HV &hv, int i, float *vx, float *v
 }
 
 // rotcalipers.cpp CALIPERS_MINAREARECT, n > 2.  out = corner, vec1, vec2 (6 floats).
+// (core: from the four extreme vertices on; rotating_calipers_dev finds them with the sequential scan of the source, the
+// wave-per-key kernel with a wave-wide one that resolves ties the same way: lowest index)
 template <class HV>
-__device__ void rotating_calipers_dev(const HV &hv, float *out) {
+__device__ void rotating_calipers_core(const HV &hv, int left, int bottom, int right, int top, float *out) {
     int n = hv.n;
     float minarea = 3.402823466e+38f;
     int buf_i0 = 0, buf_i5 = 0;
     float buf1 = 0, buf2 = 0, buf3 = 0, buf4 = 0;
-    int left = 0, bottom = 0, right = 0, top = 0;
     int seq[4];
     float orientation = 0, base_a, base_b = 0;
-    float left_x, right_x, top_y, bottom_y;
-    left_x = right_x = hv.px(0);
-    top_y = bottom_y = hv.py(0);
-    for (int i = 0; i < n; i++) {
-        float x = hv.px(i), y = hv.py(i);
-        if (x < left_x) { left_x = x; left = i; }
-        if (x > right_x) { right_x = x; right = i; }
-        if (y > top_y) { top_y = y; top = i; }
-        if (y < bottom_y) { bottom_y = y; bottom = i; }
-    }
     {
         float vx, vy, il;
         hv_vect(hv, n - 1, &vx, &vy, &il);
@@ -297,6 +288,30 @@ __device__ void rotating_calipers_dev(const HV &hv, float *out) {
     }
 }
 
+template <class HV>
+__device__ void rotating_calipers_dev(const HV &hv, float *out) {
+    int n = hv.n;
+    int left = 0, bottom = 0, right = 0, top = 0;
+    float left_x, right_x, top_y, bottom_y;
+    left_x = right_x = hv.px(0);
+    top_y = bottom_y = hv.py(0);
+    for (int i = 0; i < n; i++) {
+        float x = hv.px(i), y = hv.py(i);
+        if (x < left_x) { left_x = x; left = i; }
+        if (x > right_x) { right_x = x; right = i; }
+        if (y > top_y) { top_y = y; top = i; }
+        if (y < bottom_y) { bottom_y = y; bottom = i; }
+    }
+    rotating_calipers_core(hv, left, bottom, right, top, out);
+}
+
+// What the wave-per-key kernel works out with all its lanes before the (sequential) calipers: the scans over the hull.
+struct HullPre {
+    int left, bottom, right, top;   // first vertex with the smallest x / smallest y / largest x / largest y
+    long long a2;                   // twice the signed area (shoelace)
+    int xmin, xmax, ymin, ymax;
+};
+
 __device__ __forceinline__ long long cross_i(int2 o, int2 a, int2 b) {
     return (long long)(a.x - o.x) * (b.y - o.y) - (long long)(a.y - o.y) * (b.x - o.x);
 }
@@ -304,7 +319,7 @@ __device__ __forceinline__ long long cross_i(int2 o, int2 a, int2 b) {
 // minAreaRect of a hull -> lfd's filter -> boxPoints -> truncated quad appended to the slot's list
 template <class HV>
 __device__ __forceinline__ void rect_from_hull(const HV &hv, double minLen, double lwTresh, int *cnt, int *quads,
-                                               size_t quad_base, bool writer) {
+                                               size_t quad_base, bool writer, const HullPre *pre = nullptr) {
     float cx = 0, cy = 0, sw = 0, sh = 0, angle = 0;
     if (hv.n > 2) {
         // Cheap certain rejection before the calipers: the rectangle contains the hull (area sw * sh >= A) and
@@ -313,23 +328,28 @@ __device__ __forceinline__ void rect_from_hull(const HV &hv, double minLen, doub
         // D^2 / A ~ 1.3) can never pass `length / width > lwTresh`; the 0.1 % margin is three orders of
         // magnitude above the float32 noise of the exact computation.  Integer shoelace, exact.
         {
-            int2 p0 = hv.at(0);
-            int xmin = p0.x, xmax = p0.x, ymin = p0.y, ymax = p0.y;
+            int xmin, xmax, ymin, ymax;
             long long a2 = 0;
-            int2 prev = p0;
-            for (int i = 1; i < hv.n; i++) {
-                int2 q = hv.at(i);
-                a2 += (long long)prev.x * q.y - (long long)q.x * prev.y;
-                xmin = min(xmin, q.x); xmax = max(xmax, q.x); ymin = min(ymin, q.y); ymax = max(ymax, q.y);
-                prev = q;
+            if (pre) { xmin = pre->xmin; xmax = pre->xmax; ymin = pre->ymin; ymax = pre->ymax; a2 = pre->a2; }
+            else {
+                int2 p0 = hv.at(0);
+                xmin = p0.x; xmax = p0.x; ymin = p0.y; ymax = p0.y;
+                int2 prev = p0;
+                for (int i = 1; i < hv.n; i++) {
+                    int2 q = hv.at(i);
+                    a2 += (long long)prev.x * q.y - (long long)q.x * prev.y;
+                    xmin = min(xmin, q.x); xmax = max(xmax, q.x); ymin = min(ymin, q.y); ymax = max(ymax, q.y);
+                    prev = q;
+                }
+                a2 += (long long)prev.x * p0.y - (long long)p0.x * prev.y;
             }
-            a2 += (long long)prev.x * p0.y - (long long)p0.x * prev.y;
             if (a2 < 0) a2 = -a2;
             double d2 = (double)(xmax - xmin) * (xmax - xmin) + (double)(ymax - ymin) * (ymax - ymin);
             if (a2 > 0 && lwTresh > 0 && 2.0 * d2 < lwTresh * (double)a2 * 0.999) return;
         }
         float out[6];
-        rotating_calipers_dev(hv, out);
+        if (pre) rotating_calipers_core(hv, pre->left, pre->bottom, pre->right, pre->top, out);
+        else rotating_calipers_dev(hv, out);
         cx = __fadd_rn(out[0], __fmul_rn(__fadd_rn(out[2], out[4]), 0.5f));
         cy = __fadd_rn(out[1], __fmul_rn(__fadd_rn(out[3], out[5]), 0.5f));
         sw = (float)sqrt((double)out[2] * out[2] + (double)out[3] * out[3]);
@@ -473,9 +493,92 @@ __device__ __forceinline__ int2 *filter_chain(int2 *A, int2 *B, int *n_io) {
     return A;
 }
 
+// The hull of a wave-per-key key laid out for the sequential calipers: vertices rotated so that vertex 0 is (min x, then min y),
+// and every edge's vector and reciprocal length (hv_vect's double-precision square root and division, the expensive part of a
+// calipers step) evaluated once, by all lanes side by side, with the expressions of hv_vect -- same bits, no dependent chain.
+struct PreHullView {
+    const int2 *P;     // n vertices
+    const float *E;    // n x (vx, vy, 1 / length) of the edge i -> i + 1
+    int n;
+    __device__ __forceinline__ int2 at(int i) const { return P[i]; }
+    __device__ __forceinline__ float px(int i) const { return (float)P[i].x; }
+    __device__ __forceinline__ float py(int i) const { return (float)P[i].y; }
+};
+__device__ __forceinline__ void hv_vect(const PreHullView &hv, int i, float *vx, float *vy, float *inv) {
+    *vx = hv.E[3 * i]; *vy = hv.E[3 * i + 1]; *inv = hv.E[3 * i + 2];
+}
+
+// lane-parallel argmin / argmax over (value, index) with the lowest index on equal values
+__device__ __forceinline__ void wave_arg(int &v, int &i, bool want_max) {
+    for (int o = 32; o > 0; o >>= 1) {
+        int ov = __shfl_xor(v, o), oi = __shfl_xor(i, o);
+        bool take = want_max ? (ov > v || (ov == v && oi < i)) : (ov < v || (ov == v && oi < i));
+        if (take) { v = ov; i = oi; }
+    }
+}
+
+// Fills P (LDS, at least n int2) from the raw hull and returns the scans of rect_from_hull / the calipers.
+template <class HV>
+__device__ __forceinline__ HullPre wave_prepare_hull(const HV &raw, int2 *P) {
+    const int n = raw.n, lane = lfd_lane();
+    // vertex 0: smallest x, then smallest y (vertices are distinct)
+    int bx = 0x7fffffff, by = 0x7fffffff, bi = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        int2 v = raw.raw(i);
+        if (v.x < bx || (v.x == bx && v.y < by)) { bx = v.x; by = v.y; bi = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        int ox = __shfl_xor(bx, o), oy = __shfl_xor(by, o), oi = __shfl_xor(bi, o);
+        if (ox < bx || (ox == bx && oy < by)) { bx = ox; by = oy; bi = oi; }
+    }
+    const int s0 = bi;
+    for (int i = lane; i < n; i += 64) {
+        int k = i + s0;
+        if (k >= n) k -= n;
+        P[i] = raw.raw(k);
+    }
+    __syncthreads(); // (one wave per block)
+    HullPre pre;
+    int lv = 0x7fffffff, li = 0x7fffffff, rv = -0x7fffffff - 1, ri = 0x7fffffff, tv = -0x7fffffff - 1, ti = 0x7fffffff, bv = 0x7fffffff, bti = 0x7fffffff;
+    long long a2 = 0;
+    for (int i = lane; i < n; i += 64) {
+        int j = (i + 1 < n) ? i + 1 : 0;
+        int2 a = P[i], b = P[j];
+        a2 += (long long)a.x * b.y - (long long)b.x * a.y;
+        if (a.x < lv) { lv = a.x; li = i; }   // (i increases per lane: strict compares keep the lane's first index)
+        if (a.x > rv) { rv = a.x; ri = i; }
+        if (a.y > tv) { tv = a.y; ti = i; }
+        if (a.y < bv) { bv = a.y; bti = i; }
+    }
+    wave_arg(lv, li, false);
+    wave_arg(rv, ri, true);
+    wave_arg(tv, ti, true);
+    wave_arg(bv, bti, false);
+    for (int o = 32; o > 0; o >>= 1) a2 += __shfl_xor(a2, o);
+    pre.left = li; pre.right = ri; pre.top = ti; pre.bottom = bti;
+    pre.a2 = a2;
+    pre.xmin = lv; pre.xmax = rv; pre.ymax = tv; pre.ymin = bv;
+    __syncthreads();
+    return pre;
+}
+
+// E (LDS, 3 n floats): every edge's vector and reciprocal length, hv_vect's expressions, one edge per lane and round
+__device__ __forceinline__ void wave_edges(const int2 *P, float *E, int n) {
+    for (int i = lfd_lane(); i < n; i += 64) {
+        int j = (i + 1 < n) ? i + 1 : 0;
+        int2 a = P[i], b = P[j];
+        double dx = (double)__fsub_rn((float)b.x, (float)a.x);
+        double dy = (double)__fsub_rn((float)b.y, (float)a.y);
+        E[3 * i] = (float)dx;
+        E[3 * i + 1] = (float)dy;
+        E[3 * i + 2] = (float)(1. / sqrt(dx * dx + dy * dy));
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(64)
 k_rects_big(const int4 *keys, const int *bigkeys, int cidx, const int2 *rowext, int *quads, int *counters, int h, int w,
-            int key_cap, int slot_cap, int cap, double minLen, double lwTresh, const int *active) {
+            int key_cap, int slot_cap, int cap, double minLen, double lwTresh, const int *active, int wave_prep) {
     int g = blockIdx.y;
     if (slot_off(active, counters, g)) return;
     extern __shared__ int2 lds_pts[]; // 4 x cap
@@ -490,12 +593,28 @@ k_rects_big(const int4 *keys, const int *bigkeys, int cidx, const int2 *rowext, 
         if (extent > cap) { if (lane == 0) cnt[C_OVERFLOW] = 1; continue; }
         int2 *P0 = lds_pts, *P1 = lds_pts + cap, *P2 = lds_pts + 2 * cap, *P3 = lds_pts + 3 * cap;
         __syncthreads();
+        // the key's rows into P3 first, eight loads per lane in flight (a tall key is 24 rounds of 64 rows; one dependent
+        // global load per round and chain was most of this kernel's time)
+        for (int r0 = 0; r0 < extent; r0 += 512) {
+            int2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                int r = r0 + u * 64 + lane;
+                v[u] = r < extent ? re[base + r] : make_int2(1, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                int r = r0 + u * 64 + lane;
+                if (r < extent) P3[r] = v[u];
+            }
+        }
+        __syncthreads();
         // chain 1: left-most pixel of every row, rows increasing
         int n1 = 0;
         for (int r0 = 0; r0 < extent; r0 += 64) {
             int r = r0 + lane;
             int2 e = make_int2(1, 0);
-            if (r < extent) e = re[base + r];
+            if (r < extent) e = P3[r];
             bool ok = e.x <= e.y;
             u64 bal = __ballot(ok);
             if (ok) P0[n1 + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(e.x, ymin + r);
@@ -506,7 +625,7 @@ k_rects_big(const int4 *keys, const int *bigkeys, int cidx, const int2 *rowext, 
         for (int r0 = 0; r0 < extent; r0 += 64) {
             int r = extent - 1 - (r0 + lane);
             int2 e = make_int2(1, 0);
-            if (r >= 0) e = re[base + r];
+            if (r >= 0) e = P3[r];
             bool ok = e.x <= e.y;
             u64 bal = __ballot(ok);
             if (ok) P2[n2 + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(e.y, ymin + r);
@@ -521,6 +640,22 @@ k_rects_big(const int4 *keys, const int *bigkeys, int cidx, const int2 *rowext, 
         if (bnd > a && c2[bnd - 1].x == c1[0].x && c2[bnd - 1].y == c1[0].y) bnd--;
         LdsHullView hv;
         hv.c1 = c1; hv.c2 = c2 + a; hv.n1 = n1; hv.n = n1 + (bnd - a); hv.s0 = 0;
+        // the two buffers the chains did not end up in hold the prepared hull when it fits (it does unless a key is nearly convex
+        // over its whole height: 3 floats per edge in 2 * cap floats)
+        int2 *F1 = (c1 == P0) ? P1 : P0, *F2 = (c2 == P2) ? P3 : P2;
+        if (hv.n > 2 && 3 * hv.n <= 2 * cap && wave_prep) {
+            HullPre pre = wave_prepare_hull(hv, F1);
+            { // rect_from_hull's certain rejection (roundish contours: most keys), before the edges are worked out
+                long long A2 = pre.a2 < 0 ? -pre.a2 : pre.a2;
+                double d2 = (double)(pre.xmax - pre.xmin) * (pre.xmax - pre.xmin) + (double)(pre.ymax - pre.ymin) * (pre.ymax - pre.ymin);
+                if (A2 > 0 && lwTresh > 0 && 2.0 * d2 < lwTresh * (double)A2 * 0.999) continue;
+            }
+            wave_edges(F1, (float *)F2, hv.n);
+            PreHullView pv;
+            pv.P = F1; pv.E = (const float *)F2; pv.n = hv.n;
+            rect_from_hull(pv, minLen, lwTresh, cnt, quads, (size_t)g * key_cap, lane == 0, &pre);
+            continue;
+        }
         int s0 = 0;
         int2 best = hv.raw(0);
         for (int i = 1; i < hv.n; i++) {

@@ -108,8 +108,10 @@ struct lfdmi_ctx {
     bool use_tile_perm = true;         // LFDMI_TILE_PERM=0
     bool sky_fast = true;              // LFDMI_SKY_FAST=0: the bright sweep without its all-sky shortcut
     bool vote_classes = true;          // LFDMI_VOTE_CLASSES=0: one chunk list per image (no longer cut for the mid-angle slabs)
+    bool rects_prep = true;            // LFDMI_RECTS_PREP=0: the wave-per-key rectangle kernels scan their hulls sequentially
     bool vote_balance = true;          // LFDMI_VOTE_BALANCE=0: a fixed number of list pieces per image in the vote kernel
     lfdmi_result *res_dev = nullptr;   // G x LFDMI_MAX_SCALES records (one block of G per Hough scale)
+    void *res_host = nullptr;          // page-locked: G flags + G records of the chunk just finished (lfdmi_detect_batch)
     // Workspace sizing (include/lfdmi.h: lfdmi_caps).  A compact context keeps a worst-case one for single frames
     // (`spill`, created on first use): a frame whose tables overflow here (per-frame LFDMI_ERR_CAPACITY) is run
     // again there, so no input fails for lack of table space.
@@ -380,6 +382,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_SKY_FAST")) ctx->sky_fast = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_VOTE_CLASSES")) ctx->vote_classes = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_VOTE_BALANCE")) ctx->vote_balance = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_RECTS_PREP")) ctx->rects_prep = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_PERM")) ctx->use_perm = atoi(e) != 0;
     RET(dmalloc(ctx, &ctx->fb_fg, G));
     RET(dmalloc(ctx, &ctx->fb_bg, G));
@@ -418,8 +421,13 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
         RET(dmalloc(ctx, &ctx->candmask, G * (size_t)((max_h + MORPH_TH - 1) / MORPH_TH) * 2));
     }
     RET(dmalloc(ctx, &ctx->need_dim, G));
-    RET(dmalloc(ctx, &ctx->pass_flags, G));
-    RET(dmalloc(ctx, &ctx->res_dev, G * LFDMI_MAX_SCALES));
+    { // flags and records side by side: lfdmi_detect_batch fetches both with one copy into page-locked memory (res_host)
+        char *blk = nullptr;
+        RET(dmalloc(ctx, &blk, G * sizeof(int) + G * LFDMI_MAX_SCALES * sizeof(lfdmi_result)));
+        ctx->pass_flags = (int *)blk;
+        ctx->res_dev = (lfdmi_result *)(blk + G * sizeof(int));
+        HIPCHK(hipHostMalloc(&ctx->res_host, G * sizeof(int) + G * sizeof(lfdmi_result), hipHostMallocDefault));
+    }
     HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
@@ -495,6 +503,7 @@ extern "C" void lfdmi_ctx_destroy(lfdmi_ctx *ctx) {
         if (ctx->ev_join[i]) hipEventDestroy(ctx->ev_join[i]);
     }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->res_host) hipHostFree(ctx->res_host);
     delete ctx;
 }
 
@@ -945,28 +954,31 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     // but each holding 24 KB of LDS, kept the two wave-per-key kernels on the side streams waiting: 0.405 -> 0.355 ms per step)
     static const int rects_grid = getenv("LFDMI_RECTS_GRID") ? std::max(1, atoi(getenv("LFDMI_RECTS_GRID"))) : 8; // developer knobs
     static const bool rects_side = getenv("LFDMI_RECTS_SIDE") ? atoi(getenv("LFDMI_RECTS_SIDE")) != 0 : true;
+    const int wave_prep = ctx->rects_prep ? 1 : 0; // (developer switch LFDMI_RECTS_PREP)
+    static const int med_grid = getenv("LFDMI_RECTS_MED_GRID") ? std::max(1, atoi(getenv("LFDMI_RECTS_MED_GRID"))) : 64;
+    static const int big_grid = getenv("LFDMI_RECTS_BIG_GRID") ? std::max(1, atoi(getenv("LFDMI_RECTS_BIG_GRID"))) : 8;
     if (!rects_side) { // all three on the launch stream, one after the other (to see what the side streams buy)
-        k_rects_big<<<dim3(32, nc), 64, (size_t)BIG_KEY_ROWS * 4 * sizeof(int2), ctx->stream>>>(
+        k_rects_big<<<dim3(med_grid, nc), 64, (size_t)BIG_KEY_ROWS * 4 * sizeof(int2), ctx->stream>>>(
             ctx->keys, ctx->medkeys, C_NMED, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, BIG_KEY_ROWS,
-            minLen, lwTresh, active);
-        k_rects_big<<<dim3(8, nc), 64, (size_t)cap * 4 * sizeof(int2), ctx->stream>>>(
+            minLen, lwTresh, active, wave_prep);
+        k_rects_big<<<dim3(big_grid, nc), 64, (size_t)cap * 4 * sizeof(int2), ctx->stream>>>(
             ctx->keys, ctx->bigkeys, C_NBIG, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, cap,
-            minLen, lwTresh, active);
+            minLen, lwTresh, active, wave_prep);
         k_rects<<<dim3(rects_grid, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, nullptr, ctx->quads, ctx->counters, h, w,
                                                         ctx->key_cap, ctx->slot_cap, minLen, lwTresh, active);
         KCHK("k_rects");
     } else {
     HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
     HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0));
-    k_rects_big<<<dim3(32, nc), 64, (size_t)BIG_KEY_ROWS * 4 * sizeof(int2), ctx->side[0]>>>(
+    k_rects_big<<<dim3(med_grid, nc), 64, (size_t)BIG_KEY_ROWS * 4 * sizeof(int2), ctx->side[0]>>>(
         ctx->keys, ctx->medkeys, C_NMED, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, BIG_KEY_ROWS,
-        minLen, lwTresh, active);
+        minLen, lwTresh, active, wave_prep);
     KCHK("k_rects_med");
     HIPCHK(hipEventRecord(ctx->ev_join[0], ctx->side[0]));
     HIPCHK(hipStreamWaitEvent(ctx->side[1], ctx->ev_fork, 0));
-    k_rects_big<<<dim3(8, nc), 64, (size_t)cap * 4 * sizeof(int2), ctx->side[1]>>>(
+    k_rects_big<<<dim3(big_grid, nc), 64, (size_t)cap * 4 * sizeof(int2), ctx->side[1]>>>(
         ctx->keys, ctx->bigkeys, C_NBIG, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, cap,
-        minLen, lwTresh, active);
+        minLen, lwTresh, active, wave_prep);
     KCHK("k_rects_big");
     HIPCHK(hipEventRecord(ctx->ev_join[1], ctx->side[1]));
     k_rects<<<dim3(rects_grid, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, nullptr, ctx->quads, ctx->counters, h, w,
@@ -2066,8 +2078,8 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
         return rc;
     }
     size_t N = (size_t)h * w;
-    std::vector<lfdmi_result> host((size_t)ctx->G);
-    std::vector<int> flags((size_t)ctx->G);
+    int *const flags = (int *)ctx->res_host;
+    lfdmi_result *const host = (lfdmi_result *)((char *)ctx->res_host + (size_t)ctx->G * sizeof(int));
     std::vector<int4> boxes;
     KeepEqu keep_guard(ctx, ctx->stage_mode == 1);
     ctx->stages_valid = ctx->keep_equ;
@@ -2171,12 +2183,11 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
             blotter = std::thread([=, bx = boxes, cpus = ctx->feed_cpus] { blot_host_frames(frames + (size_t)c0 * N, nc, h, w, cat, c0, bx, cpus); });
             blotted = true;
         }
-        HIPCHK(hipMemcpyAsync(host.data(), ctx->res_dev, (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(flags.data(), ctx->pass_flags, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->res_host, ctx->pass_flags, (size_t)ctx->G * sizeof(int) + (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
         { double t0_ = feed && getenv("LFDMI_FEED_TRACE") ? feed_now() : 0;
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (t0_ > 0) fprintf(stderr, "[feed] chunk %d (%d frames): passes synced after %.2f ms (t=%.2f)\n", kc, nc, feed_now() - t0_, feed_now()); }
-        if (!gg.again(flags.data(), nc)) break;
+        if (!gg.again(flags, nc)) break;
         }
         {
             int na[2] = {nc, 0}, nd[2] = {0, 0};
