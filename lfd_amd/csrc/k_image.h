@@ -174,17 +174,50 @@ __device__ __forceinline__ unsigned prep_f64(double x, int mode, double mf, doub
 // every pixel.  With 0 <= addFlux <= 1 and minFlux <= 0.5 that value is the bright one or one more, so one bit per pixel
 // (dbits, a bit-row plane in the output orientation) and the dim image's histogram (hist2) are all the dim pass's front end
 // needs besides the 8-bit bright image: it never reads the float frames again (12.2 MB -> 3.4 MB per SDSS frame).
-template <int MODE, bool DELTA = false, bool MFPOS = false> // MFPOS: DELTA with mf2 > 0 (one compare and one select per value)
+// RS: remove_stars' squares (k_rs_boxes) are applied to the values as they are loaded -- a blotted pixel is 0.0f whatever the
+// frame holds -- so the sweep does not wait for k_rs_fill's stores (which then run beside the latency-bound stages of the
+// pass, see lfdmi_detect_batch).  A workgroup marks the squares that cross its rows in an LDS bit plane first (every object
+// of the frame is looked at: ~400 int4 from L2, two per lane), one bit per pixel, rows of RS_MAXW / 32 words.
+#define RS_MAXW 4096
+#define RS_MAXROWS 16
+template <int MODE, bool DELTA = false, bool MFPOS = false, bool RS = false> // MFPOS: DELTA with mf2 > 0 (one compare and one select per value)
 __global__ void __launch_bounds__(256)
 k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double minFlux,
             double addFlux, uint8_t *gray, int *hist, u64 *cellbm, int bm_bands, const int *active, u64 *fullbits,
             int prep_rows, // rows per workgroup: a divisor of CELLBM_ROWS (a workgroup's rows lie in one band)
             u64 *dbits = nullptr, int *hist2 = nullptr, float mf2 = 0.f, float af2 = 0.f, u64 *nzd = nullptr,
-            int sky_fast = 0) { // DELTA + MFPOS with fl(mf2 + af2) > 0.5 (host-checked): the all-sky shortcut below is exact
+            int sky_fast = 0, // DELTA + MFPOS with fl(mf2 + af2) > 0.5 (host-checked): the all-sky shortcut below is exact
+            const int4 *rs_boxes = nullptr, const int *rs_count = nullptr, int rs_max_obj = 0) { // RS: w <= RS_MAXW, prep_rows <= RS_MAXROWS
     int g = blockIdx.y;
     if (active && !active[g]) return;
     __shared__ int sh[DELTA ? 8 : 4][256];
+    __shared__ uint32_t rsm[RS ? RS_MAXROWS * (RS_MAXW / 32) : 1];
+    const int rsw = w >> 5; // (RS: w % 32 == 0, a DELTA precondition)
     for (int k = threadIdx.x; k < (DELTA ? 2048 : 1024); k += 256) ((int *)sh)[k] = 0;
+    if (RS) {
+        for (int k = threadIdx.x; k < prep_rows * rsw; k += 256) rsm[k] = 0u;
+        __syncthreads();
+        const int ra = blockIdx.x * prep_rows, rb_ = min(ra + prep_rows, h); // this workgroup's output rows [ra, rb_)
+        // ... which are the source rows [sa, sb) (k_rs_boxes' squares are in the frame's own orientation)
+        const int sa = flip ? h - rb_ : ra, sb = flip ? h - ra : rb_;
+        const int n_obj = min(rs_count[g], rs_max_obj);
+        for (int o = threadIdx.x; o < n_obj; o += 256) {
+            const int4 bx = rs_boxes[(size_t)g * rs_max_obj + o]; // rows [x, y) x columns [z, w)
+            const int y0 = max(bx.x, sa), y1 = min(bx.y, sb);
+            if (y0 >= y1 || bx.w <= bx.z) continue;
+            const int wa = bx.z >> 5, wb = (bx.w - 1) >> 5;
+            for (int sr = y0; sr < y1; sr++) {
+                const int r = flip ? h - 1 - sr : sr;
+                uint32_t *row = rsm + (r - ra) * rsw;
+                for (int wq_ = wa; wq_ <= wb; wq_++) {
+                    uint32_t m = 0xFFFFFFFFu;
+                    if (wq_ == wa) m &= 0xFFFFFFFFu << (bx.z & 31);
+                    if (wq_ == wb) m &= 0xFFFFFFFFu >> (31 - ((bx.w - 1) & 31));
+                    atomicOr(&row[wq_], m);
+                }
+            }
+        }
+    }
     __syncthreads();
     int wv = threadIdx.x >> 6;
     size_t N = (size_t)h * w;
@@ -208,6 +241,18 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
                 for (int k = 0; k < 4; k++) {
                     int r = rb + k;
                     if (FULL || (k < prep_rows && r < h)) v[k] = ((const float4 *)(fs + (size_t)(flip ? (h - 1 - r) : r) * w))[x4];
+                }
+                if constexpr (RS) { // blotted pixels are +0.0f (v_bfe_i32: all ones where the pixel's bit is set; v_bfi_b32 clears those)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        int r = rb + k;
+                        if (!FULL && (k >= prep_rows || r >= h)) break;
+                        const uint32_t nib = rsm[(r - r0) * rsw + (x4 >> 3)] >> ((x4 & 7) * 4);
+                        v[k].x = __uint_as_float(__float_as_uint(v[k].x) & ~(uint32_t)(((int)(nib << 31)) >> 31));
+                        v[k].y = __uint_as_float(__float_as_uint(v[k].y) & ~(uint32_t)(((int)(nib << 30)) >> 31));
+                        v[k].z = __uint_as_float(__float_as_uint(v[k].z) & ~(uint32_t)(((int)(nib << 29)) >> 31));
+                        v[k].w = __uint_as_float(__float_as_uint(v[k].w) & ~(uint32_t)(((int)(nib << 28)) >> 31));
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {

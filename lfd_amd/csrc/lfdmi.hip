@@ -108,6 +108,14 @@ struct lfdmi_ctx {
     bool use_tile_perm = true;         // LFDMI_TILE_PERM=0
     bool sky_fast = true;              // LFDMI_SKY_FAST=0: the bright sweep without its all-sky shortcut
     bool vote_classes = true;          // LFDMI_VOTE_CLASSES=0: one chunk list per image (no longer cut for the mid-angle slabs)
+    bool rs_fold_on = true;            // LFDMI_RS_FOLD=0: lfdmi_detect_batch zero-fills remove_stars' squares before the sweep instead of masking them in it
+    bool rs_fold = false;              // (this chunk: the sweep masks the squares of rs_boxes; rs_count_dev / rs_max_obj describe them)
+    const int *rs_count_dev = nullptr; int rs_max_obj = 0;
+    int rs_fill_at = 4;                // LFDMI_RS_FILL_AT: where the deferred zero fill of device-resident frames is enqueued (developer)
+    float *rs_fill_frames = nullptr;   // (pending deferred fill: frames, nc, h, w)
+    int rs_fill_nc = 0, rs_fill_h = 0, rs_fill_w = 0;
+    hipEvent_t ev_rsfill = nullptr;
+    bool rs_fill_inflight = false;
     bool rects_prep = true;            // LFDMI_RECTS_PREP=0: the wave-per-key rectangle kernels scan their hulls sequentially
     bool vote_balance = true;          // LFDMI_VOTE_BALANCE=0: a fixed number of list pieces per image in the vote kernel
     lfdmi_result *res_dev = nullptr;   // G x LFDMI_MAX_SCALES records (one block of G per Hough scale)
@@ -219,7 +227,8 @@ static int fail(lfdmi_ctx *c, int code, const std::string &msg) {
 struct Span {
     lfdmi_ctx *c;
     int idx = -1;
-    Span(lfdmi_ctx *ctx, int group, int det = 0) : c(ctx) {
+    hipStream_t st;
+    Span(lfdmi_ctx *ctx, int group, int det = 0, hipStream_t on = nullptr) : c(ctx), st(on ? on : ctx->stream) {
         if (!c->timing || (c->timing_mask && !((c->timing_mask >> group) & 1ull))) return;
         TimedSpan s;
         s.group = group;
@@ -229,12 +238,12 @@ struct Span {
             if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); }
             else hipEventCreate(e);
         }
-        hipEventRecord(s.a, c->stream);
+        hipEventRecord(s.a, st);
         c->spans.push_back(s);
         idx = (int)c->spans.size() - 1;
     }
     ~Span() {
-        if (idx >= 0) hipEventRecord(c->spans[idx].b, c->stream);
+        if (idx >= 0) hipEventRecord(c->spans[idx].b, st);
     }
 };
 
@@ -352,6 +361,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
         HIPCHK(hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_rsfill, hipEventDisableTiming));
     RET(dmalloc(ctx, &ctx->gray, G * N));
     RET(dmalloc(ctx, &ctx->tmp, G * N));
     RET(dmalloc(ctx, &ctx->equ, G * N));
@@ -383,6 +393,8 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_VOTE_CLASSES")) ctx->vote_classes = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_VOTE_BALANCE")) ctx->vote_balance = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_RECTS_PREP")) ctx->rects_prep = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_RS_FOLD")) ctx->rs_fold_on = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_RS_FILL_AT")) ctx->rs_fill_at = atoi(e);
     if (const char *e = getenv("LFDMI_PERM")) ctx->use_perm = atoi(e) != 0;
     RET(dmalloc(ctx, &ctx->fb_fg, G));
     RET(dmalloc(ctx, &ctx->fb_bg, G));
@@ -503,6 +515,7 @@ extern "C" void lfdmi_ctx_destroy(lfdmi_ctx *ctx) {
         if (ctx->ev_join[i]) hipEventDestroy(ctx->ev_join[i]);
     }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_rsfill) hipEventDestroy(ctx->ev_rsfill);
     if (ctx->res_host) hipHostFree(ctx->res_host);
     delete ctx;
 }
@@ -604,6 +617,28 @@ static int sync(lfdmi_ctx *ctx, int nc = 0, const int *n_act = nullptr, const in
     return 0;
 }
 
+// lfdmi_detect_batch, device-resident frames whose squares the sweep masked (rs_fold): the zero fill the caller is owed runs on
+// side[1], started at stage k of the bright pass (LFDMI_RS_FILL_AT; -1: whatever is still pending), joined before the
+// chunk's results are fetched.  It is 0.63 GB of partial-line stores and next to no instructions.
+static int rs_fill_point(lfdmi_ctx *ctx, int k) {
+    if (!ctx->rs_fill_frames || (k >= 0 && k != ctx->rs_fill_at)) return 0;
+    float *fr = ctx->rs_fill_frames;
+    static const int side_i = getenv("LFDMI_RS_FILL_SIDE") ? (atoi(getenv("LFDMI_RS_FILL_SIDE")) & 1) : 1; // developer
+    hipStream_t sd = ctx->side[side_i];
+    ctx->rs_fill_frames = nullptr;
+    HIPCHK(hipEventRecord(ctx->ev_rsfill, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(sd, ctx->ev_rsfill, 0));
+    {
+        Span sp(ctx, KID_REMOVESTARS, 0, sd);
+        k_rs_fill<<<dim3((ctx->rs_max_obj + 3) / 4, ctx->rs_fill_nc), 256, 0, sd>>>(fr, ctx->rs_fill_h, ctx->rs_fill_w, ctx->rs_max_obj,
+                                                                                        ctx->rs_count_dev, ctx->rs_boxes);
+        KCHK("k_rs_fill");
+    }
+    HIPCHK(hipEventRecord(ctx->ev_rsfill, sd));
+    ctx->rs_fill_inflight = true;
+    return 0;
+}
+
 static dim3 word_grid(int h, int w, int n) { return dim3((unsigned)((h * LFD_WQ(w) + 255) / 256), (unsigned)n); }
 
 // ---- stage runners (device pointers only, nc <= G images in workspace slots 0..nc-1) --------
@@ -626,16 +661,18 @@ static int run_prep(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, i
     k_prep_hist<M_><<<pgrid, 256, 0, ctx->stream>>>(src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist, ctx->cellbm, \
                                                     ctx->bm_bands, active, fullbits, prep_rows)
         if (delta_dim) { // the bright pass of lfdmi_detect_batch: the dim pass's values and histogram from the same sweep
-#define LFD_PREP_DELTA(P_)                                                                                                            \
-    k_prep_hist<1, true, P_><<<pgrid, 256, 0, ctx->stream>>>(src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist,     \
+#define LFD_PREP_DELTA(P_, RS_)                                                                                                       \
+    k_prep_hist<1, true, P_, RS_><<<pgrid, 256, 0, ctx->stream>>>(src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist, \
                                                               ctx->cellbm, ctx->bm_bands, active, fullbits, prep_rows, ctx->dbits,    \
-                                                              ctx->hist2, (float)delta_dim->minFlux, (float)delta_dim->addFlux, ctx->nzd, sky_fast)
+                                                              ctx->hist2, (float)delta_dim->minFlux, (float)delta_dim->addFlux, ctx->nzd, sky_fast, \
+                                                              ctx->rs_boxes, ctx->rs_count_dev, ctx->rs_max_obj)
             // (all-sky shortcut of the sweep: exact when the smallest kept value already rounds to 1, see k_prep_hist)
             const bool sky_on = ctx->sky_fast; // (developer switch LFDMI_SKY_FAST)
             const float mfa = (float)delta_dim->minFlux + (float)delta_dim->addFlux;
             const int sky_fast = (sky_on && mode == LFDMI_PREP_BRIGHT && mfa > 0.5f) ? 1 : 0;
-            if ((float)delta_dim->minFlux > 0.f) LFD_PREP_DELTA(true);
-            else LFD_PREP_DELTA(false);
+            const bool rs = ctx->rs_fold && w <= RS_MAXW && prep_rows <= RS_MAXROWS; // (remove_stars' squares masked in the sweep)
+            if ((float)delta_dim->minFlux > 0.f) { if (rs) LFD_PREP_DELTA(true, true); else LFD_PREP_DELTA(true, false); }
+            else { if (rs) LFD_PREP_DELTA(false, true); else LFD_PREP_DELTA(false, false); }
 #undef LFD_PREP_DELTA
         } else
         if (dtype == LFDMI_F32 && (w & 3) == 0) { // float frames: the mode as a compile-time constant
@@ -746,6 +783,7 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
     { Span sp(ctx, KID_RUNS_INIT_FG);
       RET(run_scan(ctx, ctx->candb, 1, ctx->scanf_, C_NRUNF, nc, h, w, ctx->wl_fg, ctx->wl_bg, ctx->edgeb, active));
     }
+    RET(rs_fill_point(ctx, 3));
     if (ctx->frame_ccl) { // frames that fit the LDS tables; the rest (fallback flag) take the kernels below
         Span sp(ctx, KID_FRAME_FG);
         size_t lds = (size_t)(ctx->frame_lds + 2 * (ctx->frame_lds / 32)) * sizeof(int);
@@ -907,6 +945,7 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     rt.Lb = ctx->Lb; rt.YMb = ctx->YMb; rt.FLb = ctx->FLb; rt.SBb = ctx->SBb; rt.PAb = ctx->PAb; rt.ROWb = ctx->ROWb;
     rt.run_cap = rc;
     const int *gen = active; // frames for the general run kernels
+    RET(rs_fill_point(ctx, 4));
     if (ctx->frame_ccl) {
         Span sp(ctx, KID_FRAME_BG);
         size_t lds = (size_t)(ctx->frame_lds + 4 * (ctx->frame_lds / 32)) * sizeof(int);
@@ -986,6 +1025,7 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     KCHK("k_rects");
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[1], 0));
+    RET(rs_fill_point(ctx, 5));
     }
     }
     Span sp(ctx, KID_FILL);
@@ -1278,6 +1318,7 @@ static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, 
         const lfdmi_params *dd = (!dim && ctx->delta_state == 1) ? dual_dim : nullptr;
         if (dd) HIPCHK(hipMemsetAsync(ctx->hist2, 0, (size_t)nc * 256 * sizeof(int), ctx->stream));
         RET(run_prep(ctx, src, dtype, nc, h, w, flip, prep_mode, p->minFlux, p->addFlux, active, true, wide ? ctx->fullbits : nullptr, dd));
+        RET(rs_fill_point(ctx, 1));
         if (dim) {
             bool marked = false;
             // (the eroded plane is zero-filled only where the tile kernel can read it when that kernel is its one consumer)
@@ -1300,6 +1341,7 @@ static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, 
     } else if (can_fuse_dilate_canny(p->dilateKernel, p->dilate_kh, p->dilate_kw, w)) {
         // the prep kernel of this pass left the cell occupancy of its output (a superset of the eroded image's)
         RET(run_dilate_canny(ctx, dil_src, nc, h, w, ctx->lut, p->dilate_kh, p->dilate_kw, active, ctx->use_cellbm ? bm : nullptr));
+        RET(rs_fill_point(ctx, 2));
         RET(run_canny(ctx, ctx->equ, nc, h, w, 0, 255, active, true));
     } else {
         RET(run_morph(ctx, dil_src, ctx->equ, ctx->equb, ctx->lut, p->dilateKernel, p->dilate_kh, p->dilate_kw, 0, nc, h, w, active));
@@ -1611,7 +1653,7 @@ static int stage_catalog(lfdmi_ctx *ctx, const lfdmi_catalog *cat, int f0, int n
 }
 
 static int run_removestars(lfdmi_ctx *ctx, float *frames_dev, int f0, int nc, int h, int w, const lfdmi_catalog *cat,
-                           const lfdmi_rs_params *rs, std::vector<int4> *host_boxes = nullptr) {
+                           const lfdmi_rs_params *rs, std::vector<int4> *host_boxes = nullptr, bool fill = true) {
     if (!cat || cat->max_obj <= 0) return 0;
     if (!rs || rs->filter_index < 0 || rs->filter_index > 4) return fail(ctx, LFDMI_ERR_ARG, "removestars params");
     lfdmi_catalog dev;
@@ -1632,8 +1674,12 @@ static int run_removestars(lfdmi_ctx *ctx, float *frames_dev, int f0, int nc, in
         k_rs_boxes<<<dim3((cat->max_obj + 255) / 256, nc), 256, 0, ctx->stream>>>(h, w, cat->max_obj, dev.count, dev.rowc, dev.colc, dev.psfmag,
                                                                                dev.petro90, dev.nobserve, dev.ndetect, p, boxes);
         KCHK("k_rs_boxes");
-        k_rs_fill<<<dim3((cat->max_obj + 3) / 4, nc), 256, 0, ctx->stream>>>(frames_dev, h, w, cat->max_obj, dev.count, boxes);
-        KCHK("k_rs_fill");
+        ctx->rs_count_dev = dev.count;
+        ctx->rs_max_obj = cat->max_obj;
+        if (fill) {
+            k_rs_fill<<<dim3((cat->max_obj + 3) / 4, nc), 256, 0, ctx->stream>>>(frames_dev, h, w, cat->max_obj, dev.count, boxes);
+            KCHK("k_rs_fill");
+        }
     }
     if (host_boxes)
         HIPCHK(hipMemcpyAsync(host_boxes->data(), boxes, host_boxes->size() * sizeof(int4), hipMemcpyDeviceToHost, ctx->stream));
@@ -2057,7 +2103,7 @@ static int pinned_upload(lfdmi_ctx *ctx, const char *src, size_t bytes, int kc) 
 
 static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, int w, const lfdmi_catalog *cat,
                        const lfdmi_rs_params *rs, const lfdmi_params *bright, const lfdmi_params *dim,
-                       lfdmi_result *results, int loc) {
+                       lfdmi_result *results, int loc, int cat_f0 = 0) { // cat_f0: catalogue entry of frame 0 (a frame run again alone)
     RET(check_shape(ctx, n, h, w));
     RET(check_params(ctx, bright, false));
     RET(check_params(ctx, dim, true));
@@ -2073,7 +2119,7 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
         lfdmi_ctx *sp = get_spill(ctx); // rho finer than this workspace's accumulators: the worst-case one takes the call
         if (!sp || !hough_fits(sp, h, w, bright->houghMethod, LFD_PI / 180) || !hough_fits(sp, h, w, dim->houghMethod, LFD_PI / 180))
             return fail(ctx, LFDMI_ERR_CAPACITY, "Hough accumulator larger than the workspace (rho < 1 px)");
-        int rc = detect_impl(sp, frames, dtype, n, h, w, cat, rs, bright, dim, results, pinned ? LFDMI_HOST_PINNED : loc);
+        int rc = detect_impl(sp, frames, dtype, n, h, w, cat, rs, bright, dim, results, pinned ? LFDMI_HOST_PINNED : loc, cat_f0);
         if (rc) ctx->err = sp->err;
         return rc;
     }
@@ -2083,6 +2129,18 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
     std::vector<int4> boxes;
     KeepEqu keep_guard(ctx, ctx->stage_mode == 1);
     ctx->stages_valid = ctx->keep_equ;
+    // both passes read the same float frames: one sweep feeds both where the dim pass's front end can be fused at all
+    const bool dual = ctx->fuse_dual && can_fuse_prep_erode(ctx, LFDMI_F32, w, dim->erodeKernel, dim->erode_kh, dim->erode_kw);
+    // ... or, cheaper, the bright pass's sweep leaves one bit per pixel from which the dim pass rebuilds its 8-bit image
+    // (dim value = bright value + bit, for 0 <= addFlux <= 1 and minFlux <= 0.5) together with that image's histogram
+    // (small erosion kernels only: k_bits_erode fetches kh x kw values per surviving pixel, which is nothing on sky frames but
+    // would be slow on a dense image with a large kernel; those keep the band kernel)
+    // (addFlux must stay clear of 1: x = 0.5 gives bright rne(0.5) = 0 but dim rne(1.5) = 2, and an addFlux within half an ulp
+    // of 1 rounds x + addFlux up to the same tie; up to 0.999 the float sum of an even k + 0.5 < 256 stays below k + 1.5)
+    const bool delta = !dual && ctx->delta_dim && (w % 32) == 0 && (float)dim->addFlux >= 0.0f && (float)dim->addFlux <= 0.999f &&
+                       (float)dim->minFlux <= 0.5f &&
+                       dim->erode_kh * dim->erode_kw <= 25 &&
+                       can_fuse_prep_erode(ctx, LFDMI_F32, w, dim->erodeKernel, dim->erode_kh, dim->erode_kw);
     // Host frames: chunks of up to ~feed_chunk_bytes (and at most G frames) go through the pinned double buffer
     // (feed_* above), chunk k+1 uploading while chunk k is processed.  Device frames (LFDMI_FEED_MB=0, tiny batches):
     // chunks of G frames, used in place / staged by the runtime.
@@ -2139,9 +2197,19 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
         // (raw big-endian frames are a file's data unit, a read-only input: only the device copy is blotted -- no squares come
         // back, no mid-call synchronisation, no host threads)
         const bool host_blot = cat && loc == LFDMI_HOST && cat->loc == LFDMI_HOST && !be;
+        // The bit-plane sweep can mask remove_stars' squares as it loads the values (k_prep_hist<.., RS>), so nothing waits for the
+        // zero fill: a host frame's device copy is never filled at all (the caller's array is blotted by host threads, a big-endian
+        // frame is read-only), a device-resident frame -- which the caller does get back blotted -- is filled on a side stream
+        // beside the latency-bound stages of the bright pass (rs_fill_point).  Frames whose blotted copy travels back over PCIe
+        // (catalogue on the device, frames on the host) keep the fill in front.
+        const bool copy_back = cat && loc == LFDMI_HOST && !host_blot && !be;
+        ctx->rs_fold = cat && cat->max_obj > 0 && ctx->rs_fold_on && delta && w <= RS_MAXW && !copy_back;
+        ctx->rs_fill_frames = nullptr;
+        struct FoldState { lfdmi_ctx *c; ~FoldState() { c->rs_fold = false; c->rs_fill_frames = nullptr; } } fold_guard{ctx};
         if (cat) {
-            RET(run_removestars(ctx, (float *)d, c0, nc, h, w, cat, rs, host_blot ? &boxes : nullptr));
-            if (loc == LFDMI_HOST && !host_blot && !be) RET(out_copy(ctx, frames, (size_t)c0 * N * 4, d, (size_t)nc * N * 4, loc));
+            RET(run_removestars(ctx, (float *)d, cat_f0 + c0, nc, h, w, cat, rs, host_blot ? &boxes : nullptr, !ctx->rs_fold));
+            if (ctx->rs_fold && loc == LFDMI_DEVICE) { ctx->rs_fill_frames = (float *)d; ctx->rs_fill_nc = nc; ctx->rs_fill_h = h; ctx->rs_fill_w = w; }
+            if (copy_back) RET(out_copy(ctx, frames, (size_t)c0 * N * 4, d, (size_t)nc * N * 4, loc));
             if (host_blot) {
                 double t0_ = feed && getenv("LFDMI_FEED_TRACE") ? feed_now() : 0;
                 HIPCHK(hipStreamSynchronize(ctx->stream)); // the squares are on the host; the passes are enqueued next
@@ -2153,19 +2221,7 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
         for (;;) { // (again, with the general run kernels, if a frame turned out to need them)
         k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, ctx->pass_flags, nc);
         KCHK("k_init_results");
-        // both passes read the same float frames: one sweep feeds both where the dim pass's front end can be fused at all
-        const bool dual = ctx->fuse_dual && can_fuse_prep_erode(ctx, LFDMI_F32, w, dim->erodeKernel, dim->erode_kh, dim->erode_kw);
         struct DualState { lfdmi_ctx *c; ~DualState() { c->dual_state = 0; } } dual_guard{ctx};
-        // ... or, cheaper, the bright pass's sweep leaves one bit per pixel from which the dim pass rebuilds its 8-bit image
-        // (dim value = bright value + bit, for 0 <= addFlux <= 1 and minFlux <= 0.5) together with that image's histogram
-        // (small erosion kernels only: k_bits_erode fetches kh x kw values per surviving pixel, which is nothing on sky frames but
-        // would be slow on a dense image with a large kernel; those keep the band kernel)
-        // (addFlux must stay clear of 1: x = 0.5 gives bright rne(0.5) = 0 but dim rne(1.5) = 2, and an addFlux within half an ulp
-        // of 1 rounds x + addFlux up to the same tie; up to 0.999 the float sum of an even k + 0.5 < 256 stays below k + 1.5)
-        const bool delta = !dual && ctx->delta_dim && (w % 32) == 0 && (float)dim->addFlux >= 0.0f && (float)dim->addFlux <= 0.999f &&
-                           (float)dim->minFlux <= 0.5f &&
-                           dim->erode_kh * dim->erode_kw <= 25 &&
-                           can_fuse_prep_erode(ctx, LFDMI_F32, w, dim->erodeKernel, dim->erode_kh, dim->erode_kw);
         struct DeltaState { lfdmi_ctx *c; ~DeltaState() { c->delta_state = 0; } } delta_guard{ctx};
         ctx->cur_pass = 0;
         ctx->dual_state = 0;
@@ -2180,9 +2236,11 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
         ctx->delta_state = 0;
         if (host_blot && !blotted) { // host threads zero-fill the caller's frames in the background (joined below / at the end)
             if (blotter.joinable()) blotter.join();
-            blotter = std::thread([=, bx = boxes, cpus = ctx->feed_cpus] { blot_host_frames(frames + (size_t)c0 * N, nc, h, w, cat, c0, bx, cpus); });
+            blotter = std::thread([=, bx = boxes, cpus = ctx->feed_cpus] { blot_host_frames(frames + (size_t)c0 * N, nc, h, w, cat, cat_f0 + c0, bx, cpus); });
             blotted = true;
         }
+        RET(rs_fill_point(ctx, -1)); // (a fill no stage has started yet)
+        if (ctx->rs_fill_inflight) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_rsfill, 0)); ctx->rs_fill_inflight = false; }
         HIPCHK(hipMemcpyAsync(ctx->res_host, ctx->pass_flags, (size_t)ctx->G * sizeof(int) + (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
         { double t0_ = feed && getenv("LFDMI_FEED_TRACE") ? feed_now() : 0;
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2202,7 +2260,9 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
                 lfdmi_ctx *sp = get_spill(ctx);
                 if (sp) {
                     if (blotter.joinable()) blotter.join(); // (a host frame is read again below: its blotting must be complete)
-                    int rc = detect_impl(sp, frames + (size_t)(c0 + i) * N, dtype, 1, h, w, nullptr, nullptr, bright, dim, &results[c0 + i], loc);
+                    // (a big-endian frame is a read-only input: what the rerun uploads is not blotted, it needs the frame's catalogue entry)
+                    int rc = detect_impl(sp, frames + (size_t)(c0 + i) * N, dtype, 1, h, w, be ? cat : nullptr, be ? rs : nullptr, bright, dim,
+                                         &results[c0 + i], loc, cat_f0 + c0 + i);
                     if (rc) { ctx->err = sp->err; return rc; }
                     ctx->n_spilled++;
                     continue;

@@ -87,6 +87,30 @@ def test_tiny_capacities_spill_to_the_worst_case_workspace(oracle):
         assert res.tobytes() == ref[:2].tobytes() and ctx.spill_count() == 0
 
 
+def test_spilled_big_endian_frames_keep_their_catalogue_entry():
+    """A raw big-endian frame is a read-only input: what the worst-case rerun of a spilled frame uploads is not blotted, so
+    the rerun takes the frame's own catalogue entry (frames 1 .. 5 of a batch: the entry is not the first one); native host
+    frames, blotted by then, go without.  Records equal those of a context that never spills."""
+    from lfd_amd import _native, synth
+    pb, pd, prs = params()
+    rs_g = _native.make_rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
+    frames, cats = zip(*[synth.make_frame(k)[:2] for k in range(6)])
+    batch = np.stack(frames)
+    packed = synth.pack_catalogs(list(cats))
+    with _native.Context(0, 1489, 2048, 6) as ref_ctx:
+        ref = ref_ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g)
+        none = ref_ctx.detect_batch(batch.copy(), pb, pd)              # (the stars matter: without the catalogue records differ)
+        assert ref_ctx.spill_count() == 0 and none.tobytes() != ref.tobytes()
+    be = batch.astype(">f4")
+    with _native.Context(0, 1489, 2048, 6, caps={"key_cap": 64, "slot_cap": 2000}) as ctx:
+        got = ctx.detect_batch(be, pb, pd, packed, rs_g)
+        assert ctx.spill_count() > 0
+        assert got.tobytes() == ref.tobytes()
+        assert np.array_equal(be.astype(np.float32), batch)
+        n0 = ctx.spill_count()
+        assert ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g).tobytes() == ref.tobytes() and ctx.spill_count() > n0
+
+
 def test_operator_entry_points_spill_too(oracle):
     """Canny / fit_minAreaRect / HoughLines on a dense random image through a workspace with tiny tables."""
     from lfd_amd import _native

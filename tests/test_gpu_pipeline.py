@@ -311,18 +311,20 @@ def test_cell_bitmap_and_general_run_kernels_do_not_change_results(monkeypatch):
     bright image and one bit per pixel); round 3: LFDMI_PERM=0 / LFDMI_TILE_PERM=0 (frame slot == workgroup index: no XCD
     balancing of a pass's active frames / no sorting by tiles), LFDMI_VOTE_BALANCE=0 and LFDMI_VOTE_CLASSES=0 (fixed pieces per
     image, one chunk list per image in the Hough vote), LFDMI_SKY_FAST=0 (the bright sweep without its all-sky shortcut),
-    LFDMI_FRAME_LDS=16384 (smaller label tables: busy frames take the general kernels) -- against the default fast paths:
+    LFDMI_FRAME_LDS=16384 (smaller label tables: busy frames take the general kernels), LFDMI_RECTS_PREP=0 (the wave-per-key
+    rectangle kernels scan their hulls sequentially) -- against the default fast paths:
     identical records and edge images."""
     from lfd_amd import _native, synth
     pb, pd, prs = params()
     frames = np.stack([synth.make_frame(k, with_catalog=False)[0] for k in range(6)])
     outs = []
     switches = ("LFDMI_CELLBM", "LFDMI_FRAME_CCL", "LFDMI_DC_TILELIST", "LFDMI_DC_PARTS", "LFDMI_DC_SPECIALIZE", "LFDMI_FUSE_DUAL", "LFDMI_DELTA_DIM",
-                "LFDMI_PERM", "LFDMI_TILE_PERM", "LFDMI_VOTE_BALANCE", "LFDMI_VOTE_CLASSES", "LFDMI_SKY_FAST", "LFDMI_FRAME_LDS")
+                "LFDMI_PERM", "LFDMI_TILE_PERM", "LFDMI_VOTE_BALANCE", "LFDMI_VOTE_CLASSES", "LFDMI_SKY_FAST", "LFDMI_FRAME_LDS", "LFDMI_RECTS_PREP")
     for env in ({}, {"LFDMI_CELLBM": "0"}, {"LFDMI_FRAME_CCL": "0"}, {"LFDMI_DC_TILELIST": "0"}, {"LFDMI_DC_TILELIST": "0", "LFDMI_CELLBM": "0"},
                 {"LFDMI_DC_PARTS": "7"}, {"LFDMI_DC_SPECIALIZE": "0"}, {"LFDMI_FUSE_DUAL": "1"}, {"LFDMI_DELTA_DIM": "0"},
                 {"LFDMI_PERM": "0"}, {"LFDMI_TILE_PERM": "0"}, {"LFDMI_VOTE_BALANCE": "0"}, {"LFDMI_VOTE_CLASSES": "0"}, {"LFDMI_SKY_FAST": "0"},
-                {"LFDMI_FRAME_LDS": "16384"}, {"LFDMI_VOTE_BALANCE": "0", "LFDMI_VOTE_CLASSES": "0", "LFDMI_PERM": "0", "LFDMI_SKY_FAST": "0"}):
+                {"LFDMI_FRAME_LDS": "16384"}, {"LFDMI_RECTS_PREP": "0"},
+                {"LFDMI_VOTE_BALANCE": "0", "LFDMI_VOTE_CLASSES": "0", "LFDMI_PERM": "0", "LFDMI_SKY_FAST": "0"}):
         for k in switches:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -335,6 +337,52 @@ def test_cell_bitmap_and_general_run_kernels_do_not_change_results(monkeypatch):
         assert o[0] == outs[0][0]
         for a, b in zip(o[1], outs[0][1]):
             assert np.array_equal(a, b)
+
+
+def test_remove_stars_masked_in_the_sweep_or_filled_before_it(oracle, monkeypatch):
+    """lfdmi_detect_batch with a catalogue: by default the bright sweep masks remove_stars' squares as it loads the values and
+    the zero fill of a device-resident frame runs later, on a side stream (LFDMI_RS_FILL_AT picks the stage); LFDMI_RS_FOLD=0
+    fills before the sweep.  Records, the frames the caller gets back (device-resident and host frames are blotted in place,
+    big-endian ones are not touched) and the oracle agree in every mode; a flipped catalogue row (objects near the frame's
+    edges, squares clipped like Python slices) is part of the batch."""
+    import torch
+    from lfd_amd import _native, synth
+    pb, pd, prs = params()
+    rs_g, rs_o = rs_pair(oracle, prs)
+    frames, cats = zip(*[synth.make_frame(k)[:2] for k in range(5)])
+    cats = [dict(c) for c in cats]
+    for key in ("ROWC", "COLC"):                                       # frame 4: objects pushed to the edges and beyond
+        cats[4][key] = np.array(cats[4][key], copy=True)
+    half = len(cats[4]["ROWC"]) // 2
+    cats[4]["ROWC"][:half] *= 0.02
+    cats[4]["COLC"][half:] = 2040.0 + 0.05 * cats[4]["COLC"][half:]
+    batch = np.stack(frames)
+    packed = synth.pack_catalogs(cats)
+    outs = []
+    for env in ({}, {"LFDMI_RS_FOLD": "0"}, {"LFDMI_RS_FILL_AT": "1"}, {"LFDMI_RS_FILL_AT": "3"}, {"LFDMI_RS_FILL_AT": "5"}, {"LFDMI_RS_FILL_AT": "9"}):
+        for k in ("LFDMI_RS_FOLD", "LFDMI_RS_FILL_AT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with _native.Context(0, 1489, 2048, 5) as ctx:
+            dev = torch.from_numpy(batch.copy()).cuda()
+            r_dev = ctx.detect_batch(dev, pb, pd, packed, rs_g)
+            torch.cuda.synchronize()
+            host = batch.copy()
+            r_host = ctx.detect_batch(host, pb, pd, packed, rs_g)
+            be = batch.astype(">f4")
+            r_be = ctx.detect_batch(be, pb, pd, packed, rs_g)
+            assert np.array_equal(be.astype(np.float32), batch)
+            outs.append((r_dev.tobytes(), r_host.tobytes(), r_be.tobytes(), dev.cpu().numpy(), host))
+    for o in outs:
+        assert o[0] == outs[0][0] == o[1] == o[2]
+        assert np.array_equal(o[3], outs[1][3]) and np.array_equal(o[4], outs[1][3])
+    res = np.frombuffer(outs[0][0], _native.RESULT_DTYPE)
+    for i in (0, 1, 4):
+        assert same(res[i], oracle.detect_frame(frames[i].copy(), pb, pd, cats[i], rs_o))
+        f = frames[i].copy()
+        oracle.remove_stars(f, cats[i], rs_o)
+        assert np.array_equal(f, outs[0][3][i])                         # the oracle blots its frame the same way
 
 
 @pytest.mark.parametrize("caps", ["worst", None])
