@@ -363,6 +363,10 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
                              "frac_of_peak": round(min(frac, 1.0), 4)}
             if frac > 1.0:  # the stage's kernels skip empty tiles / bands: the algorithmic bytes were never moved, so this is no bandwidth figure
                 stages[sname]["sparse"] = "algorithmic bytes not moved (activity-driven kernels skip empty regions): uncapped %.2f" % frac
+            if sname == "prep" and "k_removestars" in table and table["k_removestars"][1] >= 2:
+                # (two timed spans per step: k_rs_boxes in front of the sweep, the zero fill on a side stream beside k_frame_bg)
+                stages[sname]["overlapped"] = ("k_removestars' zero fill runs on a side stream beside k_frame_bg (the sweep masks the squares on load); "
+                                               "its time is still charged to this stage, and stretches k_frame_bg's")
         ch = None
         if "canny" in stages and "hough" in stages:  # what north_star asks for: Canny (2N) + Hough (1N per image) over their kernels
             gb = stages["canny"]["algorithmic_GB"] + stages["hough"]["algorithmic_GB"]

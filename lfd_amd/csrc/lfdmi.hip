@@ -783,7 +783,7 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
     { Span sp(ctx, KID_RUNS_INIT_FG);
       RET(run_scan(ctx, ctx->candb, 1, ctx->scanf_, C_NRUNF, nc, h, w, ctx->wl_fg, ctx->wl_bg, ctx->edgeb, active));
     }
-    RET(rs_fill_point(ctx, 3));
+    RET(rs_fill_point(ctx, 3 + 10 * ctx->cur_pass));
     if (ctx->frame_ccl) { // frames that fit the LDS tables; the rest (fallback flag) take the kernels below
         Span sp(ctx, KID_FRAME_FG);
         size_t lds = (size_t)(ctx->frame_lds + 2 * (ctx->frame_lds / 32)) * sizeof(int);
@@ -945,7 +945,7 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     rt.Lb = ctx->Lb; rt.YMb = ctx->YMb; rt.FLb = ctx->FLb; rt.SBb = ctx->SBb; rt.PAb = ctx->PAb; rt.ROWb = ctx->ROWb;
     rt.run_cap = rc;
     const int *gen = active; // frames for the general run kernels
-    RET(rs_fill_point(ctx, 4));
+    RET(rs_fill_point(ctx, 4 + 10 * ctx->cur_pass));
     if (ctx->frame_ccl) {
         Span sp(ctx, KID_FRAME_BG);
         size_t lds = (size_t)(ctx->frame_lds + 4 * (ctx->frame_lds / 32)) * sizeof(int);
@@ -1025,7 +1025,7 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     KCHK("k_rects");
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[1], 0));
-    RET(rs_fill_point(ctx, 5));
+    RET(rs_fill_point(ctx, 5 + 10 * ctx->cur_pass));
     }
     }
     Span sp(ctx, KID_FILL);
@@ -1341,7 +1341,7 @@ static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, 
     } else if (can_fuse_dilate_canny(p->dilateKernel, p->dilate_kh, p->dilate_kw, w)) {
         // the prep kernel of this pass left the cell occupancy of its output (a superset of the eroded image's)
         RET(run_dilate_canny(ctx, dil_src, nc, h, w, ctx->lut, p->dilate_kh, p->dilate_kw, active, ctx->use_cellbm ? bm : nullptr));
-        RET(rs_fill_point(ctx, 2));
+        RET(rs_fill_point(ctx, 2 + 10 * ctx->cur_pass));
         RET(run_canny(ctx, ctx->equ, nc, h, w, 0, 255, active, true));
     } else {
         RET(run_morph(ctx, dil_src, ctx->equ, ctx->equb, ctx->lut, p->dilateKernel, p->dilate_kh, p->dilate_kw, 0, nc, h, w, active));
