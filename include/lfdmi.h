@@ -226,8 +226,10 @@ int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w,
 /* lfdmi_detect_batch with the frames' element type given: LFDMI_F32, or LFDMI_F32_BE for HOST / HOST_PINNED frames holding the
  * big-endian data unit of a FITS image as read from the file (DetectTrails.process reads frame files straight into pinned
  * memory and leaves the byte swap to the device: detecttrails.py:73-117 is a read + swap + copy per frame in the reference).
- * Big-endian frames are treated as a read-only input: remove_stars blots the library's device copy only (the caller's
- * bytes are a file's data unit; LFDMI_F32 frames are blotted in place as in lfdmi_detect_batch). */
+ * Big-endian frames are treated as a read-only input: remove_stars' squares are applied inside the library (masked as
+ * the bright sweep loads the values; a frame that has to be run again alone takes its own catalogue entry) and the caller's
+ * bytes -- a file's data unit -- stay as they are; LFDMI_F32 frames are blotted in place as in lfdmi_detect_batch (complete
+ * when the call returns: for device-resident frames the zero fill runs on a side stream during the call). */
 int lfdmi_detect_batch_raw(lfdmi_ctx *ctx, void *frames, int dtype, int n, int h, int w,
                            const lfdmi_catalog *cat, const lfdmi_rs_params *rs,
                            const lfdmi_params *bright, const lfdmi_params *dim, lfdmi_result *results,

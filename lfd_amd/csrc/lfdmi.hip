@@ -2205,7 +2205,13 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
         const bool copy_back = cat && loc == LFDMI_HOST && !host_blot && !be;
         ctx->rs_fold = cat && cat->max_obj > 0 && ctx->rs_fold_on && delta && w <= RS_MAXW && !copy_back;
         ctx->rs_fill_frames = nullptr;
-        struct FoldState { lfdmi_ctx *c; ~FoldState() { c->rs_fold = false; c->rs_fill_frames = nullptr; } } fold_guard{ctx};
+        struct FoldState { // (an error return in the middle of a chunk must not leave the fill running on the caller's frames)
+            lfdmi_ctx *c;
+            ~FoldState() {
+                if (c->rs_fill_inflight) { (void)hipStreamSynchronize(c->side[0]); (void)hipStreamSynchronize(c->side[1]); c->rs_fill_inflight = false; }
+                c->rs_fold = false; c->rs_fill_frames = nullptr;
+            }
+        } fold_guard{ctx};
         if (cat) {
             RET(run_removestars(ctx, (float *)d, cat_f0 + c0, nc, h, w, cat, rs, host_blot ? &boxes : nullptr, !ctx->rs_fold));
             if (ctx->rs_fold && loc == LFDMI_DEVICE) { ctx->rs_fill_frames = (float *)d; ctx->rs_fill_nc = nc; ctx->rs_fill_h = h; ctx->rs_fill_w = w; }
