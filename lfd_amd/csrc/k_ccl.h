@@ -210,6 +210,105 @@ k_scan_write(const u64 *bits, int val, const int4 *segcnt, int *scan, int h, int
     }
 }
 
+// The three scan kernels in one launch (round 3): a workgroup counts its 32 segments, publishes its totals, adds up the
+// totals of the frame's workgroups before it (a decoupled look-back: it waits for their COUNTS only, which they publish
+// without waiting for anybody, so a workgroup is held up by at most the count phase of a neighbour that started late), and
+// writes the per-word scan values and the work lists from the words it still holds -- the bit plane is read once instead of
+// twice and two launches (~8 us of drain each) go.  `partial` holds one word per (frame slot, workgroup): totals + the
+// launch's epoch as the "published" mark (every launch of a context has its own epoch; the host clears the words when the epoch wraps).  The wait is
+// bounded: a workgroup that gives up flags the frame as overflowed (it is then run again in the worst-case workspace)
+// instead of hanging -- which needs a predecessor that never starts, i.e. a dispatcher that does not hand out
+// workgroups in index order.
+#define SCAN_MAX_BLK (SCAN_MAX_SEG / (SCANW_WAVES * SCAN_SEGS))
+__global__ void __launch_bounds__(64 * SCANW_WAVES)
+k_scan_fused(const u64 *bits, int val, u64 *partial, int epoch /* 1 .. 2^22 - 1 */, int *scan, int h, int w, int *wl_fg, int *wl_bg, u64 *clear,
+             int *counters, int cidx, int run_cap, const int *active) {
+    const int g = blockIdx.y, bx = blockIdx.x;
+    if (active && !active[g]) return;
+    const int wq = LFD_WQ(w), nw = h * wq, nseg = (nw + 63) >> 6;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int seg0 = (bx * SCANW_WAVES + wv) * SCAN_SEGS;
+    const bool lists = wl_fg != nullptr;
+    int c[SCAN_SEGS]; bool tf[SCAN_SEGS], tb[SCAN_SEGS];
+    scan_words(bits + (size_t)g * nw, seg0, nseg, nw, wq, val, w, lists, lane, c, tf, tb);
+    int cs[SCAN_SEGS], nf[SCAN_SEGS], nb[SCAN_SEGS], incl[SCAN_SEGS];
+    int wc = 0, wf = 0, wb = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_SEGS; k++) {
+        int v = c[k];
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(v, off);
+            if (lane >= off) v += t;
+        }
+        incl[k] = v;
+        cs[k] = __builtin_amdgcn_readlane(v, 63);
+        nf[k] = __popcll(__ballot(tf[k]));
+        nb[k] = __popcll(__ballot(tb[k]));
+        wc += cs[k]; wf += nf[k]; wb += nb[k];
+    }
+    __shared__ int wt[SCANW_WAVES][3];
+    __shared__ int base_s[4]; // frame-wide totals before this workgroup: runs, fg words, bg words; [3]: look-back gave up
+    if (lane == 0) { wt[wv][0] = wc; wt[wv][1] = wf; wt[wv][2] = wb; }
+    __syncthreads();
+    // one 64-bit word per workgroup carries totals and mark together -- [epoch:22][bg words:12][fg words:12][runs:18] -- so a
+    // relaxed device-scope store / load pair is all the protocol needs (a release / acquire pair costs an L2 write-back per
+    // workgroup and an invalidate per poll on this part: measured 3x the three-kernel scan)
+    u64 *pg = partial + (size_t)g * SCAN_MAX_BLK;
+    int tc = 0, tfw = 0, tbw = 0;
+    for (int k = 0; k < SCANW_WAVES; k++) { tc += wt[k][0]; tfw += wt[k][1]; tbw += wt[k][2]; }
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&pg[bx], ((u64)(unsigned)epoch << 42) | ((u64)tbw << 30) | ((u64)tfw << 18) | (u64)tc, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (wv == 0) {
+        int bc = 0, bf = 0, bb = 0, bad = 0;
+        for (int p0 = 0; p0 < bx; p0 += 64) {
+            const int p = p0 + lane;
+            if (p < bx) {
+                bool ok = false;
+                u64 v = 0;
+                for (int spin = 0; spin < (1 << 20); spin++) {
+                    v = __hip_atomic_load(&pg[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((int)(v >> 42) == epoch) { ok = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (ok) { bc += (int)(v & 0x3FFFFu); bf += (int)((v >> 18) & 0xFFFu); bb += (int)((v >> 30) & 0xFFFu); }
+                else bad = 1;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            bc += __shfl_xor(bc, off); bf += __shfl_xor(bf, off); bb += __shfl_xor(bb, off); bad |= __shfl_xor(bad, off);
+        }
+        if (lane == 0) { base_s[0] = bc; base_s[1] = bf; base_s[2] = bb; base_s[3] = bad; }
+    }
+    __syncthreads();
+    int rc = base_s[0], rf = base_s[1], rb = base_s[2];
+    for (int k = 0; k < wv; k++) { rc += wt[k][0]; rf += wt[k][1]; rb += wt[k][2]; }
+    if (bx == (int)gridDim.x - 1 && threadIdx.x == 0) { // the frame's totals (the last workgroup: everything before it + its own)
+        int *cnt = counters + (size_t)g * C_COUNT;
+        const int total = base_s[0] + tc;
+        cnt[cidx] = total;
+        if (total > run_cap) cnt[C_OVERFLOW] = 1;
+        if (lists) { cnt[C_NFGW] = base_s[1] + tfw; cnt[C_NBGW] = base_s[2] + tbw; }
+    }
+    if (base_s[3] && threadIdx.x == 0) counters[(size_t)g * C_COUNT + C_OVERFLOW] = 1;
+    if (seg0 >= nseg) return;
+#pragma unroll
+    for (int k = 0; k < SCAN_SEGS; k++) {
+        if (seg0 + k >= nseg) break;
+        const int i = ((seg0 + k) << 6) + lane;
+        if (lists) {
+            u64 bfm = __ballot(tf[k]), bbm = __ballot(tb[k]), lt = (1ull << lane) - 1ull;
+            if (tf[k]) wl_fg[(size_t)g * nw + rf + __popcll(bfm & lt)] = i;
+            if (tb[k]) wl_bg[(size_t)g * nw + rb + __popcll(bbm & lt)] = i;
+        }
+        if (i < nw) {
+            scan[(size_t)g * nw + i] = rc + incl[k] - c[k];
+            if (clear) clear[(size_t)g * nw + i] = 0ull;
+        }
+        rc += cs[k]; rf += nf[k]; rb += nb[k];
+    }
+}
+
 // id of the `val`-run holding pixel (y, x) (the pixel must have that value)
 __device__ __forceinline__ int run_id(const int *scan_frame, const u64 *frame_bits, int y, int x, int val, int wq, int W) {
     int q = x >> 6, b = x & 63;

@@ -116,6 +116,9 @@ struct lfdmi_ctx {
     int rs_fill_nc = 0, rs_fill_h = 0, rs_fill_w = 0;
     hipEvent_t ev_rsfill = nullptr;
     bool rs_fill_inflight = false;
+    bool scan_fused = true;            // LFDMI_SCAN_FUSED=0: the run scans as three launches (count, bases, write)
+    u64 *scan_partial = nullptr;       // G x SCAN_MAX_BLK: k_scan_fused's per-workgroup totals + epoch marks
+    int scan_epoch = 0;
     bool rects_prep = true;            // LFDMI_RECTS_PREP=0: the wave-per-key rectangle kernels scan their hulls sequentially
     bool vote_balance = true;          // LFDMI_VOTE_BALANCE=0: a fixed number of list pieces per image in the vote kernel
     lfdmi_result *res_dev = nullptr;   // G x LFDMI_MAX_SCALES records (one block of G per Hough scale)
@@ -394,6 +397,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_VOTE_BALANCE")) ctx->vote_balance = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_RECTS_PREP")) ctx->rects_prep = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_RS_FOLD")) ctx->rs_fold_on = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_SCAN_FUSED")) ctx->scan_fused = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_RS_FILL_AT")) ctx->rs_fill_at = atoi(e);
     if (const char *e = getenv("LFDMI_PERM")) ctx->use_perm = atoi(e) != 0;
     RET(dmalloc(ctx, &ctx->fb_fg, G));
@@ -433,6 +437,8 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
         RET(dmalloc(ctx, &ctx->candmask, G * (size_t)((max_h + MORPH_TH - 1) / MORPH_TH) * 2));
     }
     RET(dmalloc(ctx, &ctx->need_dim, G));
+    RET(dmalloc(ctx, &ctx->scan_partial, G * SCAN_MAX_BLK));
+    HIPCHK(hipMemsetAsync(ctx->scan_partial, 0, G * SCAN_MAX_BLK * sizeof(u64), ctx->stream));
     { // flags and records side by side: lfdmi_detect_batch fetches both with one copy into page-locked memory (res_host)
         char *blk = nullptr;
         RET(dmalloc(ctx, &blk, G * sizeof(int) + G * LFDMI_MAX_SCALES * sizeof(lfdmi_result)));
@@ -757,6 +763,16 @@ static int run_scan(lfdmi_ctx *ctx, const u64 *bits, int val, int *scan, int cid
                     u64 *clear, const int *active) {
     int nseg = (h * LFD_WQ(w) + 63) / 64;
     dim3 grid((nseg + SCANW_WAVES * SCAN_SEGS - 1) / (SCANW_WAVES * SCAN_SEGS), nc);
+    if (ctx->scan_fused && (int)grid.x <= SCAN_MAX_BLK) { // count + bases + write in one launch (k_scan_fused)
+        if (++ctx->scan_epoch >= (1 << 22)) { // (the mark is 22 bits wide: start over on clean words)
+            HIPCHK(hipMemsetAsync(ctx->scan_partial, 0, (size_t)ctx->G * SCAN_MAX_BLK * sizeof(u64), ctx->stream));
+            ctx->scan_epoch = 1;
+        }
+        k_scan_fused<<<grid, 64 * SCANW_WAVES, 0, ctx->stream>>>(bits, val, ctx->scan_partial, ctx->scan_epoch, scan, h, w, wl_fg, wl_bg, clear,
+                                                                  ctx->counters, cidx, ctx->run_cap, active);
+        KCHK("k_scan_fused");
+        return 0;
+    }
     k_scan_count<<<grid, 64 * SCANW_WAVES, 0, ctx->stream>>>(bits, val, ctx->segcnt, h, w, wl_fg != nullptr, active);
     KCHK("k_scan_count");
     k_scan_bases<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->segcnt, ctx->counters, cidx, h, w, ctx->run_cap, wl_fg != nullptr, active);

@@ -312,18 +312,18 @@ def test_cell_bitmap_and_general_run_kernels_do_not_change_results(monkeypatch):
     balancing of a pass's active frames / no sorting by tiles), LFDMI_VOTE_BALANCE=0 and LFDMI_VOTE_CLASSES=0 (fixed pieces per
     image, one chunk list per image in the Hough vote), LFDMI_SKY_FAST=0 (the bright sweep without its all-sky shortcut),
     LFDMI_FRAME_LDS=16384 (smaller label tables: busy frames take the general kernels), LFDMI_RECTS_PREP=0 (the wave-per-key
-    rectangle kernels scan their hulls sequentially) -- against the default fast paths:
+    rectangle kernels scan their hulls sequentially), LFDMI_SCAN_FUSED=0 (run scans as three launches instead of one with a look-back) -- against the default fast paths:
     identical records and edge images."""
     from lfd_amd import _native, synth
     pb, pd, prs = params()
     frames = np.stack([synth.make_frame(k, with_catalog=False)[0] for k in range(6)])
     outs = []
     switches = ("LFDMI_CELLBM", "LFDMI_FRAME_CCL", "LFDMI_DC_TILELIST", "LFDMI_DC_PARTS", "LFDMI_DC_SPECIALIZE", "LFDMI_FUSE_DUAL", "LFDMI_DELTA_DIM",
-                "LFDMI_PERM", "LFDMI_TILE_PERM", "LFDMI_VOTE_BALANCE", "LFDMI_VOTE_CLASSES", "LFDMI_SKY_FAST", "LFDMI_FRAME_LDS", "LFDMI_RECTS_PREP")
+                "LFDMI_PERM", "LFDMI_TILE_PERM", "LFDMI_VOTE_BALANCE", "LFDMI_VOTE_CLASSES", "LFDMI_SKY_FAST", "LFDMI_FRAME_LDS", "LFDMI_RECTS_PREP", "LFDMI_SCAN_FUSED")
     for env in ({}, {"LFDMI_CELLBM": "0"}, {"LFDMI_FRAME_CCL": "0"}, {"LFDMI_DC_TILELIST": "0"}, {"LFDMI_DC_TILELIST": "0", "LFDMI_CELLBM": "0"},
                 {"LFDMI_DC_PARTS": "7"}, {"LFDMI_DC_SPECIALIZE": "0"}, {"LFDMI_FUSE_DUAL": "1"}, {"LFDMI_DELTA_DIM": "0"},
                 {"LFDMI_PERM": "0"}, {"LFDMI_TILE_PERM": "0"}, {"LFDMI_VOTE_BALANCE": "0"}, {"LFDMI_VOTE_CLASSES": "0"}, {"LFDMI_SKY_FAST": "0"},
-                {"LFDMI_FRAME_LDS": "16384"}, {"LFDMI_RECTS_PREP": "0"},
+                {"LFDMI_FRAME_LDS": "16384"}, {"LFDMI_RECTS_PREP": "0"}, {"LFDMI_SCAN_FUSED": "0"},
                 {"LFDMI_VOTE_BALANCE": "0", "LFDMI_VOTE_CLASSES": "0", "LFDMI_PERM": "0", "LFDMI_SKY_FAST": "0"}):
         for k in switches:
             monkeypatch.delenv(k, raising=False)
