@@ -398,6 +398,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_RECTS_PREP")) ctx->rects_prep = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_RS_FOLD")) ctx->rs_fold_on = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_SCAN_FUSED")) ctx->scan_fused = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_SCAN_EPOCH0")) ctx->scan_epoch = atoi(e) & ((1 << 22) - 1); // (tests: start next to the 22-bit wrap)
     if (const char *e = getenv("LFDMI_RS_FILL_AT")) ctx->rs_fill_at = atoi(e);
     if (const char *e = getenv("LFDMI_PERM")) ctx->use_perm = atoi(e) != 0;
     RET(dmalloc(ctx, &ctx->fb_fg, G));

@@ -385,6 +385,22 @@ def test_remove_stars_masked_in_the_sweep_or_filled_before_it(oracle, monkeypatc
         assert np.array_equal(f, outs[0][3][i])                         # the oracle blots its frame the same way
 
 
+def test_fused_run_scan_survives_the_wrap_of_its_epoch(monkeypatch):
+    """k_scan_fused marks a workgroup's published totals with the launch's 22-bit epoch; when the epoch wraps the host clears
+    the words and starts over.  A context started three launches before the wrap (LFDMI_SCAN_EPOCH0) gives the records of an
+    ordinary one over several calls (four scans per call)."""
+    from lfd_amd import _native, synth
+    pb, pd, _ = params()
+    frames = np.stack([synth.make_frame(k, with_catalog=False)[0] for k in range(4)])
+    with _native.Context(0, 1489, 2048, 4) as ctx:
+        want = ctx.detect_batch(frames.copy(), pb, pd)
+    monkeypatch.setenv("LFDMI_SCAN_EPOCH0", str((1 << 22) - 3))
+    with _native.Context(0, 1489, 2048, 4) as ctx:
+        for _ in range(3):
+            assert ctx.detect_batch(frames.copy(), pb, pd).tobytes() == want.tobytes()
+        assert ctx.spill_count() == 0
+
+
 @pytest.mark.parametrize("caps", ["worst", None])
 def test_dense_noise_frames_take_the_general_kernels_and_match_the_oracle(oracle, caps):
     """Frames the per-frame LDS kernels cannot hold (noise everywhere: far more than 32 768 runs) are
