@@ -216,12 +216,16 @@ k_scan_write(const u64 *bits, int val, const int4 *segcnt, int *scan, int h, int
 // writes the per-word scan values and the work lists from the words it still holds -- the bit plane is read once instead of
 // twice and two launches (~8 us of drain each) go.  `partial` holds one word per (frame slot, workgroup): totals + the
 // launch's epoch as the "published" mark (every launch of a context has its own epoch; the host clears the words when the epoch wraps).  The wait is
-// bounded: a workgroup that gives up flags the frame as overflowed (it is then run again in the worst-case workspace)
-// instead of hanging -- which needs a predecessor that never starts, i.e. a dispatcher that does not hand out
-// workgroups in index order.
+// bounded (~0.5 ms; a neighbour's count phase is ~20 us): a workgroup that gives up flags the frame as overflowed (it is
+// then run again in the worst-case workspace) and raises PASS_FLAG_SCAN_GAVEUP, on which the host goes back to the three
+// launches for the rest of the context's life.  That happens when several PROCESSES share the GPU: the waiting workgroups
+// of one hold the CU slots the other's not yet dispatched workgroups need, and the other way round (measured: four ranks on
+// one device, every look-back ran into a -- then 150 ms -- bound); with one process per GPU the predecessors of a waiting
+// workgroup are resident or done, because every XCD hands its workgroups out in index order and publishing waits for nobody.
 #define SCAN_MAX_BLK (SCAN_MAX_SEG / (SCANW_WAVES * SCAN_SEGS))
+#define PASS_FLAG_SCAN_GAVEUP 512 // pass_flags bit (beside k_frame.h's PASS_FLAG_GENERAL): the look-back gave up on this frame
 __global__ void __launch_bounds__(64 * SCANW_WAVES)
-k_scan_fused(const u64 *bits, int val, u64 *partial, int epoch /* 1 .. 2^22 - 1 */, int *scan, int h, int w, int *wl_fg, int *wl_bg, u64 *clear,
+k_scan_fused(const u64 *bits, int val, u64 *partial, int epoch /* 1 .. 2^22 - 1 */, int max_spin, int *pass_flags, int *scan, int h, int w, int *wl_fg, int *wl_bg, u64 *clear,
              int *counters, int cidx, int run_cap, const int *active) {
     const int g = blockIdx.y, bx = blockIdx.x;
     if (active && !active[g]) return;
@@ -266,7 +270,7 @@ k_scan_fused(const u64 *bits, int val, u64 *partial, int epoch /* 1 .. 2^22 - 1 
             if (p < bx) {
                 bool ok = false;
                 u64 v = 0;
-                for (int spin = 0; spin < (1 << 20); spin++) {
+                for (int spin = 0; spin < max_spin; spin++) {
                     v = __hip_atomic_load(&pg[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((int)(v >> 42) == epoch) { ok = true; break; }
                     __builtin_amdgcn_s_sleep(2);
@@ -290,7 +294,10 @@ k_scan_fused(const u64 *bits, int val, u64 *partial, int epoch /* 1 .. 2^22 - 1 
         if (total > run_cap) cnt[C_OVERFLOW] = 1;
         if (lists) { cnt[C_NFGW] = base_s[1] + tfw; cnt[C_NBGW] = base_s[2] + tbw; }
     }
-    if (base_s[3] && threadIdx.x == 0) counters[(size_t)g * C_COUNT + C_OVERFLOW] = 1;
+    if (base_s[3] && threadIdx.x == 0) {
+        counters[(size_t)g * C_COUNT + C_OVERFLOW] = 1;
+        atomicOr(&pass_flags[g], PASS_FLAG_SCAN_GAVEUP);
+    }
     if (seg0 >= nseg) return;
 #pragma unroll
     for (int k = 0; k < SCAN_SEGS; k++) {

@@ -119,6 +119,7 @@ struct lfdmi_ctx {
     bool scan_fused = true;            // LFDMI_SCAN_FUSED=0: the run scans as three launches (count, bases, write)
     u64 *scan_partial = nullptr;       // G x SCAN_MAX_BLK: k_scan_fused's per-workgroup totals + epoch marks
     int scan_epoch = 0;
+    int scan_spin = 4096;              // polls a workgroup of k_scan_fused waits for a predecessor's totals (~0.5 ms; LFDMI_SCAN_SPIN, tests: 0)
     bool rects_prep = true;            // LFDMI_RECTS_PREP=0: the wave-per-key rectangle kernels scan their hulls sequentially
     bool vote_balance = true;          // LFDMI_VOTE_BALANCE=0: a fixed number of list pieces per image in the vote kernel
     lfdmi_result *res_dev = nullptr;   // G x LFDMI_MAX_SCALES records (one block of G per Hough scale)
@@ -398,6 +399,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_RECTS_PREP")) ctx->rects_prep = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_RS_FOLD")) ctx->rs_fold_on = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_SCAN_FUSED")) ctx->scan_fused = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_SCAN_SPIN")) ctx->scan_spin = std::max(0, atoi(e));
     if (const char *e = getenv("LFDMI_SCAN_EPOCH0")) ctx->scan_epoch = atoi(e) & ((1 << 22) - 1); // (tests: start next to the 22-bit wrap)
     if (const char *e = getenv("LFDMI_RS_FILL_AT")) ctx->rs_fill_at = atoi(e);
     if (const char *e = getenv("LFDMI_PERM")) ctx->use_perm = atoi(e) != 0;
@@ -492,6 +494,7 @@ static lfdmi_ctx *get_spill(lfdmi_ctx *ctx) {
             return nullptr;
         }
         sp->timing = false;
+        sp->scan_fused = false; // (one frame at a time, rarely: nothing to gain from the look-back scan)
         ctx->spill = sp;
     }
     return ctx->spill;
@@ -769,7 +772,7 @@ static int run_scan(lfdmi_ctx *ctx, const u64 *bits, int val, int *scan, int cid
             HIPCHK(hipMemsetAsync(ctx->scan_partial, 0, (size_t)ctx->G * SCAN_MAX_BLK * sizeof(u64), ctx->stream));
             ctx->scan_epoch = 1;
         }
-        k_scan_fused<<<grid, 64 * SCANW_WAVES, 0, ctx->stream>>>(bits, val, ctx->scan_partial, ctx->scan_epoch, scan, h, w, wl_fg, wl_bg, clear,
+        k_scan_fused<<<grid, 64 * SCANW_WAVES, 0, ctx->stream>>>(bits, val, ctx->scan_partial, ctx->scan_epoch, ctx->scan_spin, ctx->pass_flags, scan, h, w, wl_fg, wl_bg, clear,
                                                                   ctx->counters, cidx, ctx->run_cap, active);
         KCHK("k_scan_fused");
         return 0;
@@ -1818,6 +1821,11 @@ static int pass_api(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, in
             HIPCHK(hipMemcpyAsync(hl.data(), ctx->lines, (size_t)nc * 2 * K * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipMemcpyAsync(flags.data(), ctx->pass_flags, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
+            {
+                bool gave = false;
+                for (int i = 0; i < nc; i++) gave = gave || (flags[i] & PASS_FLAG_SCAN_GAVEUP);
+                if (gave && ctx->scan_fused) { ctx->scan_fused = false; continue; } // (see lfdmi_detect_batch)
+            }
             if (!gg.again(flags.data(), nc)) break;
         }
         {
@@ -2268,6 +2276,12 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
         { double t0_ = feed && getenv("LFDMI_FEED_TRACE") ? feed_now() : 0;
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (t0_ > 0) fprintf(stderr, "[feed] chunk %d (%d frames): passes synced after %.2f ms (t=%.2f)\n", kc, nc, feed_now() - t0_, feed_now()); }
+        { // the look-back scan gave up on a frame (the GPU is shared with another process: see k_scan_fused): three launches from
+          // now on, and this chunk once more (cheaper than the worst-case rerun of every frame that was flagged)
+            bool gave = false;
+            for (int i = 0; i < nc; i++) gave = gave || (flags[i] & PASS_FLAG_SCAN_GAVEUP);
+            if (gave && ctx->scan_fused) { ctx->scan_fused = false; continue; }
+        }
         if (!gg.again(flags, nc)) break;
         }
         {

@@ -385,6 +385,31 @@ def test_remove_stars_masked_in_the_sweep_or_filled_before_it(oracle, monkeypatc
         assert np.array_equal(f, outs[0][3][i])                         # the oracle blots its frame the same way
 
 
+def test_fused_run_scan_gives_up_gracefully(oracle, monkeypatch):
+    """k_scan_fused's workgroups wait (bounded) for the totals of the frame's earlier workgroups; when several processes share
+    the GPU that wait can run into its bound.  With the bound set to zero polls (LFDMI_SCAN_SPIN=0) every such wait gives up:
+    the frames are flagged, the context goes back to the three-launch scan for good and runs the chunk once more -- same
+    records as an ordinary context, nothing sent to the worst-case workspace, through the batch entry point and the per-pass ones."""
+    from lfd_amd import _native, synth
+    pb, pd, prs = params()
+    rs_g, rs_o = rs_pair(oracle, prs)
+    frames, cats = zip(*[synth.make_frame(k)[:2] for k in range(4)])
+    batch = np.stack(frames)
+    packed = synth.pack_catalogs(list(cats))
+    with _native.Context(0, 1489, 2048, 4) as ctx:
+        want = ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g)
+        wb, _, _ = ctx.process_bright(np.ascontiguousarray(batch[:2, ::-1]), pb)
+    monkeypatch.setenv("LFDMI_SCAN_SPIN", "0")
+    with _native.Context(0, 1489, 2048, 4) as ctx:
+        for _ in range(2):
+            assert ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g).tobytes() == want.tobytes()
+        assert ctx.spill_count() == 0
+    with _native.Context(0, 1489, 2048, 4) as ctx:
+        rb, _, _ = ctx.process_bright(np.ascontiguousarray(batch[:2, ::-1]), pb)
+        assert rb.tobytes() == wb.tobytes() and ctx.spill_count() == 0
+    assert same(want[1], oracle.detect_frame(frames[1].copy(), pb, pd, cats[1], rs_o))
+
+
 def test_fused_run_scan_survives_the_wrap_of_its_epoch(monkeypatch):
     """k_scan_fused marks a workgroup's published totals with the launch's 22-bit epoch; when the epoch wraps the host clears
     the words and starts over.  A context started three launches before the wrap (LFDMI_SCAN_EPOCH0) gives the records of an
