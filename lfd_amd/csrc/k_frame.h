@@ -128,8 +128,11 @@ struct FgWordItem { int idx, id0; u64 c, cp, m; };
 __global__ void __launch_bounds__(FRAME_THREADS)
 k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_fg, const int *counters, int *Lf, int *YMf,
            int *FLf, int *ROWf, u64 *edge, int h, int w, int run_cap, int lds_cap, const int *active, int *fallback,
-           int *pass_flags, int lds_n, const int *perm) { // lds_n: entries of the label table this launch allocated (a multiple of 32, >= lds_cap)
+           int *pass_flags, int lds_n, const int *perm, long long *prof) { // lds_n: entries of the label table this launch allocated (a multiple of 32, >= lds_cap)
     const int g = perm ? perm[blockIdx.x] : (int)blockIdx.x; // (active frames first: one workgroup per frame, XCD = workgroup % 8)
+    const long long t0 = prof ? wall_clock64() : 0;
+    int pk = 8;
+#define FG_PROF() do { if (prof) { __syncthreads(); if (threadIdx.x == 0) prof[g * 16 + (pk++)] = wall_clock64() - t0; } } while (0)
     if (slot_off(active, counters, g)) {
         if (threadIdx.x == 0) fallback[g] = 0;
         return;
@@ -219,6 +222,7 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
             }
         });
     __syncthreads();
+    FG_PROF(); // 8: merge
     // ---- flatten; last row and strong flag per root
     frame_pipeline<FgWordItem>(
         wl, nwork,
@@ -263,6 +267,7 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
             }
         });
     __syncthreads();
+    FG_PROF(); // 9: flatten + strong
     // ---- edge = candidate runs whose component holds a strong pixel
     frame_pipeline<FgWordItem>(
         wl, nwork,
@@ -292,11 +297,13 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
             }
             edge[fo + t.idx] = res;
         });
+    FG_PROF(); // 10: edge bits
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
         int root = L[i];
         Lf[ro + i] = root;
         FLf[ro + i] = (root == i) ? (int)((FL[i >> 5] >> (i & 31)) & 1u) : 0; // root of an edge component
     }
+    FG_PROF(); // 11: write-out
 }
 
 struct BgMergeItem { int idx, id0, idu, first, firstu; u64 c, cp, u, up, r0, u0; };
@@ -322,12 +329,12 @@ struct ExtItem { int idx, id0, sbc, sbu, sbd; u64 e, ep, en, c, cp, u, up, d, dp
 __global__ void __launch_bounds__(FRAME_THREADS)
 k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, int4 *keys, int *bigkeys, int *medkeys, int2 *rowext,
                  int2 *rsa, int h, int w, int key_cap, int slot_cap, int lds_cap, const int *active, int *fallback, int *pass_flags, long long *prof,
-                 int lds_n, const int *perm) {
+                 int lds_n, const int *perm, int dbg) {
     // developer profile (prof != nullptr): wall-clock ticks (10 ns) at the end of every phase, per frame
     const long long t0 = prof ? wall_clock64() : 0;
     int pk = 0;
     const int g_prof = perm ? perm[blockIdx.x] : (int)blockIdx.x;
-#define FRAME_PROF() do { if (prof && threadIdx.x == 0) prof[g_prof * 8 + (pk++)] = wall_clock64() - t0; } while (0)
+#define FRAME_PROF() do { if (prof && threadIdx.x == 0) prof[g_prof * 16 + (pk++)] = wall_clock64() - t0; } while (0)
     const u64 *edge = t.edge;
     const int *scanb = t.scanb;
     int *Lb = t.Lb, *YMb = t.YMb, *FLb = t.FLb, *ROWb = t.ROWb;
@@ -414,7 +421,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
                 // own, joining them would only build a 1 489-link chain down the left image border
                 bool a0 = (ia == t.first) && !(t.r0 & 1ull), b0 = (ib == t.firstu) && !(t.u0 & 1ull);
                 if (a0 && b0) continue;
-                lds_union(L, ia, ib);
+                if (!(dbg & 8)) lds_union(L, ia, ib);
             }
         });
     __syncthreads();
@@ -597,7 +604,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
     // (the inside of their own ring); the memory-side atomics are what this phase is short of.
     struct SlotAcc { int slot, lo, hi; };
     auto acc_flush = [&](SlotAcc &a) {
-        if (a.slot >= 0) {
+        if (a.slot >= 0 && !(dbg & 4)) {
             if (lds_slots) {
                 if ((unsigned)a.slot < (unsigned)n_slots) { atomicMin(&SL[2 * a.slot], a.lo); atomicMax(&SL[2 * a.slot + 1], a.hi); }
             } else slot_update(re, a.slot, a.lo, a.hi);
@@ -614,6 +621,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
         a.slot = slot; a.lo = xa; a.hi = xb;
     };
     auto hole_update = [&](SlotAcc &acc, int bid, int A, int y, int xa, int xb) {
+        if (dbg & 2) return;
         if (!((HL[bid >> 5] >> (bid & 31)) & 1u)) return; // a run of the outside
         int B = L[bid];
         unsigned hs = ((unsigned)B * 2654435761u) >> 22;
@@ -676,7 +684,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
                 int xs = (q << 6) + b, xe = xs + len - 1;
                 int fid = k.id0 + __popcll(sc & upto_bit(b)) - 1; // a stretch continuing from the previous word: id0 - 1
                 if (fid < 0 || fid >= nrunf) continue;
-                int2 ra = RSA[fid];
+                int2 ra = (dbg & 1) ? make_int2(fid & 1023, 0) : RSA[fid];
                 const int slot = ra.x, A = ra.y;
                 if (slot >= 0) acc_add(outer, slot, xs, xe);
                 // same-row neighbours: the 0-pixel before the run and the one after it

@@ -189,6 +189,7 @@ struct lfdmi_ctx {
     bool general_seen = false, general_on = true;
     bool frame_ccl = true;             // per-frame LDS connectivity kernels (k_frame.h)
     int frame_runcap = FRAME_RUNCAP;   // runs per frame they take (LFDMI_FRAME_RUNCAP lowers it: tests of the fallback path)
+    int frame_dbg = 0;                 // LFDMI_FRAME_DBG: developer attribution switches of k_frame_contours (wrong results)
     int frame_lds = FRAME_RUNCAP;      // entries of their LDS label table (LFDMI_FRAME_LDS: a smaller table leaves LDS to other kernels
                                        // on the CU; frames with more runs take the general kernels)
     int *tile_list = nullptr;          // per slot: active 64 x 16 tiles of the pass image (k_dc_tiles -> k_dilate_canny_t)
@@ -324,6 +325,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_SPARSE_ERODE_FILL")) ctx->sparse_erode_fill = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_VOTE_SPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->vote_split = v; }
     if (const char *e = getenv("LFDMI_PE_ROWS")) { int v = atoi(e); if (v >= 2 && v <= 64) ctx->pe_rows = v; }
+    if (const char *e = getenv("LFDMI_FRAME_DBG")) ctx->frame_dbg = atoi(e);
     if (const char *e = getenv("LFDMI_FRAME_RUNCAP")) { int v = atoi(e); if (v >= 0 && v < FRAME_RUNCAP) ctx->frame_runcap = v; }
     if (const char *e = getenv("LFDMI_FRAME_LDS")) {
         int v = atoi(e);
@@ -383,7 +385,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
         RET(dmalloc(ctx, p, G * ctx->run_cap));
     if (const char *e = getenv("LFDMI_DC_PROFILE")) ctx->dc_profile = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_DC_SPECIALIZE")) ctx->dc_specialize = atoi(e) != 0;
-    if (getenv("LFDMI_FRAME_PROFILE") || ctx->dc_profile) RET(dmalloc(ctx, &ctx->prof, G * 8));
+    if (getenv("LFDMI_FRAME_PROFILE") || ctx->dc_profile) RET(dmalloc(ctx, &ctx->prof, G * 16));
     RET(dmalloc(ctx, &ctx->rsa, G * FRAME_RUNCAP));
     ctx->bm_bands = (max_h + CELLBM_ROWS - 1) / CELLBM_ROWS;
     if (const char *e = getenv("LFDMI_CELLBM")) ctx->use_cellbm = atoi(e) != 0;
@@ -809,7 +811,7 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
         size_t lds = (size_t)(ctx->frame_lds + 2 * (ctx->frame_lds / 32)) * sizeof(int);
         k_frame_fg<<<nc, FRAME_THREADS, lds, ctx->stream>>>(ctx->candb, ctx->strongb, ctx->scanf_, ctx->wl_fg, ctx->counters, ctx->Lf,
                                                             ctx->YMf, ctx->FLf, ctx->ROWf, ctx->edgeb, h, w, rc, ctx->frame_runcap, active, ctx->fb_fg,
-                                                            ctx->pass_flags, ctx->frame_lds, active ? ctx->perm_cur : nullptr);
+                                                            ctx->pass_flags, ctx->frame_lds, active ? ctx->perm_cur : nullptr, ctx->dc_profile ? nullptr : ctx->prof);
         KCHK("k_frame_fg");
         if (!ctx->general_on) return 0; // (a frame that did not fit raises PASS_FLAG_GENERAL: the caller runs the chunk again)
         active = ctx->fb_fg;
@@ -972,7 +974,7 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
         k_frame_contours<<<nc, FRAME_THREADS, lds, ctx->stream>>>(rt, ctx->wl_fg, ctx->wl_bg, ctx->counters, ctx->keys, ctx->bigkeys,
                                                                   ctx->medkeys, ctx->rowext, ctx->rsa, h, w, ctx->key_cap, ctx->slot_cap,
                                                                   ctx->frame_runcap, active, ctx->fb_bg, ctx->pass_flags, ctx->dc_profile ? nullptr : ctx->prof,
-                                                                  ctx->frame_lds, active ? ctx->perm_cur : nullptr);
+                                                                  ctx->frame_lds, active ? ctx->perm_cur : nullptr, ctx->frame_dbg);
         KCHK("k_frame_contours");
         gen = ctx->fb_bg;
     }
@@ -2370,7 +2372,7 @@ extern "C" int lfdmi_debug_fail_chunk(lfdmi_ctx *ctx, int chunk) {
 // developer tool: phase clocks of the last k_frame_contours launch
 extern "C" int lfdmi_debug_frame_profile(lfdmi_ctx *ctx, int n, long long *dst) {
     if (!ctx || !ctx->prof || n < 0 || n > ctx->G) return LFDMI_ERR_ARG;
-    HIPCHK(hipMemcpyAsync(dst, ctx->prof, (size_t)n * 8 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dst, ctx->prof, (size_t)n * 16 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
