@@ -198,7 +198,7 @@ extern "C" int lfdmi_fits_read_photoobj(const char *const *paths, int n, int max
         status[i] = -2;
         if (!ok) return;
         const size_t e0 = header_end(buf.data(), buf.size(), 0);
-        if (!e0) return;
+        if (!e0 || e0 > buf.size()) return; // (no END card, or the file stops inside the header's last block: e0 is rounded up to a block)
         // the primary HDU's data unit (photoObj files have none, NAXIS = 0)
         size_t off = e0;
         long long naxis = 0, bitpix = 8;
@@ -210,14 +210,16 @@ extern "C" int lfdmi_fits_read_photoobj(const char *const *paths, int n, int max
                 char key[16];
                 long long na = 0;
                 snprintf(key, sizeof key, "NAXIS%d", a);
-                if (!card_int(buf.data(), e0, key, &na)) return;
+                if (!card_int(buf.data(), e0, key, &na) || na < 0) return;
+                if (na && nb > (unsigned long long)buf.size() / (unsigned long long)na) return; // (data unit larger than the file: also keeps the product from wrapping)
                 nb *= (unsigned long long)na;
             }
+            if (nb > buf.size()) return;
             off += (nb + BLOCK - 1) / BLOCK * BLOCK;
         }
         if (off >= buf.size()) return;
         const size_t e1 = header_end(buf.data(), buf.size(), off);
-        if (!e1) return;
+        if (!e1 || e1 > buf.size()) return;
         const char *th = buf.data() + off;
         const size_t tl = e1 - off;
         std::string xt;
@@ -225,12 +227,14 @@ extern "C" int lfdmi_fits_read_photoobj(const char *const *paths, int n, int max
         if (!card_str(th, tl, "XTENSION", &xt) || xt != "BINTABLE" || !card_int(th, tl, "NAXIS1", &row_bytes) ||
             !card_int(th, tl, "NAXIS2", &nrows) || !card_int(th, tl, "TFIELDS", &nf) || nf <= 0 || nf > 999 || row_bytes <= 0 || nrows < 0)
             return;
-        if (e1 + (unsigned long long)row_bytes * nrows > buf.size()) return;
+        // sizes from the header are checked against the file before they are used as offsets (hostile or truncated files)
+        if ((unsigned long long)row_bytes > buf.size() - e1 || (nrows && (unsigned long long)nrows > (buf.size() - e1) / (unsigned long long)row_bytes)) return;
         status[i] = 1; // from here on: a well-formed table this reader may still decline
         if (nrows > max_obj) return;
         long long col_off[6], col_rep[6];
         char col_code[6];
         for (int c = 0; c < 6; c++) col_off[c] = -1;
+        bool has_objc_type = false, has_type = false; // read_photoObj (removestars.py:97-104) also asks for these two columns
         long long pos = 0;
         for (int f = 1; f <= nf; f++) {
             char key[16];
@@ -239,8 +243,8 @@ extern "C" int lfdmi_fits_read_photoobj(const char *const *paths, int n, int max
             if (!card_str(th, tl, key, &form) || form.empty()) { status[i] = -2; return; }
             size_t j = 0;
             while (j < form.size() && form[j] >= '0' && form[j] <= '9') j++;
-            const long long rep = j ? atoll(form.substr(0, j).c_str()) : 1;
-            if (j >= form.size()) { status[i] = -2; return; }
+            const long long rep = (j && j <= 9) ? atoll(form.substr(0, j).c_str()) : (j ? -1 : 1);
+            if (j >= form.size() || rep < 0 || rep > row_bytes * 8) { status[i] = -2; return; } // (a repeat count no row of this table could hold)
             const char code = form[j];
             long long width;
             switch (code) {
@@ -258,6 +262,8 @@ extern "C" int lfdmi_fits_read_photoobj(const char *const *paths, int n, int max
             snprintf(key, sizeof key, "TTYPE%d", f);
             if (card_str(th, tl, key, &name)) {
                 for (auto &ch : name) if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 'a' + 'A');
+                has_objc_type = has_objc_type || name == "OBJC_TYPE";
+                has_type = has_type || name == "TYPE";
                 for (int c = 0; c < 6; c++)
                     if (col_off[c] < 0 && name == WANT[c]) {
                         std::string dummy;
@@ -269,8 +275,10 @@ extern "C" int lfdmi_fits_read_photoobj(const char *const *paths, int n, int max
                     }
             }
             pos += width;
+            if (pos > row_bytes) { status[i] = -2; return; }
         }
         if (pos != row_bytes) { status[i] = -2; return; }
+        if (!has_objc_type || !has_type) { status[i] = -3; return; } // (KeyError in the reference and in the general reader: same outcome for every batch size)
         for (int c = 0; c < 6; c++) {
             if (col_off[c] < 0) { status[i] = -3; return; } // a wanted column is missing (KeyError in the general reader)
             if (c < 4 ? !(col_code[c] == 'E' && col_rep[c] == 5) : !((col_code[c] == 'J' || col_code[c] == 'I' || col_code[c] == 'B' || col_code[c] == 'K') && col_rep[c] == 1))

@@ -116,6 +116,25 @@ __device__ __forceinline__ void frame_pipeline(const int *wl, int nwork, LoadF l
     }
 }
 
+// The same over list POSITIONS, for phases that read the item records the scan kernels left (k_ccl.h: scan_write_records):
+// dense, coalesced loads.  Two load stages: loadA(pos) reads the record, loadB(item) issues what depends on it (the scan value
+// of the word above, one gather); both run ahead of proc.
+template <class Item, class LoadA, class LoadB, class ProcF>
+__device__ __forceinline__ void frame_pipeline_rec(int nwork, LoadA loadA, LoadB loadB, ProcF proc) {
+    int p0 = threadIdx.x, p1 = p0 + FRAME_THREADS, p2 = p1 + FRAME_THREADS;
+    Item cur, nxt, nn;
+    if (p0 < nwork) cur = loadA(p0);
+    if (p1 < nwork) nxt = loadA(p1);
+    if (p0 < nwork) loadB(cur);
+    while (p0 < nwork) {
+        if (p2 < nwork) nn = loadA(p2);
+        if (p1 < nwork) loadB(nxt);
+        proc(cur);
+        cur = nxt; nxt = nn;
+        p0 = p1; p1 = p2; p2 += FRAME_THREADS;
+    }
+}
+
 // bits 0 .. b
 __device__ __forceinline__ u64 upto_bit(int b) { return (b == 63) ? ~0ull : ((2ull << b) - 1ull); }
 
@@ -128,7 +147,7 @@ struct FgWordItem { int idx, id0; u64 c, cp, m; };
 __global__ void __launch_bounds__(FRAME_THREADS)
 k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_fg, const int *counters, int *Lf, int *YMf,
            int *FLf, int *ROWf, u64 *edge, int h, int w, int run_cap, int lds_cap, const int *active, int *fallback,
-           int *pass_flags, int lds_n, const int *perm, long long *prof) { // lds_n: entries of the label table this launch allocated (a multiple of 32, >= lds_cap)
+           int *pass_flags, int lds_n, const int *perm, long long *prof, const uint4 *recA, const uint4 *recB, int rec_cap) { // lds_n: entries of the label table this launch allocated (a multiple of 32, >= lds_cap)
     const int g = perm ? perm[blockIdx.x] : (int)blockIdx.x; // (active frames first: one workgroup per frame, XCD = workgroup % 8)
     const long long t0 = prof ? wall_clock64() : 0;
     int pk = 8;
@@ -153,13 +172,25 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
     int *YMg = YMf + ro, *ROWg = ROWf + ro;
     const u64 *fb = cand + fo, *mb = strong + fo;
     const int *sf = scanf + fo, *wl = wl_fg + fo;
+    // item records of this frame's list (the scan kernel wrote them when the list fits rec_cap): every phase then reads a
+    // dense array instead of gathering its words
+    const bool use_rec = recA != nullptr && nwork <= rec_cap;
+    const uint4 *ra = recA + (size_t)g * rec_cap, *rb = recB + (size_t)g * rec_cap;
+    auto rec_word_item = [&](int pos) { // (flatten / edge phases: everything is in the record)
+        FgWordItem t;
+        const uint4 a = ra[pos], b = rb[pos];
+        t.idx = (int)(b.z & ((1u << REC_FLAG_SHIFT) - 1u));
+        t.id0 = (int)b.w;
+        t.c = (u64)a.x | ((u64)a.y << 32);
+        t.cp = (u64)((b.z >> REC_FLAG_SHIFT) & 1u) << 63;
+        t.m = (u64)b.x | ((u64)b.y << 32);
+        return t;
+    };
     for (int i = threadIdx.x; i < (nrun + 31) / 32; i += FRAME_THREADS) { FL[i] = 0u; HB[i] = 0u; }
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) L[i] = i; // every run its own root
     __syncthreads();
     // ---- row of every run; 8-connectivity between rows y and y-1
-    frame_pipeline<FgMergeItem>(
-        wl, nwork,
-        [&](int idx) {
+    auto merge_load = [&](int idx) {
             FgMergeItem t;
             int y = idx / wq, q = idx - y * wq;
             t.idx = idx;
@@ -174,8 +205,8 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
                 t.idu = sf[idx - wq];
             }
             return t;
-        },
-        [&](const FgMergeItem &t) {
+    };
+    auto merge_proc = [&](const FgMergeItem &t) {
             int y = t.idx / wq, q = t.idx - y * wq;
             u64 vmask = valid_mask(q, w);
             u64 c = t.c & vmask;
@@ -220,13 +251,32 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
                 // run there (bit 63 above is clear): the first run after those starting in this word
                 join(own(b), b < 63 ? above(b + 1) : t.idu + __popcll(su));
             }
-        });
+    };
+    if (use_rec)
+        frame_pipeline_rec<FgMergeItem>(
+            nwork,
+            [&](int pos) {
+                FgMergeItem t;
+                const uint4 a = ra[pos], b = rb[pos];
+                const unsigned fl = b.z >> REC_FLAG_SHIFT;
+                t.idx = (int)(b.z & ((1u << REC_FLAG_SHIFT) - 1u));
+                t.id0 = (int)b.w;
+                t.c = (u64)a.x | ((u64)a.y << 32);
+                t.u = (u64)a.z | ((u64)a.w << 32);
+                t.cp = (u64)(fl & 1u) << 63;         // (only the neighbour pixels the merge looks at)
+                t.up = (u64)((fl >> 1) & 1u) << 63;
+                t.un = (u64)((fl >> 2) & 1u);
+                t.idu = 0;
+                return t;
+            },
+            [&](FgMergeItem &t) { if (t.idx >= wq) t.idu = sf[t.idx - wq]; },
+            merge_proc);
+    else
+        frame_pipeline<FgMergeItem>(wl, nwork, merge_load, merge_proc);
     __syncthreads();
     FG_PROF(); // 8: merge
     // ---- flatten; last row and strong flag per root
-    frame_pipeline<FgWordItem>(
-        wl, nwork,
-        [&](int idx) {
+    auto flat_load = [&](int idx) {
             FgWordItem t;
             int y = idx / wq, q = idx - y * wq;
             t.idx = idx;
@@ -235,8 +285,8 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
             t.m = mb[idx];
             t.id0 = sf[idx];
             return t;
-        },
-        [&](const FgWordItem &t) {
+    };
+    auto flat_proc = [&](const FgWordItem &t) {
             int y = t.idx / wq, q = t.idx - y * wq;
             u64 c = t.c & valid_mask(q, w);
             u64 s = c & ~((c << 1) | (t.cp >> 63));
@@ -265,13 +315,13 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
                 int root = lds_find(L, t.id0 + __popcll(s & upto_bit(b)) - 1);
                 atomicOr(&FL[root >> 5], 1u << (root & 31));
             }
-        });
+    };
+    if (use_rec) frame_pipeline_rec<FgWordItem>(nwork, rec_word_item, [](FgWordItem &) {}, flat_proc);
+    else frame_pipeline<FgWordItem>(wl, nwork, flat_load, flat_proc);
     __syncthreads();
     FG_PROF(); // 9: flatten + strong
     // ---- edge = candidate runs whose component holds a strong pixel
-    frame_pipeline<FgWordItem>(
-        wl, nwork,
-        [&](int idx) {
+    auto edge_load = [&](int idx) {
             FgWordItem t;
             int y = idx / wq, q = idx - y * wq;
             t.idx = idx;
@@ -280,8 +330,8 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
             t.m = 0;
             t.id0 = sf[idx];
             return t;
-        },
-        [&](const FgWordItem &t) {
+    };
+    auto edge_proc = [&](const FgWordItem &t) {
             int y = t.idx / wq, q = t.idx - y * wq;
             u64 c = t.c & valid_mask(q, w);
             u64 s = c & ~((c << 1) | (t.cp >> 63));
@@ -296,7 +346,9 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
                 rem &= ~seg;
             }
             edge[fo + t.idx] = res;
-        });
+    };
+    if (use_rec) frame_pipeline_rec<FgWordItem>(nwork, rec_word_item, [](FgWordItem &) {}, edge_proc);
+    else frame_pipeline<FgWordItem>(wl, nwork, edge_load, edge_proc);
     FG_PROF(); // 10: edge bits
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
         int root = L[i];

@@ -433,21 +433,39 @@ class DetectTrails:
         world_size = int(os.environ.get("WORLD_SIZE", 1)) if world_size is None else world_size
         suffix = f".rank{rank}" if world_size > 1 else ""
         keys = list(self._frames())
+        n_selection = len(keys)
         if world_size > 1:
             a, b = shard_range(len(keys), rank, world_size)
             keys = keys[a:b]
         progress_path = self.results + suffix + ".progress"
+        # first line of the progress file: what the marks below it belong to.  A resume only trusts marks written for the same
+        # selection, shard and world size; anything else (an older run of another selection into the same savepath, a change
+        # of world_size: the marks would be compared against a different shard) is refused, not silently applied.
+        header = "# lfd-progress v1 pick=%s run=%s camcol=%s filter=%s field=%s rank=%d world_size=%d selection=%d" % (
+            self._pick, self.kwargs.get("run", 0), self._camcol, self._filter, self._field, rank, world_size, n_selection)
         skipped = 0
+        fresh = True
         if resume and os.path.exists(progress_path):
             with open(progress_path) as f:
-                done = {tuple(ln.split()) for ln in f if ln.strip()}
-            before = len(keys)
-            keys = [k for k in keys if tuple(str(x) for x in k) not in done]
-            skipped = before - len(keys)
+                lines = [ln.strip() for ln in f if ln.strip()]
+            if lines:
+                if lines[0] != header:
+                    raise ValueError("resume=True: %s was written for another selection / shard (%r, this run: %r); "
+                                     "delete it or run with resume=False" % (progress_path, lines[0], header))
+                done = {tuple(ln.split()) for ln in lines[1:]}
+                before = len(keys)
+                keys = [k for k in keys if tuple(str(x) for x in k) not in done]
+                skipped = before - len(keys)
+                fresh = False
         self.last_stats = {"frames": len(keys), "chunk_frames": 0, "setup_s": 0.0, "chunk_done_s": [], "seconds": 0.0,
                            "skipped_by_resume": skipped}
+        # resume=False starts a new record of marks (an earlier run's marks must never make a later resume skip frames this
+        # run did not process); rows and errors are appended to, as in the reference
         with open(self.results + suffix, "a") as results, open(self.errors + suffix, "a") as errors, \
-                open(progress_path, "a") as progress:
+                open(progress_path, "w" if fresh else "a") as progress:
+            if fresh:
+                progress.write(header + "\n")
+                progress.flush()
 
             def mark(done_keys):                     # rows first, then the marks: a crash in between repeats a chunk, never loses one
                 results.flush()

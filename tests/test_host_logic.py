@@ -220,10 +220,50 @@ def test_resume_skips_frames_already_marked_done(tmp_path, monkeypatch):
     import pytest
     with pytest.raises(KeyboardInterrupt):
         dt.process(batch=1)
-    assert open(dt.results + ".progress").read().split("\n")[:3] == ["94 1 r 100", "94 1 r 101", "94 1 r 102"]
+    marks = open(dt.results + ".progress").read().split("\n")
+    assert marks[0].startswith("# lfd-progress v1 ") and "world_size=1" in marks[0]
+    assert marks[1:4] == ["94 1 r 100", "94 1 r 101", "94 1 r 102"]
     dt.process(batch=1, resume=True)
     assert calls == [100, 101, 102, 103, 103, 104, 105] and dt.last_stats["skipped_by_resume"] == 3
     rows = [ln.split()[3] for ln in open(dt.results)]
     assert rows == ["100", "101", "102", "103", "104", "105"]
     dt.process(batch=1, resume=True)                                  # nothing left
     assert dt.last_stats["frames"] == 0 and len(calls) == 7
+
+
+def test_progress_marks_of_an_earlier_run_never_leak_into_a_later_resume(tmp_path, monkeypatch):
+    """a finished run, then an interrupted resume=False run, then resume=True must process exactly the frames the
+    interrupted run did not reach (resume=False starts a new progress file); marks written for another shard layout or
+    another selection are refused instead of being compared against the wrong frames."""
+    import pytest
+    _write_runlist(tmp_path)
+    monkeypatch.setattr(detecttrails.DetectTrails, "_runInfo", lambda self: (100, 106))
+    calls, stop_at = [], [None]
+
+    def fake_field(results, errors, run, camcol, flt, field, pb, pd, prs):
+        if stop_at[0] is not None and field == stop_at[0]:
+            raise KeyboardInterrupt
+        calls.append(field)
+        results.write("%d %d %s %d row\n" % (run, camcol, flt, field))
+
+    monkeypatch.setattr(detecttrails, "process_field", fake_field)
+    dt = detecttrails.DetectTrails(run=94, camcol=1, filter="r", savepath=str(tmp_path))
+    dt.process(batch=1)                                               # a full run: six marks
+    assert calls == [100, 101, 102, 103, 104, 105]
+    del calls[:]
+    stop_at[0] = 102
+    with pytest.raises(KeyboardInterrupt):
+        dt.process(batch=1)                                           # a second run from scratch, cut short after two frames
+    assert calls == [100, 101]
+    stop_at[0] = None
+    dt.process(batch=1, resume=True)                                  # ... continues with the other four, not with nothing
+    assert calls == [100, 101, 102, 103, 104, 105] and dt.last_stats["skipped_by_resume"] == 2
+    # another shard layout / another selection: refused
+    with pytest.raises(ValueError, match="another selection"):
+        detecttrails.DetectTrails(run=94, camcol=1, filter="g", savepath=str(tmp_path)).process(batch=1, resume=True)
+    # the same selection sharded over two ranks keeps its own files (.rank0 / .rank1) and headers
+    dt.process(batch=1, rank=0, world_size=2)
+    assert "world_size=2" in open(dt.results + ".rank0.progress").readline()
+    os.rename(dt.results + ".rank0.progress", dt.results + ".rank1.progress")
+    with pytest.raises(ValueError, match="another selection"):
+        dt.process(batch=1, rank=1, world_size=2, resume=True)        # rank 0's marks are not rank 1's

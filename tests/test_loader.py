@@ -147,3 +147,40 @@ def test_native_reader_statuses(tmp_path):
     assert out.slot[5] >= 0 and len(out.hdr[5]) > loader.HDR_CAP
     assert loader.header_values(out.hdr[5], ["K299", "TAI"]) == [299.0, hdr["TAI"]]
     assert np.array_equal(out.buffer[out.slot[5]].astype(np.float32), frames[5])
+
+
+def test_table_without_the_type_columns_is_a_keyerror_for_every_batch_size(tmp_path):
+    """read_photoObj (removestars.py:97-104) also asks for OBJC_TYPE and TYPE: a table without them is a KeyError (an
+    errors.txt entry) in the reference and frame by frame; the native batch reader must not quietly accept it."""
+    frames, cats, hdr = _tree(tmp_path)
+    from lfd_amd.detecttrails import fitslite as F
+    F.write_table(sdssfiles.filename("photoObj", 94, 1, 100), dict(cats[0]))                 # the six columns only
+    keys = [(94, 1, "r", f) for f in (100, 101)]
+    with loader.FrameLoader(_Ctx(), (64, 96), 4, threads=2) as ld:
+        out = ld.load(keys, 0)
+    assert isinstance(out.error[0], KeyError) and out.slot[0] < 0
+    assert out.error[1] is None and out.slot[1] >= 0
+    assert loader.read_catalog(sdssfiles.filename("photoObj", 94, 1, 100)) is None
+
+
+def test_truncated_and_hostile_table_headers_are_declined_not_read_past(tmp_path):
+    """A photoObj file cut inside its table header's last block, and headers whose sizes do not fit the file:
+    status 'malformed', nothing read outside the buffer (run under ASan by tools/oracle_sanitize.sh)."""
+    frames, cats, hdr = _tree(tmp_path)
+    p = sdssfiles.filename("photoObj", 94, 1, 100)
+    data = open(p, "rb").read()
+    e0 = loader.header_end(data)
+    e1 = e0 + loader.header_end(data[e0:])
+    cases = {"cut_in_table_header": data[:e1 - 1000], "cut_in_primary_header": data[:e0 - 100], "cut_in_rows": data[:e1 + 10]}
+    tbl = bytearray(data)
+    k = data.index(b"NAXIS1  =", e0)
+    tbl[k:k + 30] = b"NAXIS1  =  9223372036854775807"                                        # row_bytes * nrows wraps 64 bits
+    cases["row_bytes_wraps"] = bytes(tbl)
+    tbl = bytearray(data)
+    k = data.index(b"TFORM1  =", e0)
+    tbl[k:k + 40] = (b"TFORM1  = '99999999999999999999E'" + b" " * 40)[:40]
+    cases["repeat_count_overflows"] = bytes(tbl)
+    for name, blob in cases.items():
+        q = str(tmp_path / (name + ".fits"))
+        open(q, "wb").write(blob)
+        assert loader.read_catalog(q) is None, name
