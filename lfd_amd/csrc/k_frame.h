@@ -145,30 +145,44 @@ struct FgWordItem { int idx, id0; u64 c, cp, m; };
 // bit rows; Lf / YMf / FLf / ROWf written for the contour kernels.  Replaces k_runs_init(fg),
 // k_runs_merge8, k_runs_flatten(fg) and k_edge_from_cand.
 __global__ void __launch_bounds__(FRAME_THREADS)
-k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_fg, const int *counters, int *Lf, int *YMf,
+k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_fg, int *counters, int *Lf, int *YMf,
            int *FLf, int *ROWf, u64 *edge, int h, int w, int run_cap, int lds_cap, const int *active, int *fallback,
-           int *pass_flags, int lds_n, const int *perm, long long *prof, const uint4 *recA, const uint4 *recB, int rec_cap) { // lds_n: entries of the label table this launch allocated (a multiple of 32, >= lds_cap)
+           int *pass_flags, int lds_ints, const int *perm, long long *prof, const uint4 *recA, const uint4 *recB, int rec_cap,
+           int4 *keys, int *bigkeys, int *medkeys, int2 *rowext, int key_cap, int slot_cap, int *fg_keys) {
+    // lds_ints: ints of dynamic LDS this launch allocated.  keys != nullptr: the contour stage follows (k_frame_contours): the
+    // OUTER-border keys of the edge components, their row slots and the per-row extremes are made here, where the labels of the
+    // candidate runs already sit in LDS (round 4; until then k_frame_contours re-read them from memory: three of its phases and
+    // a gather per edge stretch), and fg_keys[frame] = 1 tells k_frame_contours so.
     const int g = perm ? perm[blockIdx.x] : (int)blockIdx.x; // (active frames first: one workgroup per frame, XCD = workgroup % 8)
     const long long t0 = prof ? wall_clock64() : 0;
     int pk = 8;
 #define FG_PROF() do { if (prof) { __syncthreads(); if (threadIdx.x == 0) prof[g * 16 + (pk++)] = wall_clock64() - t0; } } while (0)
     if (slot_off(active, counters, g)) {
-        if (threadIdx.x == 0) fallback[g] = 0;
+        if (threadIdx.x == 0) { fallback[g] = 0; if (fg_keys) fg_keys[g] = 0; }
         return;
     }
     const int wq = LFD_WQ(w);
     const size_t fo = (size_t)g * h * wq, ro = (size_t)g * run_cap;
     const int nwork = counters[g * C_COUNT + C_NFGW], nrun = counters[g * C_COUNT + C_NRUNF];
-    const bool fits = nrun <= lds_cap; // lds_cap <= FRAME_RUNCAP (k_scan_bases flags nrun > run_cap as an overflow)
+    // LDS: labels L[n32] | strong-root bits | "a run below" bits | X: the rest (last rows per root, then the row slots)
+    const int n32 = (nrun + 31) & ~31;
+    const int sizeX = lds_ints - n32 - 2 * (n32 / 32);
+    const bool fits = nrun <= lds_cap && sizeX >= 0; // lds_cap <= FRAME_RUNCAP (k_scan_bases flags nrun > run_cap as an overflow)
+    const bool keys_path = keys != nullptr && fits && sizeX >= n32; // (room for a last-row entry per run)
     if (threadIdx.x == 0) {
         fallback[g] = fits ? 0 : 1;
+        if (fg_keys) fg_keys[g] = keys_path ? 1 : 0;
         if (!fits) atomicOr(&pass_flags[g], PASS_FLAG_GENERAL); // tells the host the general kernels are needed
     }
     if (!fits) return;
     extern __shared__ int sm_frame[];
     int *L = sm_frame;
-    unsigned *FL = (unsigned *)(sm_frame + lds_n);       // root holds a strong pixel
-    unsigned *HB = FL + lds_n / 32;                      // run touches a run of the next row
+    unsigned *FL = (unsigned *)(sm_frame + n32);         // root holds a strong pixel
+    unsigned *HB = FL + n32 / 32;                        // run touches a run of the next row
+    int *X = (int *)(HB + n32 / 32);
+    int *YM = X;                                         // keys_path: last row of every root's component
+    __shared__ int c_slots, c_keys, c_big, c_med, c_ovf;
+    if (threadIdx.x == 0) { c_slots = 0; c_keys = 0; c_big = 0; c_med = 0; c_ovf = 0; }
     int *YMg = YMf + ro, *ROWg = ROWf + ro;
     const u64 *fb = cand + fo, *mb = strong + fo;
     const int *sf = scanf + fo, *wl = wl_fg + fo;
@@ -213,7 +227,7 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
             u64 s = c & ~((c << 1) | (t.cp >> 63)); // run starts of this word
             for (int k = 0, n = __popcll(s); k < n; k++) {
                 ROWg[t.id0 + k] = y;
-                YMg[t.id0 + k] = y;
+                if (keys_path) YM[t.id0 + k] = y; else YMg[t.id0 + k] = y;
             }
             if (y == 0 || !c) return;
             u64 u = t.u & vmask;
@@ -298,7 +312,7 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
                     L[id] = root;
                     // last row of the component: only runs with nothing below them can hold it (a big
                     // component would otherwise serialise thousands of atomics on one address)
-                    if (!((HB[id >> 5] >> (id & 31)) & 1u)) atomicMax(&YMg[root], y);
+                    if (!((HB[id >> 5] >> (id & 31)) & 1u)) { if (keys_path) atomicMax(&YM[root], y); else atomicMax(&YMg[root], y); }
                 }
             }
             // strong pixels, stretch by stretch INSIDE this word (a run that started in an earlier word is
@@ -320,7 +334,50 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
     else frame_pipeline<FgWordItem>(wl, nwork, flat_load, flat_proc);
     __syncthreads();
     FG_PROF(); // 9: flatten + strong
-    // ---- edge = candidate runs whose component holds a strong pixel
+    // ---- contour keys of the edge components (their outer borders), keys_path only
+    const int NOEDGE = INT_MIN, EDGE_NOSLOT = INT_MIN + 1;
+    int4 *kg = keys + (size_t)g * key_cap;
+    int2 *re = rowext + (size_t)g * slot_cap;
+    bool lds_slots = false;
+    int n_slots = 0;
+    int *SL = X; // (x min, x max) pairs over the dead last-row table
+    if (keys_path) {
+        // labels and flags for the contour stage / the general kernels (before the table is rewritten below)
+        for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
+            const int root = L[i];
+            Lf[ro + i] = root;
+            FLf[ro + i] = (root == i) ? (int)((FL[i >> 5] >> (i & 31)) & 1u) : 0; // root of an edge component
+            YMg[i] = YM[i];
+        }
+        for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
+            if (L[i] != i || !((FL[i >> 5] >> (i & 31)) & 1u)) continue;
+            const int y0 = ROWg[i], extent = YM[i] - y0 + 1; // (ROWg: written by this workgroup before the barriers above)
+            const int base = atomicAdd(&c_slots, extent), ki = atomicAdd(&c_keys, 1);
+            if (base + extent > slot_cap || ki >= key_cap) {
+                c_ovf = 1;
+                YM[i] = EDGE_NOSLOT;
+                continue;
+            }
+            kg[ki] = make_int4(i, extent, y0, base);
+            if (extent > BIG_KEY_ROWS) bigkeys[(size_t)g * key_cap + atomicAdd(&c_big, 1)] = ki;
+            else if (extent > SMALL_KEY_ROWS) medkeys[(size_t)g * key_cap + atomicAdd(&c_med, 1)] = ki;
+            YM[i] = base - y0; // row y of this component lives in slot YM[root] + y
+        }
+        __syncthreads();
+        // L[run] := slot offset of its component (or "not an edge run"): one LDS read per stretch below
+        for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
+            const int r = L[i];
+            L[i] = ((FL[r >> 5] >> (r & 31)) & 1u) ? YM[r] : NOEDGE;
+        }
+        __syncthreads(); // the last-row table is dead: its space takes the row slots
+        n_slots = min(c_slots, slot_cap);
+        lds_slots = 2 * n_slots <= sizeX && c_ovf == 0;
+        if (lds_slots) for (int i = threadIdx.x; i < n_slots; i += FRAME_THREADS) { SL[2 * i] = 0x7fffffff; SL[2 * i + 1] = -1; }
+        else for (int i = threadIdx.x; i < n_slots; i += FRAME_THREADS) re[i] = make_int2(0x7fffffff, -1);
+        __syncthreads();
+        FG_PROF(); // 10: outer keys
+    }
+    // ---- edge = candidate runs whose component holds a strong pixel (keys_path: and the per-row extremes of the outer borders)
     auto edge_load = [&](int idx) {
             FgWordItem t;
             int y = idx / wq, q = idx - y * wq;
@@ -347,6 +404,52 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
             }
             edge[fo + t.idx] = res;
     };
+    auto edge_keys_proc = [&](const FgWordItem &t) {
+            int y = t.idx / wq, q = t.idx - y * wq;
+            u64 c = t.c & valid_mask(q, w);
+            u64 s = c & ~((c << 1) | (t.cp >> 63));
+            u64 rem = c, res = 0;
+            // a word's stretches mostly widen the same row slot: consecutive updates of one slot are merged in registers
+            int aslot = -1, alo = 0, ahi = 0;
+            auto flush = [&]() {
+                if (aslot < 0) return;
+                if (lds_slots) { if (aslot < n_slots) { atomicMin(&SL[2 * aslot], alo); atomicMax(&SL[2 * aslot + 1], ahi); } }
+                else slot_update(re, aslot, alo, ahi);
+                aslot = -1;
+            };
+            while (rem) {
+                int b = __ffsll((long long)rem) - 1;
+                u64 inv = ~(c >> b);
+                int len = inv ? (__ffsll((long long)inv) - 1) : (64 - b);
+                u64 seg = (len >= 64 ? ~0ull : ((1ull << len) - 1)) << b;
+                rem &= ~seg;
+                const int v = L[t.id0 + __popcll(s & upto_bit(b)) - 1]; // a stretch continuing from the previous word: id0 - 1
+                if (v == NOEDGE) continue;
+                res |= seg;
+                if (v == EDGE_NOSLOT) continue;
+                const int slot = v + y, xs = (q << 6) + b, xe = xs + len - 1;
+                if (slot == aslot) { alo = min(alo, xs); ahi = max(ahi, xe); }
+                else { flush(); aslot = slot; alo = xs; ahi = xe; }
+            }
+            flush();
+            edge[fo + t.idx] = res;
+    };
+    if (keys_path) {
+        if (use_rec) frame_pipeline_rec<FgWordItem>(nwork, rec_word_item, [](FgWordItem &) {}, edge_keys_proc);
+        else frame_pipeline<FgWordItem>(wl, nwork, edge_load, edge_keys_proc);
+        __syncthreads();
+        if (lds_slots) for (int i = threadIdx.x; i < n_slots; i += FRAME_THREADS) re[i] = make_int2(SL[2 * i], SL[2 * i + 1]);
+        if (threadIdx.x == 0) {
+            int *cnt = counters + g * C_COUNT;
+            cnt[C_NSLOTS] = c_slots;
+            cnt[C_NKEYS] = c_keys < key_cap ? c_keys : key_cap;
+            cnt[C_NBIG] = c_big;
+            cnt[C_NMED] = c_med;
+            if (c_ovf) cnt[C_OVERFLOW] = 1;
+        }
+        FG_PROF(); // 11: edge bits + outer extremes
+        return;
+    }
     if (use_rec) frame_pipeline_rec<FgWordItem>(nwork, rec_word_item, [](FgWordItem &) {}, edge_proc);
     else frame_pipeline<FgWordItem>(wl, nwork, edge_load, edge_proc);
     FG_PROF(); // 10: edge bits
@@ -381,7 +484,9 @@ struct ExtItem { int idx, id0, sbc, sbu, sbd; u64 e, ep, en, c, cp, u, up, d, dp
 __global__ void __launch_bounds__(FRAME_THREADS)
 k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, int4 *keys, int *bigkeys, int *medkeys, int2 *rowext,
                  int2 *rsa, int h, int w, int key_cap, int slot_cap, int lds_cap, const int *active, int *fallback, int *pass_flags, long long *prof,
-                 int lds_n, const int *perm, int dbg) {
+                 int lds_n, const int *perm, int dbg, const int *fg_keys) {
+    // fg_keys[frame] != 0: k_frame_fg has made the outer-border keys, their row slots and extremes already (counters C_NKEYS /
+    // C_NSLOTS / C_NBIG / C_NMED hold its totals): only the hole borders are left to do here
     // developer profile (prof != nullptr): wall-clock ticks (10 ns) at the end of every phase, per frame
     const long long t0 = prof ? wall_clock64() : 0;
     int pk = 0;
@@ -401,9 +506,16 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
     const int nwork = counters[g * C_COUNT + C_NBGW], nrun = counters[g * C_COUNT + C_NRUNB];
     const int nwf = counters[g * C_COUNT + C_NFGW], nrunf = counters[g * C_COUNT + C_NRUNF];
     const bool fits = nrun <= lds_cap && nrunf <= lds_cap; // (then k_frame_fg took the frame too: FLf is set)
+    const bool fgk = fg_keys != nullptr && fg_keys[g] != 0;
     if (threadIdx.x == 0) {
         fallback[g] = fits ? 0 : 1;
-        if (!fits) atomicOr(&pass_flags[g], PASS_FLAG_GENERAL);
+        if (!fits) {
+            atomicOr(&pass_flags[g], PASS_FLAG_GENERAL);
+            if (fgk) { // the general kernels (k_keys) make every key of this frame themselves
+                int *cnt = counters + g * C_COUNT;
+                cnt[C_NSLOTS] = 0; cnt[C_NKEYS] = 0; cnt[C_NBIG] = 0; cnt[C_NMED] = 0;
+            }
+        }
     }
     if (!fits) return;
     extern __shared__ int sm_frame[];
@@ -420,7 +532,11 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
     // holes of the frame, keyed by their root run: (slot of border row 0 minus that row, surrounding component)
     __shared__ int hkey[FRAME_HOLECAP];
     __shared__ int2 hval[FRAME_HOLECAP];
-    if (threadIdx.x == 0) { c_slots = 0; c_keys = 0; c_big = 0; c_med = 0; c_ovf = 0; c_hovf = 0; }
+    if (threadIdx.x == 0) {
+        const int *cnt = counters + g * C_COUNT;
+        c_slots = fgk ? cnt[C_NSLOTS] : 0; c_keys = fgk ? cnt[C_NKEYS] : 0; c_big = fgk ? cnt[C_NBIG] : 0; c_med = fgk ? cnt[C_NMED] : 0;
+        c_ovf = 0; c_hovf = 0;
+    }
     for (int i = threadIdx.x; i < FRAME_HOLECAP; i += FRAME_THREADS) hkey[i] = -1;
     for (int i = threadIdx.x; i < (nrun + 31) / 32; i += FRAME_THREADS) { FL[i] = 0u; HB[i] = 0u; HL[i] = 0u; HR[i] = 0u; }
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) L[i] = i;
@@ -565,6 +681,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
         else if (extent > SMALL_KEY_ROWS) medkeys[(size_t)g * key_cap + atomicAdd(&c_med, 1)] = ki;
         return base; // the slots themselves are initialised by the whole workgroup, see below
     };
+    if (!fgk)
     for (int i0 = threadIdx.x; i0 < nrunf; i0 += 4 * FRAME_THREADS) { // four independent loads in flight per lane
         int lf[4], fl[4];
 #pragma unroll
@@ -583,11 +700,12 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
     }
     __syncthreads(); // hole extents (memory-side atomics), SBf and the hole bits are complete
     const int n_outer_slots = min(c_slots, slot_cap);
-    for (int i = threadIdx.x; i < n_outer_slots; i += FRAME_THREADS) re[i] = make_int2(0x7fffffff, -1);
+    if (!fgk) for (int i = threadIdx.x; i < n_outer_slots; i += FRAME_THREADS) re[i] = make_int2(0x7fffffff, -1);
     FRAME_PROF(); // 4: outer keys
     // ---- rsa[i] = (row-extent slot of candidate run i in its component's key, that component): one load
     // per edge stretch later instead of a chain through Lf / SBf / ROWf
     int2 *RSA = rsa + (size_t)g * FRAME_RUNCAP;
+    if (!fgk)
     for (int i0 = threadIdx.x; i0 < nrunf; i0 += 4 * FRAME_THREADS) {
         int A[4], r[4], sbA[4], rA[4];
 #pragma unroll
@@ -639,10 +757,11 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
     // were 40 % of this kernel.  The label table only uses its first nrun entries, so when the frame's slots fit into the rest
     // of it (they do on sky frames: a few thousand slots, 8 bytes each) the updates go to LDS and are copied out once at the end.
     const int n_slots = min(c_slots, slot_cap);
-    int *SL = L + ((nrun + 1) & ~1);                       // (x, y) pairs; 8-byte aligned
-    const bool lds_slots = 2 * n_slots <= lds_n - ((nrun + 1) & ~1) && c_ovf == 0;
+    const int sl0 = fgk ? n_outer_slots : 0;               // first slot this kernel updates (the outer borders' are done)
+    int *SL = L + ((nrun + 1) & ~1);                       // (x, y) pairs of slots sl0 .. n_slots - 1; 8-byte aligned
+    const bool lds_slots = 2 * (n_slots - sl0) <= lds_n - ((nrun + 1) & ~1) && c_ovf == 0;
     if (lds_slots) {
-        for (int i = threadIdx.x; i < n_slots; i += FRAME_THREADS) { SL[2 * i] = 0x7fffffff; SL[2 * i + 1] = -1; }
+        for (int i = threadIdx.x; i < n_slots - sl0; i += FRAME_THREADS) { SL[2 * i] = 0x7fffffff; SL[2 * i + 1] = -1; }
     } else
         for (int i = n_outer_slots + threadIdx.x; i < n_slots; i += FRAME_THREADS) re[i] = make_int2(0x7fffffff, -1);
     __syncthreads(); // every slot is initialised before the first update
@@ -658,7 +777,8 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
     auto acc_flush = [&](SlotAcc &a) {
         if (a.slot >= 0 && !(dbg & 4)) {
             if (lds_slots) {
-                if ((unsigned)a.slot < (unsigned)n_slots) { atomicMin(&SL[2 * a.slot], a.lo); atomicMax(&SL[2 * a.slot + 1], a.hi); }
+                const int k = a.slot - sl0;
+                if ((unsigned)k < (unsigned)(n_slots - sl0)) { atomicMin(&SL[2 * k], a.lo); atomicMax(&SL[2 * k + 1], a.hi); }
             } else slot_update(re, a.slot, a.lo, a.hi);
         }
         a.slot = -1;
@@ -672,9 +792,11 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
         acc_flush(a);
         a.slot = slot; a.lo = xa; a.hi = xb;
     };
-    auto hole_update = [&](SlotAcc &acc, int bid, int A, int y, int xa, int xb) {
+    // A: the edge stretch's component, or -2 = not looked up yet (fgk: Lf[fid], fetched only when a hole is in reach)
+    auto hole_update = [&](SlotAcc &acc, int bid, int &A, int fid, int y, int xa, int xb) {
         if (dbg & 2) return;
         if (!((HL[bid >> 5] >> (bid & 31)) & 1u)) return; // a run of the outside
+        if (A == -2) A = Lfg[fid];
         int B = L[bid];
         unsigned hs = ((unsigned)B * 2654435761u) >> 22;
         for (int probe = 0; probe < 16; probe++, hs = (hs + 1) & (FRAME_HOLECAP - 1)) {
@@ -736,15 +858,18 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
                 int xs = (q << 6) + b, xe = xs + len - 1;
                 int fid = k.id0 + __popcll(sc & upto_bit(b)) - 1; // a stretch continuing from the previous word: id0 - 1
                 if (fid < 0 || fid >= nrunf) continue;
-                int2 ra = (dbg & 1) ? make_int2(fid & 1023, 0) : RSA[fid];
-                const int slot = ra.x, A = ra.y;
-                if (slot >= 0) acc_add(outer, slot, xs, xe);
+                int A = -2;
+                if (!fgk) {
+                    int2 ra = (dbg & 1) ? make_int2(fid & 1023, 0) : RSA[fid];
+                    A = ra.y;
+                    if (ra.x >= 0) acc_add(outer, ra.x, xs, xe);
+                }
                 // same-row neighbours: the 0-pixel before the run and the one after it
                 bool starts = (se >> b) & 1ull;
                 bool ends = (b + len < 64) || q + 1 >= wq || !(k.en & 1ull);
-                if (starts && xs > 0) hole_update(hole, b ? k.sbc + __popcll(s0 & upto_bit(b - 1)) - 1 : k.sbc - 1, A, y, xs, xs);
+                if (starts && xs > 0) hole_update(hole, b ? k.sbc + __popcll(s0 & upto_bit(b - 1)) - 1 : k.sbc - 1, A, fid, y, xs, xs);
                 if (ends && xe < w - 1)
-                    hole_update(hole, (b + len < 64) ? k.sbc + __popcll(s0 & upto_bit(b + len)) - 1 : k.sbc + __popcll(s0), A, y, xe, xe);
+                    hole_update(hole, (b + len < 64) ? k.sbc + __popcll(s0 & upto_bit(b + len)) - 1 : k.sbc + __popcll(s0), A, fid, y, xe, xe);
                 // rows above and below: 0-runs overlapping [xs, xe]
                 for (int dy = -1; dy <= 1; dy += 2) {
                     int yy = y + dy;
@@ -758,7 +883,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
                         int bx = __ffsll((long long)ov) - 1;
                         u64 inv2 = ~(ov >> bx);
                         int l2 = inv2 ? (__ffsll((long long)inv2) - 1) : (64 - bx);
-                        hole_update(hole, sbo + __popcll(s0o & upto_bit(bx)) - 1, A, y, (q << 6) + bx, (q << 6) + bx + l2 - 1);
+                        hole_update(hole, sbo + __popcll(s0o & upto_bit(bx)) - 1, A, fid, y, (q << 6) + bx, (q << 6) + bx + l2 - 1);
                         ov &= ~((l2 >= 64 ? ~0ull : ((1ull << l2) - 1)) << bx);
                     }
                 }
@@ -768,7 +893,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
         });
     __syncthreads();
     if (lds_slots)
-        for (int i = threadIdx.x; i < n_slots; i += FRAME_THREADS) re[i] = make_int2(SL[2 * i], SL[2 * i + 1]);
+        for (int i = threadIdx.x; i < n_slots - sl0; i += FRAME_THREADS) re[sl0 + i] = make_int2(SL[2 * i], SL[2 * i + 1]);
     FRAME_PROF(); // 7: extremes
     if (threadIdx.x == 0) {
         int *cnt = counters + g * C_COUNT;

@@ -96,13 +96,15 @@ struct lfdmi_ctx {
     int dual_state = 0;                // 0: none; 1: the next run_front is a bright pass that also feeds the dim pass; 2: dim pass already fed
     uint4 *recA = nullptr, *recB = nullptr; // item records of the candidate-word list (k_ccl.h: scan_write_records), rec_cap per slot
     int rec_cap = 0;
-    bool use_rec = true;               // LFDMI_FRAME_REC=0: the per-frame kernels gather their words themselves
+    bool use_rec = false;              // LFDMI_FRAME_REC=1: the scan kernel leaves item records for k_frame_fg (measured: -0.03 ms in k_frame_fg, +0.08 ms in the scans)
     int2 *rsa = nullptr;               // k_frame_contours: (row slot, component) per candidate run, FRAME_RUNCAP per slot
     long long *prof = nullptr;         // LFDMI_FRAME_PROFILE=1: per-frame phase clocks of k_frame_contours (developer tool)
     u64 *cellbm = nullptr;             // cell occupancy of the last prep output, bm_bands x CELLBM_WORDS words per slot
     int bm_bands = 0;
     bool use_cellbm = true;
     int4 *segcnt = nullptr;            // per 64-word segment: run starts, fg / bg list entries (then their exclusive sums)
+    int *fg_keys = nullptr;            // per slot: k_frame_fg made the outer-border keys and their extremes (k_frame.h)
+    bool fg_keys_on = true;            // LFDMI_FG_KEYS=0: k_frame_contours makes every key itself, as before round 4
     int *fb_fg = nullptr, *fb_bg = nullptr; // per slot: frame left to the multi-workgroup run kernels (k_frame.h)
     int *perm = nullptr;               // k_active_perm: the current pass's active slots first (XCD balance of the per-frame launches)
     const int *perm_cur = nullptr;     // perm while a pass with an `active` mask runs, nullptr otherwise
@@ -414,6 +416,9 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_RS_FILL_AT")) ctx->rs_fill_at = atoi(e);
     if (const char *e = getenv("LFDMI_PERM")) ctx->use_perm = atoi(e) != 0;
     RET(dmalloc(ctx, &ctx->fb_fg, G));
+    RET(dmalloc(ctx, &ctx->fg_keys, G));
+    HIPCHK(hipMemsetAsync(ctx->fg_keys, 0, G * sizeof(int), ctx->stream));
+    if (const char *e = getenv("LFDMI_FG_KEYS")) ctx->fg_keys_on = atoi(e) != 0;
     RET(dmalloc(ctx, &ctx->fb_bg, G));
     RET(dmalloc(ctx, &ctx->scanf_, G * BW));
     RET(dmalloc(ctx, &ctx->scanb_, G * BW));
@@ -799,8 +804,9 @@ static int run_scan(lfdmi_ctx *ctx, const u64 *bits, int val, int *scan, int cid
 }
 
 // 8-connected labels of the surviving components in ctx->Lf
+// want_keys: the contour stage follows (run_rects): k_frame_fg also makes the outer-border keys and their row extremes
 static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, double low_d, double high_d, const int *active,
-                     bool nms_done = false) {
+                     bool nms_done = false, bool want_keys = false) {
     if (low_d > high_d) { double t = low_d; low_d = high_d; high_d = t; }
     int low = (int)floor(low_d), high = (int)floor(high_d);
     if (!nms_done) {
@@ -818,11 +824,18 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
     RET(rs_fill_point(ctx, 3 + 10 * ctx->cur_pass));
     if (ctx->frame_ccl) { // frames that fit the LDS tables; the rest (fallback flag) take the kernels below
         Span sp(ctx, KID_FRAME_FG);
+        // labels + two bit sets, and (want_keys) as much again for the last-row table / the row slots of the outer borders:
+        // everything the CU has when the label table is at its full size
+        const bool keys = want_keys && ctx->fg_keys_on;
         size_t lds = (size_t)(ctx->frame_lds + 2 * (ctx->frame_lds / 32)) * sizeof(int);
+        if (keys) lds = std::min<size_t>(2 * lds, 160 * 1024 - 512);
+        if (!keys) HIPCHK(hipMemsetAsync(ctx->fg_keys, 0, (size_t)nc * sizeof(int), ctx->stream));
         k_frame_fg<<<nc, FRAME_THREADS, lds, ctx->stream>>>(ctx->candb, ctx->strongb, ctx->scanf_, ctx->wl_fg, ctx->counters, ctx->Lf,
                                                             ctx->YMf, ctx->FLf, ctx->ROWf, ctx->edgeb, h, w, rc, ctx->frame_runcap, active, ctx->fb_fg,
-                                                            ctx->pass_flags, ctx->frame_lds, active ? ctx->perm_cur : nullptr, ctx->dc_profile ? nullptr : ctx->prof,
-                                                            ctx->use_rec ? ctx->recA : nullptr, ctx->recB, ctx->rec_cap);
+                                                            ctx->pass_flags, (int)(lds / sizeof(int)), active ? ctx->perm_cur : nullptr, ctx->dc_profile ? nullptr : ctx->prof,
+                                                            ctx->use_rec ? ctx->recA : nullptr, ctx->recB, ctx->rec_cap,
+                                                            keys ? ctx->keys : nullptr, ctx->bigkeys, ctx->medkeys, ctx->rowext, ctx->key_cap, ctx->slot_cap,
+                                                            keys ? ctx->fg_keys : nullptr);
         KCHK("k_frame_fg");
         if (!ctx->general_on) return 0; // (a frame that did not fit raises PASS_FLAG_GENERAL: the caller runs the chunk again)
         active = ctx->fb_fg;
@@ -985,7 +998,7 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
         k_frame_contours<<<nc, FRAME_THREADS, lds, ctx->stream>>>(rt, ctx->wl_fg, ctx->wl_bg, ctx->counters, ctx->keys, ctx->bigkeys,
                                                                   ctx->medkeys, ctx->rowext, ctx->rsa, h, w, ctx->key_cap, ctx->slot_cap,
                                                                   ctx->frame_runcap, active, ctx->fb_bg, ctx->pass_flags, ctx->dc_profile ? nullptr : ctx->prof,
-                                                                  ctx->frame_lds, active ? ctx->perm_cur : nullptr, ctx->frame_dbg);
+                                                                  ctx->frame_lds, active ? ctx->perm_cur : nullptr, ctx->frame_dbg, ctx->fg_keys);
         KCHK("k_frame_contours");
         gen = ctx->fb_bg;
     }
@@ -1370,15 +1383,15 @@ static int run_front(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, 
         RET(run_morph(ctx, dil_src, ctx->equ, ctx->equb, ctx->lut, p->dilateKernel, p->dilate_kh, p->dilate_kw, 0, nc, h, w, active));
         RET(ensure_scratch(ctx, (size_t)ctx->G * ctx->N));
         RET(run_gauss(ctx, ctx->equ, (uint8_t *)ctx->scratch, nc, h, w, p->gaussKernel, p->gaussSigma, active));
-        RET(run_canny(ctx, (const uint8_t *)ctx->scratch, nc, h, w, 0, 255, active));
+        RET(run_canny(ctx, (const uint8_t *)ctx->scratch, nc, h, w, 0, 255, active, false, true));
     } else if (can_fuse_dilate_canny(p->dilateKernel, p->dilate_kh, p->dilate_kw, w)) {
         // the prep kernel of this pass left the cell occupancy of its output (a superset of the eroded image's)
         RET(run_dilate_canny(ctx, dil_src, nc, h, w, ctx->lut, p->dilate_kh, p->dilate_kw, active, ctx->use_cellbm ? bm : nullptr));
         RET(rs_fill_point(ctx, 2 + 10 * ctx->cur_pass));
-        RET(run_canny(ctx, ctx->equ, nc, h, w, 0, 255, active, true));
+        RET(run_canny(ctx, ctx->equ, nc, h, w, 0, 255, active, true, true));
     } else {
         RET(run_morph(ctx, dil_src, ctx->equ, ctx->equb, ctx->lut, p->dilateKernel, p->dilate_kh, p->dilate_kw, 0, nc, h, w, active));
-        RET(run_canny(ctx, ctx->equ, nc, h, w, 0, 255, active));
+        RET(run_canny(ctx, ctx->equ, nc, h, w, 0, 255, active, false, true));
     }
     return run_rects(ctx, nc, h, w, p->contoursMode, p->contoursMethod, p->minAreaRectMinLen, p->lwTresh, active);
 }
@@ -1540,7 +1553,7 @@ extern "C" int lfdmi_fit_min_area_rect(lfdmi_ctx *ctx, const uint8_t *img, int n
         const void *d;
         RET(in_ptr(ctx, img, (size_t)c0 * N, (size_t)nc * N, loc, &d));
         RET(zero_counters(ctx, nc));
-        RET(run_canny(ctx, (const uint8_t *)d, nc, h, w, 0, 255, nullptr));
+        RET(run_canny(ctx, (const uint8_t *)d, nc, h, w, 0, 255, nullptr, false, true));
         RET(run_rects(ctx, nc, h, w, contoursMode, contoursMethod, minAreaRectMinLen, lwTresh, nullptr));
         if (box_img) {
             RET(expand_bits(ctx, ctx->boxb, ctx->tmp, nc, h, w));

@@ -11,7 +11,7 @@ frames = np.stack([synth.make_frame(k, with_catalog=False)[0] for k in range(32)
 frames = np.concatenate([frames] * 8)
 ctx = Nv.Context(0, 1489, 2048, n)
 ctx._lib.lfdmi_debug_frame_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-fgnames = ["merge", "flatten+strong", "edge bits", "write-out"]
+fgnames = ["merge", "flatten+strong", "outer keys | edge bits", "edge+extremes | write-out"]
 names = ["bg merge", "flatten", "hole extents", "write-out", "outer keys", "slot table", "hole keys", "extremes"]
 for label, fn in (("bright", lambda: ctx.process_bright(frames, pb, flip=True)),
                   ("dim", lambda: ctx.process_dim(frames, pd, flip=True, after_bright=True))):
