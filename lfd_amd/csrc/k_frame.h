@@ -97,23 +97,43 @@ __device__ __forceinline__ void lds_union(int *L, int a, int b) {
 // (Taking the items four at a time -- all of a block's loads issued back to back, the next block's list entries fetched
 // meanwhile -- measured 5-7 % SLOWER for both per-frame kernels: their phases are bound by the LDS label chains and the
 // memory-side atomics of the slot updates, not by the exposed HBM round trips, and the extra live registers cost more.)
+// Which list positions a thread walks: start, start + step, ... below limit.
+//   strided: thread t takes t, t + 1024, ... (every phase touches all rows of the frame at once);
+//   blocked: wave v takes a contiguous 1/16 of the (raster-ordered) list, 64 items per step: a wave works its band of rows
+//            top to bottom, so by the time a run is joined to the row above, that row's runs have mostly found their roots
+//            -- the union-find chains the merge phases chase stay short.
+struct ItemMap { int start, step, limit; };
+__device__ __forceinline__ ItemMap item_map(int nwork, int blocked) {
+    ItemMap m;
+    if (blocked) {
+        const int per = ((nwork + FRAME_THREADS - 1) / FRAME_THREADS) * 64, wv = threadIdx.x >> 6;
+        m.start = wv * per + (threadIdx.x & 63); m.step = 64; m.limit = min(nwork, (wv + 1) * per);
+    } else { m.start = threadIdx.x; m.step = FRAME_THREADS; m.limit = nwork; }
+    return m;
+}
+
 template <class Item, class LoadF, class ProcF>
-__device__ __forceinline__ void frame_pipeline(const int *wl, int nwork, LoadF load, ProcF proc) {
-    int it = threadIdx.x;
-    int i1 = it < nwork ? wl[it] : -1;
-    int i2 = it + FRAME_THREADS < nwork ? wl[it + FRAME_THREADS] : -1;
+__device__ __forceinline__ void frame_pipeline(const int *wl, ItemMap m, int k0, LoadF load, ProcF proc) {
+    int it = m.start + k0 * m.step;
+    int i1 = it < m.limit ? wl[it] : -1;
+    int i2 = it + m.step < m.limit ? wl[it + m.step] : -1;
     Item cur;
     if (i1 >= 0) cur = load(i1);
     while (i1 >= 0) {
-        int i3 = it + 2 * FRAME_THREADS < nwork ? wl[it + 2 * FRAME_THREADS] : -1;
+        int i3 = it + 2 * m.step < m.limit ? wl[it + 2 * m.step] : -1;
         Item nxt;
         if (i2 >= 0) nxt = load(i2);
         proc(cur);
         cur = nxt;
         i1 = i2;
         i2 = i3;
-        it += FRAME_THREADS;
+        it += m.step;
     }
+}
+template <class Item, class LoadF, class ProcF>
+__device__ __forceinline__ void frame_pipeline(const int *wl, int nwork, LoadF load, ProcF proc) {
+    ItemMap m = {(int)threadIdx.x, FRAME_THREADS, nwork};
+    frame_pipeline<Item>(wl, m, 0, load, proc);
 }
 
 // The same over list POSITIONS, for phases that read the item records the scan kernels left (k_ccl.h: scan_write_records):
@@ -138,6 +158,15 @@ __device__ __forceinline__ void frame_pipeline_rec(int nwork, LoadA loadA, LoadB
 // bits 0 .. b
 __device__ __forceinline__ u64 upto_bit(int b) { return (b == 63) ? ~0ull : ((2ull << b) - 1ull); }
 
+typedef u64 u64x2a8 __attribute__((ext_vector_type(2), aligned(8))); // two neighbouring words of a bit row: one 16-byte load
+// base[i - 1], base[i] with one load (prev = `none` when the word has no left neighbour in its row)
+__device__ __forceinline__ void word_pair(const u64 *base, int i, bool with_prev, u64 none, u64 &prev, u64 &cur) {
+    if (with_prev) {
+        const u64x2a8 v = *(const u64x2a8 *)(base + i - 1);
+        prev = v.x; cur = v.y;
+    } else { prev = none; cur = base[i]; }
+}
+
 struct FgMergeItem { int idx, id0, idu; u64 c, cp, u, up, un; };
 struct FgWordItem { int idx, id0; u64 c, cp, m; };
 
@@ -148,7 +177,7 @@ __global__ void __launch_bounds__(FRAME_THREADS)
 k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_fg, int *counters, int *Lf, int *YMf,
            int *FLf, int *ROWf, u64 *edge, int h, int w, int run_cap, int lds_cap, const int *active, int *fallback,
            int *pass_flags, int lds_ints, const int *perm, long long *prof, const uint4 *recA, const uint4 *recB, int rec_cap,
-           int4 *keys, int *bigkeys, int *medkeys, int2 *rowext, int key_cap, int slot_cap, int *fg_keys) {
+           int4 *keys, int *bigkeys, int *medkeys, int2 *rowext, int key_cap, int slot_cap, int *fg_keys, int blocked) {
     // lds_ints: ints of dynamic LDS this launch allocated.  keys != nullptr: the contour stage follows (k_frame_contours): the
     // OUTER-border keys of the edge components, their row slots and the per-row extremes are made here, where the labels of the
     // candidate runs already sit in LDS (round 4; until then k_frame_contours re-read them from memory: three of its phases and
@@ -203,18 +232,21 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
     for (int i = threadIdx.x; i < (nrun + 31) / 32; i += FRAME_THREADS) { FL[i] = 0u; HB[i] = 0u; }
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) L[i] = i; // every run its own root
     __syncthreads();
+    constexpr int FG_KC = 8;
+    const ItemMap im = item_map(nwork, blocked);
+    const bool more = nwork > FG_KC * FRAME_THREADS; // (items beyond the register copies: gathered again in every phase)
+    u64 kc_c[FG_KC];
+    int kc_i[FG_KC], kc_x[FG_KC]; // id0 | (last pixel of the word to the left) << 31, idx
     // ---- row of every run; 8-connectivity between rows y and y-1
     auto merge_load = [&](int idx) {
             FgMergeItem t;
             int y = idx / wq, q = idx - y * wq;
             t.idx = idx;
-            t.c = fb[idx];
-            t.cp = q > 0 ? fb[idx - 1] : 0ull;
+            word_pair(fb, idx, q > 0, 0ull, t.cp, t.c);
             t.id0 = sf[idx];
             t.u = 0; t.up = 0; t.un = 0; t.idu = 0;
             if (y > 0) {
-                t.u = fb[idx - wq];
-                t.up = q > 0 ? fb[idx - wq - 1] : 0ull;
+                word_pair(fb, idx - wq, q > 0, 0ull, t.up, t.u);
                 t.un = q + 1 < wq ? fb[idx - wq + 1] : 0ull;
                 t.idu = sf[idx - wq];
             }
@@ -285,8 +317,28 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
             },
             [&](FgMergeItem &t) { if (t.idx >= wq) t.idu = sf[t.idx - wq]; },
             merge_proc);
-    else
-        frame_pipeline<FgMergeItem>(wl, nwork, merge_load, merge_proc);
+    else {
+        // the thread's first FG_KC items: processed one behind the loads; word, scan value and left-neighbour bit stay in
+        // registers for the two phases below (k_frame_contours does the same, see there)
+        FgMergeItem cur, nxt;
+        int pos = im.start;
+        if (pos < im.limit) cur = merge_load(wl[pos]);
+        int inext = pos + im.step < im.limit ? wl[pos + im.step] : -1;
+#pragma unroll
+        for (int k = 0; k < FG_KC; k++) {
+            kc_x[k] = -1; kc_c[k] = 0; kc_i[k] = 0;
+            if (pos < im.limit) {
+                const int i2 = (k + 1 < FG_KC && pos + 2 * im.step < im.limit) ? wl[pos + 2 * im.step] : -1;
+                if (k + 1 < FG_KC && inext >= 0) nxt = merge_load(inext);
+                merge_proc(cur);
+                kc_x[k] = cur.idx; kc_c[k] = cur.c; kc_i[k] = cur.id0 | (int)(((cur.cp >> 63) & 1ull) << 31);
+                cur = nxt;
+                inext = i2;
+            }
+            pos += im.step;
+        }
+        if (more) frame_pipeline<FgMergeItem>(wl, im, FG_KC, merge_load, merge_proc);
+    }
     __syncthreads();
     FG_PROF(); // 8: merge
     // ---- flatten; last row and strong flag per root
@@ -330,8 +382,20 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
                 atomicOr(&FL[root >> 5], 1u << (root & 31));
             }
     };
+    auto cached_item = [&](int k, u64 m) {
+        FgWordItem t;
+        t.idx = kc_x[k]; t.c = kc_c[k]; t.id0 = kc_i[k] & 0x7fffffff; t.cp = (u64)((unsigned)kc_i[k] >> 31) << 63; t.m = m;
+        return t;
+    };
     if (use_rec) frame_pipeline_rec<FgWordItem>(nwork, rec_word_item, [](FgWordItem &) {}, flat_proc);
-    else frame_pipeline<FgWordItem>(wl, nwork, flat_load, flat_proc);
+    else {
+        u64 mk[FG_KC]; // the strong bits of the thread's items: the only loads of this phase, all in flight together
+#pragma unroll
+        for (int k = 0; k < FG_KC; k++) mk[k] = kc_x[k] >= 0 ? mb[kc_x[k]] : 0ull;
+#pragma unroll
+        for (int k = 0; k < FG_KC; k++) if (kc_x[k] >= 0) flat_proc(cached_item(k, mk[k]));
+        if (more) frame_pipeline<FgWordItem>(wl, im, FG_KC, flat_load, flat_proc);
+    }
     __syncthreads();
     FG_PROF(); // 9: flatten + strong
     // ---- contour keys of the edge components (their outer borders), keys_path only
@@ -436,7 +500,11 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
     };
     if (keys_path) {
         if (use_rec) frame_pipeline_rec<FgWordItem>(nwork, rec_word_item, [](FgWordItem &) {}, edge_keys_proc);
-        else frame_pipeline<FgWordItem>(wl, nwork, edge_load, edge_keys_proc);
+        else {
+#pragma unroll
+            for (int k = 0; k < FG_KC; k++) if (kc_x[k] >= 0) edge_keys_proc(cached_item(k, 0ull));
+            if (more) frame_pipeline<FgWordItem>(wl, im, FG_KC, edge_load, edge_keys_proc);
+        }
         __syncthreads();
         if (lds_slots) for (int i = threadIdx.x; i < n_slots; i += FRAME_THREADS) re[i] = make_int2(SL[2 * i], SL[2 * i + 1]);
         if (threadIdx.x == 0) {
@@ -451,7 +519,11 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
         return;
     }
     if (use_rec) frame_pipeline_rec<FgWordItem>(nwork, rec_word_item, [](FgWordItem &) {}, edge_proc);
-    else frame_pipeline<FgWordItem>(wl, nwork, edge_load, edge_proc);
+    else {
+#pragma unroll
+        for (int k = 0; k < FG_KC; k++) if (kc_x[k] >= 0) edge_proc(cached_item(k, 0ull));
+        if (more) frame_pipeline<FgWordItem>(wl, im, FG_KC, edge_load, edge_proc);
+    }
     FG_PROF(); // 10: edge bits
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
         int root = L[i];
@@ -461,8 +533,8 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
     FG_PROF(); // 11: write-out
 }
 
-struct BgMergeItem { int idx, id0, idu, first, firstu; u64 c, cp, u, up, r0, u0; };
-struct BgWordItem { int idx, id0, lastid; u64 c, cp, rl; };
+struct BgMergeItem { int idx, id0, idu; u64 c, cp, u, up, pl; };
+struct BgWordItem { int idx, id0; u64 c, cp; };
 
 // position of the k-th (0-based) set bit of s
 __device__ __forceinline__ int hole_bit(u64 s, int k) {
@@ -542,119 +614,140 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) L[i] = i;
     __syncthreads();
     // ---- row of every run; 4-connectivity between rows y and y-1
-    frame_pipeline<BgMergeItem>(
-        wl, nwork,
-        [&](int idx) {
-            BgMergeItem t;
-            int y = idx / wq, q = idx - y * wq;
-            t.idx = idx;
-            t.c = fb[idx];
-            t.cp = q > 0 ? fb[idx - 1] : ~0ull;
-            t.id0 = sb[idx];
-            t.u = 0; t.up = 0; t.idu = 0; t.r0 = 0; t.u0 = 0; t.first = 0; t.firstu = 0;
-            if (y > 0) {
-                t.u = fb[idx - wq];
-                t.up = q > 0 ? fb[idx - wq - 1] : ~0ull;
-                t.idu = sb[idx - wq];
-                t.r0 = fb[idx - q];
-                t.u0 = fb[idx - q - wq];
-                t.first = sb[idx - q];
-                t.firstu = sb[idx - q - wq];
+    // A compute unit's gathers are what this kernel is short of (~1.5 clocks per lane and load instruction: round 4's
+    // attribution runs), so (1) a word and its left neighbour come as ONE 16-byte load, (2) the merge loads six words per
+    // item, not ten: "both runs start at column 0" can only hold for the contact at column 0 itself (a contact stretch that
+    // begins further right begins behind an edge pixel of one of the two rows, whose run therefore starts there), which needs
+    // no table, and (3) the thread keeps its items' word, scan value and left-neighbour bit in registers: the two phases
+    // after the merge walk the same items and load nothing (items beyond BG_KC per thread: crowded frames, gathered again).
+    constexpr int BG_KC = 10;
+    const ItemMap im = item_map(nwork, dbg & 16);
+    const bool more = nwork > BG_KC * FRAME_THREADS;
+    u64 kc_c[BG_KC];
+    int kc_i[BG_KC], kc_x[BG_KC]; // id0 | (pixel to the left is an edge pixel or the frame) << 31, idx
+    const int last_bit = (w - 1) & 63;
+    unsigned *CL = HR; // during merge + flatten: run reaches the last column of its row (HR is only needed after them)
+    auto merge_load = [&](int idx) {
+        BgMergeItem t;
+        int y = idx / wq, q = idx - y * wq;
+        t.idx = idx;
+        word_pair(fb, idx, q > 0, ~0ull, t.cp, t.c);
+        t.id0 = sb[idx];
+        t.u = 0; t.up = 0; t.idu = 0; t.pl = 0;
+        if (y > 0) {
+            word_pair(fb, idx - wq, q > 0, ~0ull, t.up, t.u);
+            t.idu = sb[idx - wq];
+            if (q == 0) t.pl = fb[idx - 1]; // last word of the row above
+        }
+        return t;
+    };
+    auto merge_proc = [&](const BgMergeItem &t) {
+        int y = t.idx / wq, q = t.idx - y * wq;
+        u64 vmask = valid_mask(q, w);
+        u64 z = ~t.c & vmask;                              // 0-pixels of this word
+        u64 s = z & ~((z << 1) | ((~t.cp) >> 63));         // 0-run starts (cp = all ones left of column 0)
+        for (int k = 0, n = __popcll(s); k < n; k++) {
+            ROWg[t.id0 + k] = y;
+            YMg[t.id0 + k] = y;
+        }
+        if (y == 0) return;
+        // the run before this row's first one is the last run of the row above: it touches the frame if that row ends in a 0
+        if (q == 0 && t.id0 > 0 && !((t.pl >> last_bit) & 1ull)) atomicOr(&CL[(t.id0 - 1) >> 5], 1u << ((t.id0 - 1) & 31));
+        u64 zu = ~t.u & vmask;
+        u64 su = zu & ~((zu << 1) | ((~t.up) >> 63));
+        u64 v = z & zu;
+        // first column of every stretch; a stretch continuing from the previous word (both rows 0
+        // at the last column of that word) was already joined there
+        u64 cont = q > 0 ? ((~t.cp & ~t.up) >> 63) : 0ull;
+        u64 st = v & ~((v << 1) | cont);
+        // two runs that both start at column 0 touch the frame: each is flagged "outside" on its own, joining them would
+        // only build a 1 489-link chain down the left image border
+        if (q == 0) st &= ~1ull;
+        while (st) {
+            int b = __ffsll((long long)st) - 1;
+            st &= st - 1;
+            int ia = t.id0 + __popcll(s & upto_bit(b)) - 1, ib = t.idu + __popcll(su & upto_bit(b)) - 1;
+            atomicOr(&HB[ib >> 5], 1u << (ib & 31));
+            if (!(dbg & 8)) lds_union(L, ia, ib);
+        }
+    };
+    {   // the thread's first BG_KC items: processed one behind the loads, kept for the next two phases
+        BgMergeItem cur, nxt;
+        int pos = im.start;
+        if (pos < im.limit) cur = merge_load(wl[pos]);
+        int inext = pos + im.step < im.limit ? wl[pos + im.step] : -1;
+#pragma unroll
+        for (int k = 0; k < BG_KC; k++) {
+            kc_x[k] = -1; kc_c[k] = 0; kc_i[k] = 0;
+            if (pos < im.limit) {
+                const int i2 = (k + 1 < BG_KC && pos + 2 * im.step < im.limit) ? wl[pos + 2 * im.step] : -1;
+                if (k + 1 < BG_KC && inext >= 0) nxt = merge_load(inext);
+                merge_proc(cur);
+                kc_x[k] = cur.idx; kc_c[k] = cur.c; kc_i[k] = cur.id0 | (int)(((cur.cp >> 63) & 1ull) << 31);
+                cur = nxt;
+                inext = i2;
             }
-            return t;
-        },
-        [&](const BgMergeItem &t) {
-            int y = t.idx / wq, q = t.idx - y * wq;
-            u64 vmask = valid_mask(q, w);
-            u64 z = ~t.c & vmask;                              // 0-pixels of this word
-            u64 s = z & ~((z << 1) | ((~t.cp) >> 63));         // 0-run starts (cp = all ones left of column 0)
-            for (int k = 0, n = __popcll(s); k < n; k++) {
-                ROWg[t.id0 + k] = y;
-                YMg[t.id0 + k] = y;
-            }
-            if (y == 0) return;
-            u64 zu = ~t.u & vmask;
-            u64 su = zu & ~((zu << 1) | ((~t.up) >> 63));
-            u64 v = z & zu;
-            // first column of every stretch; a stretch continuing from the previous word (both rows 0
-            // at the last column of that word) was already joined there
-            u64 cont = q > 0 ? ((~t.cp & ~t.up) >> 63) : 0ull;
-            u64 st = v & ~((v << 1) | cont);
-            while (st) {
-                int b = __ffsll((long long)st) - 1;
-                st &= st - 1;
-                int ia = t.id0 + __popcll(s & upto_bit(b)) - 1, ib = t.idu + __popcll(su & upto_bit(b)) - 1;
-                atomicOr(&HB[ib >> 5], 1u << (ib & 31));
-                // two runs that both start at column 0 touch the frame: each is flagged "outside" on its
-                // own, joining them would only build a 1 489-link chain down the left image border
-                bool a0 = (ia == t.first) && !(t.r0 & 1ull), b0 = (ib == t.firstu) && !(t.u0 & 1ull);
-                if (a0 && b0) continue;
-                if (!(dbg & 8)) lds_union(L, ia, ib);
-            }
-        });
+            pos += im.step;
+        }
+    }
+    if (more) frame_pipeline<BgMergeItem>(wl, im, BG_KC, merge_load, merge_proc);
     __syncthreads();
     FRAME_PROF(); // 0: background merge
     // ---- flatten; outside flag per root
-    frame_pipeline<BgWordItem>(
-        wl, nwork,
-        [&](int idx) {
-            BgWordItem t;
-            int y = idx / wq, q = idx - y * wq;
-            t.idx = idx;
-            t.c = fb[idx];
-            t.cp = q > 0 ? fb[idx - 1] : ~0ull;
-            t.id0 = sb[idx];
-            t.rl = fb[idx - q + wq - 1];
-            t.lastid = (y + 1 < h) ? sb[idx - q + wq] - 1 : nrun - 1;
-            return t;
-        },
-        [&](const BgWordItem &t) {
-            int y = t.idx / wq, q = t.idx - y * wq;
-            u64 z = ~t.c & valid_mask(q, w);
-            u64 s = z & ~((z << 1) | ((~t.cp) >> 63));
-            bool last0 = !((t.rl >> ((w - 1) & 63)) & 1ull); // the row's last pixel is background
-            int id = t.id0;
-            for (; s; id++) {
-                int b = __ffsll((long long)s) - 1;
-                s &= s - 1;
-                int root = lds_find(L, id);
-                if (root != id) L[id] = root;
-                // touches the frame: first / last row, starts at column 0, or is the row's last run and
-                // that reaches the last column
-                bool flag = (y == 0) || (y == h - 1) || ((q << 6) + b == 0) || (id == t.lastid && last0);
-                if (flag && !((FL[root >> 5] >> (root & 31)) & 1u)) atomicOr(&FL[root >> 5], 1u << (root & 31));
-            }
-        });
+    auto word_load = [&](int idx) { // (items beyond the register copies)
+        BgWordItem t;
+        int q = idx % wq;
+        t.idx = idx;
+        word_pair(fb, idx, q > 0, ~0ull, t.cp, t.c);
+        t.id0 = sb[idx];
+        return t;
+    };
+    auto cached_item = [&](int k) {
+        BgWordItem t;
+        t.idx = kc_x[k]; t.c = kc_c[k]; t.id0 = kc_i[k] & 0x7fffffff; t.cp = (u64)((unsigned)kc_i[k] >> 31) << 63;
+        return t;
+    };
+    auto flat_proc = [&](const BgWordItem &t) {
+        int y = t.idx / wq, q = t.idx - y * wq;
+        u64 z = ~t.c & valid_mask(q, w);
+        u64 s = z & ~((z << 1) | ((~t.cp) >> 63));
+        int id = t.id0;
+        for (; s; id++) {
+            int b = __ffsll((long long)s) - 1;
+            s &= s - 1;
+            int root = lds_find(L, id);
+            if (root != id) L[id] = root;
+            // touches the frame: first / last row, starts at column 0, or reaches the last column (CL, set during the merge)
+            bool flag = (y == 0) || (y == h - 1) || ((q << 6) + b == 0) || ((CL[id >> 5] >> (id & 31)) & 1u);
+            if (flag && !((FL[root >> 5] >> (root & 31)) & 1u)) atomicOr(&FL[root >> 5], 1u << (root & 31));
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < BG_KC; k++) if (kc_x[k] >= 0) flat_proc(cached_item(k));
+    if (more) frame_pipeline<BgWordItem>(wl, im, BG_KC, word_load, flat_proc);
+    __syncthreads();
+    for (int i = threadIdx.x; i < (nrun + 31) / 32; i += FRAME_THREADS) HR[i] = 0u; // (CL is done: the space is HR's from here on)
     __syncthreads();
     FRAME_PROF(); // 1: flatten
     // ---- last row of every hole; which runs belong to a hole, which are a hole's root
-    frame_pipeline<BgWordItem>(
-        wl, nwork,
-        [&](int idx) {
-            BgWordItem t;
-            int q = idx % wq;
-            t.idx = idx;
-            t.c = fb[idx];
-            t.cp = q > 0 ? fb[idx - 1] : ~0ull;
-            t.id0 = sb[idx];
-            t.rl = 0; t.lastid = 0;
-            return t;
-        },
-        [&](const BgWordItem &t) {
-            int y = t.idx / wq, q = t.idx - y * wq;
-            u64 z = ~t.c & valid_mask(q, w);
-            u64 s = z & ~((z << 1) | ((~t.cp) >> 63));
-            int n = __popcll(s);
-            for (int k = 0; k < n; k++) {
-                int id = t.id0 + k, root = L[id];
-                if ((FL[root >> 5] >> (root & 31)) & 1u) continue; // outside
-                atomicOr(&HL[id >> 5], 1u << (id & 31));
-                if (root == id) {
-                    atomicOr(&HR[id >> 5], 1u << (id & 31));
-                    XSg[id] = (q << 6) + hole_bit(s, k); // column of the hole's raster-first pixel
-                } else if (!((HB[id >> 5] >> (id & 31)) & 1u)) atomicMax(&YMg[root], y);
-            }
-        });
+    auto hole_proc = [&](const BgWordItem &t) {
+        int y = t.idx / wq, q = t.idx - y * wq;
+        u64 z = ~t.c & valid_mask(q, w);
+        u64 s = z & ~((z << 1) | ((~t.cp) >> 63));
+        int n = __popcll(s);
+        for (int k = 0; k < n; k++) {
+            int id = t.id0 + k, root = L[id];
+            if ((FL[root >> 5] >> (root & 31)) & 1u) continue; // outside
+            atomicOr(&HL[id >> 5], 1u << (id & 31));
+            if (root == id) {
+                atomicOr(&HR[id >> 5], 1u << (id & 31));
+                XSg[id] = (q << 6) + hole_bit(s, k); // column of the hole's raster-first pixel
+            } else if (!((HB[id >> 5] >> (id & 31)) & 1u)) atomicMax(&YMg[root], y);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < BG_KC; k++) if (kc_x[k] >= 0) hole_proc(cached_item(k));
+    if (more) frame_pipeline<BgWordItem>(wl, im, BG_KC, word_load, hole_proc);
     if (prof) { __syncthreads(); FRAME_PROF(); } // 2: hole extents
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
         int root = L[i];
@@ -816,22 +909,18 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
             ExtItem k;
             int y = idx / wq, q = idx - y * wq;
             k.idx = idx;
-            k.e = fb[idx];
-            k.ep = q > 0 ? fb[idx - 1] : ~0ull; // "edge" left of column 0: no background run continues from there
+            word_pair(fb, idx, q > 0, ~0ull, k.ep, k.e); // "edge" left of column 0: no background run continues from there
             k.en = q + 1 < wq ? fb[idx + 1] : 0ull;
-            k.c = cb[idx];
-            k.cp = q > 0 ? cb[idx - 1] : 0ull;
+            word_pair(cb, idx, q > 0, 0ull, k.cp, k.c);
             k.id0 = sf[idx];
             k.sbc = sb[idx];
             k.u = ~0ull; k.up = ~0ull; k.sbu = 0; k.d = ~0ull; k.dp = ~0ull; k.sbd = 0;
             if (y > 0) {
-                k.u = fb[idx - wq];
-                if (q > 0) k.up = fb[idx - wq - 1];
+                word_pair(fb, idx - wq, q > 0, ~0ull, k.up, k.u);
                 k.sbu = sb[idx - wq];
             }
             if (y + 1 < h) {
-                k.d = fb[idx + wq];
-                if (q > 0) k.dp = fb[idx + wq - 1];
+                word_pair(fb, idx + wq, q > 0, ~0ull, k.dp, k.d);
                 k.sbd = sb[idx + wq];
             }
             return k;

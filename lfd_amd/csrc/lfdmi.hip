@@ -835,7 +835,7 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
                                                             ctx->pass_flags, (int)(lds / sizeof(int)), active ? ctx->perm_cur : nullptr, ctx->dc_profile ? nullptr : ctx->prof,
                                                             ctx->use_rec ? ctx->recA : nullptr, ctx->recB, ctx->rec_cap,
                                                             keys ? ctx->keys : nullptr, ctx->bigkeys, ctx->medkeys, ctx->rowext, ctx->key_cap, ctx->slot_cap,
-                                                            keys ? ctx->fg_keys : nullptr);
+                                                            keys ? ctx->fg_keys : nullptr, (ctx->frame_dbg & 16) ? 1 : 0);
         KCHK("k_frame_fg");
         if (!ctx->general_on) return 0; // (a frame that did not fit raises PASS_FLAG_GENERAL: the caller runs the chunk again)
         active = ctx->fb_fg;
