@@ -141,6 +141,20 @@ int lfdmi_ctx_create_sized(int device, int max_h, int max_w, int max_inflight, c
 /* device bytes the workspace holds; frames re-run through the worst-case workspace since creation */
 int64_t lfdmi_ctx_bytes(lfdmi_ctx *ctx);
 int64_t lfdmi_spill_count(lfdmi_ctx *ctx);
+/* What a context has had to do besides the fast path since it was created (out[0 .. n), n <= LFDMI_STAT_COUNT): none of
+ * these changes a result, all of them cost time, so a caller (bench.py prints them) can tell a slow run from a busy one. */
+enum {
+    LFDMI_STAT_SPILLED = 0,        /* frames run again alone in the worst-case workspace (= lfdmi_spill_count) */
+    LFDMI_STAT_SCAN_GIVEUPS = 1,   /* chunks in which the one-launch run scan gave up its look-back (GPU shared with other work);
+                                      each switches the context to the three-launch scan for a while and reruns that chunk */
+    LFDMI_STAT_GENERAL_RERUNS = 2, /* chunks run again because a frame needed the multi-workgroup run kernels while they were off */
+    LFDMI_STAT_GENERAL_CHUNKS = 3, /* chunks that ran with the multi-workgroup run kernels switched on */
+    LFDMI_STAT_CHUNKS = 4,         /* chunks processed by lfdmi_detect_batch / the per-pass entry points */
+    LFDMI_STAT_CAP_GROWTHS = 5,    /* times the per-frame tables were enlarged after frames overflowed them */
+    LFDMI_STAT_SCAN_FUSED_ON = 6,  /* 1 while the one-launch run scan is in use */
+    LFDMI_STAT_COUNT = 7
+};
+int lfdmi_get_stats(lfdmi_ctx *ctx, int64_t *out, int n);
 void lfdmi_ctx_destroy(lfdmi_ctx *ctx);
 const char *lfdmi_last_error(lfdmi_ctx *ctx);
 /* run on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own */
@@ -289,6 +303,14 @@ const char *lfdmi_timing_name(int slot);
 /* developer tool (LFDMI_FRAME_PROFILE=1 in the environment when the context is created): per-phase clocks
  * (8 x int64 per slot, 10 ns ticks) of the last per-frame contour kernel launch, slots 0 .. n-1 */
 int lfdmi_debug_frame_profile(lfdmi_ctx *ctx, int n, long long *dst);
+/* test entry point: the tail of a pass on line sets handed in from outside -- the device's check_theta (k_finalize;
+ * reference: lfd/detecttrails/processfield.py:36-150, zero fill :89-102) and the library's host-side dictify_hough
+ * (processfield.py:266-288), exactly as lfdmi_detect_batch runs them on its own Hough lines.  h1 / h2: [n][kmax][2] float32
+ * (rho, theta), n1 / n2: lines per set; out[i].rejected_by_theta = check_theta's True, out[i].found = which (1 / 2) when it
+ * returns None, with rho / theta / x1 .. y2 filled in.  tests/test_gpu_stages.py feeds it the reference-generated vectors of
+ * tests/golden/tail_fixtures.json. */
+int lfdmi_debug_tail(lfdmi_ctx *ctx, int n, int kmax, const float *h1, const int32_t *n1, const float *h2, const int32_t *n2,
+                     int navg, double dro, double thetaTresh, double lineSetTresh, int which, int h, int w, lfdmi_result *out);
 /* developer hook for tests of the error path: the NEXT lfdmi_detect_batch call on this context returns LFDMI_ERR_ARG at the
  * top of its chunk number `chunk` (0-based; a chunk is the feed's unit for host frames, max_inflight frames otherwise),
  * after the earlier chunks ran normally; -1 disarms.  The context stays usable. */

@@ -26,8 +26,8 @@ ERR_ARG, ERR_DTYPE, ERR_HIP, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_NOLINES = -1, -2
 
 # every symbol include/lfdmi.h declares (checked by the CPU test-suite)
 SYMBOLS = (
-    "lfdmi_version", "lfdmi_default_caps", "lfdmi_ctx_create", "lfdmi_ctx_create_sized", "lfdmi_ctx_bytes", "lfdmi_spill_count",
-    "lfdmi_ctx_destroy", "lfdmi_last_error", "lfdmi_set_stream", "lfdmi_process_multiscale", "lfdmi_debug_frame_profile", "lfdmi_debug_trig", "lfdmi_debug_fail_chunk",
+    "lfdmi_version", "lfdmi_default_caps", "lfdmi_ctx_create", "lfdmi_ctx_create_sized", "lfdmi_ctx_bytes", "lfdmi_spill_count", "lfdmi_get_stats",
+    "lfdmi_ctx_destroy", "lfdmi_last_error", "lfdmi_set_stream", "lfdmi_process_multiscale", "lfdmi_debug_frame_profile", "lfdmi_debug_tail", "lfdmi_debug_trig", "lfdmi_debug_fail_chunk",
     "lfdmi_max_inflight", "lfdmi_prep_u8", "lfdmi_equalize_hist", "lfdmi_dilate", "lfdmi_erode",
     "lfdmi_canny", "lfdmi_gaussian_blur", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
     "lfdmi_hough_dims", "lfdmi_remove_stars", "lfdmi_process_bright", "lfdmi_process_dim",
@@ -246,6 +246,14 @@ class Context:
     def set_stream(self, stream_handle):
         self._chk(self._lib.lfdmi_set_stream(self._h, C.c_void_p(stream_handle or 0)))
 
+    STAT_NAMES = ("spilled_frames", "scan_giveups", "general_reruns", "general_chunks", "chunks", "cap_growths", "scan_fused_on")
+
+    def stats(self):
+        """lfdmi_get_stats as a dict: what the context did besides the fast path (never changes a result, always costs time)."""
+        out = np.zeros(len(self.STAT_NAMES), np.int64)
+        self._chk(self._lib.lfdmi_get_stats(self._h, _ptr(out), len(out)))
+        return dict(zip(self.STAT_NAMES, (int(v) for v in out)))
+
     def debug_trig(self, y, x):
         """(angle_deg, cos/2, sin/2) float32 as the rectangle kernels compute them from atan2(y, x) (developer check)."""
         y = np.ascontiguousarray(y, np.float64)
@@ -253,6 +261,21 @@ class Context:
         n = y.size
         out = [np.zeros(n, np.float32) for _ in range(3)]
         self._chk(self._lib.lfdmi_debug_trig(self._h, n, _ptr(y), _ptr(x), *[_ptr(o) for o in out]))
+        return out
+
+    def debug_tail(self, h1, n1, h2, n2, navg, dro, thetaTresh, lineSetTresh, which, shape):
+        """The tail of a pass on line sets given from outside: the device's check_theta (k_finalize) and the library's host-side
+        dictify_hough, as detect_batch runs them.  h1 / h2: (n, kmax, 2) float32, n1 / n2: lines per set -> record array."""
+        h1 = np.ascontiguousarray(h1, np.float32)
+        h2 = np.ascontiguousarray(h2, np.float32)
+        n1 = np.ascontiguousarray(n1, np.int32)
+        n2 = np.ascontiguousarray(n2, np.int32)
+        n, kmax = h1.shape[0], h1.shape[1]
+        assert h2.shape == h1.shape and n1.shape == (n,) and n2.shape == (n,)
+        out = np.zeros(n, RESULT_DTYPE)
+        self._chk(self._lib.lfdmi_debug_tail(self._h, n, kmax, _ptr(h1), _ptr(n1), _ptr(h2), _ptr(n2), int(navg), C.c_double(dro),
+                                             C.c_double(thetaTresh), C.c_double(lineSetTresh), int(which), int(shape[0]), int(shape[1]),
+                                             _ptr(out)))
         return out
 
     def debug_fail_chunk(self, chunk):

@@ -99,6 +99,14 @@ class BatchDetector:
     def spill_count(self):
         return sum(c.spill_count() for c in self.ctxs)
 
+    def stats(self):
+        """Sum of every lane's ``Context.stats()``."""
+        out = {}
+        for c in self.ctxs:
+            for k, v in c.stats().items():
+                out[k] = out.get(k, 0) + v
+        return out
+
     def get_counters(self):
         """Work counters ([slots, 20] int32, see lfdmi_get_counters) the last pass left, all lanes."""
         return np.concatenate([c.get_counters() for c in self.ctxs])

@@ -534,7 +534,16 @@ __global__ void k_finalize(const float *lines, const int *counters, lfdmi_result
     r.detection = cnt[C_DETECT];
     r.rejected_by_theta = 0;
     r.n_lines_equ = r.n_lines_box = 0;
-    if (cnt[C_OVERFLOW]) r.status = LFDMI_ERR_CAPACITY;
+    if (cnt[C_OVERFLOW]) {
+        // a table was too small for this frame: the host enlarges the tables (or runs the frame alone in the worst-case
+        // workspace); what the frame asked for travels in the fields an overflowed record has no use for
+        r.status = LFDMI_ERR_CAPACITY;
+        r.x1 = max(cnt[C_NRUNF], cnt[C_NRUNB]);                       // runs
+        r.y1 = cnt[C_NKEYS];                                          // contour keys (clamped at the capacity)
+        r.x2 = cnt[C_NSLOTS];                                         // row slots
+        r.y2 = max(max(cnt[C_NPIX_EQU], cnt[C_NPIX_BOX]), max(cnt[C_NPIXB_EQU], cnt[C_NPIXB_BOX])); // Hough list entries
+        r.n_lines_equ = max(cnt[C_NPEAK_EQU], cnt[C_NPEAK_BOX]);      // accumulator peaks
+    }
     if (r.detection && r.status == 0) {
         int n1 = cnt[C_NPEAK_EQU], n2 = cnt[C_NPEAK_BOX];
         r.n_lines_equ = n1; r.n_lines_box = n2;

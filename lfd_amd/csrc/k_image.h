@@ -81,6 +81,98 @@ k_rs_fill(float *frames, int h, int w, int max_obj, const int *count, const int4
     }
 }
 
+// Crowded catalogues (thousands of objects per frame).  The kernels above cost (objects) x (something per object): fine for
+// the few hundred stars of a high-latitude field, but the sweep's fold looks at EVERY object in every eight-row workgroup
+// (objects x 187 per SDSS frame) and the fill writes every square whether or not another one has blotted the pixels already
+// (20 000 stars: ten times the frame's area).  k_rs_sort orders a frame's non-empty squares by their first row (counting
+// sort, one workgroup per frame) and leaves rowstart[r] = squares starting above row r; a square is at most `hmax` rows
+// high, so the squares that can touch rows [a, b) are the contiguous range rowstart[a - hmax] .. rowstart[b] of the sorted
+// list.  The fold walks that range only, and k_rs_fill_bands blots a band of rows through the same LDS bit plane: every
+// pixel is written once.  Used when a chunk's catalogue holds more than RS_SORT_MIN objects per frame (host: run_removestars).
+#define RS_SORT_MIN 1024
+#define RS_SORT_MAXH 8192
+__global__ void __launch_bounds__(1024)
+k_rs_sort(int h, int max_obj, const int *count, const int4 *boxes, int4 *sboxes, int *rowstart) {
+    const int f = blockIdx.x, n = min(count[f], max_obj);
+    __shared__ int cur[RS_SORT_MAXH + 1];
+    __shared__ int wsum[16];
+    const int4 *bx = boxes + (size_t)f * max_obj;
+    for (int r = threadIdx.x; r <= h; r += 1024) cur[r] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int4 b = bx[i];
+        if (b.y > b.x && b.w > b.z) atomicAdd(&cur[b.x], 1);
+    }
+    __syncthreads();
+    // exclusive scan of cur[0 .. h]: 8 consecutive rows per thread (h + 1 <= 8192), then across the workgroup
+    const int per = (h + 1 + 1023) / 1024, r0 = threadIdx.x * per, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int loc = 0;
+    for (int k = 0; k < per; k++) if (r0 + k <= h) loc += cur[r0 + k];
+    int inc = loc;
+    for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int base = inc - loc;
+    for (int k = 0; k < wv; k++) base += wsum[k];
+    for (int k = 0; k < per; k++)
+        if (r0 + k <= h) {
+            const int c = cur[r0 + k];
+            cur[r0 + k] = base;
+            rowstart[(size_t)f * (h + 1) + r0 + k] = base;
+            base += c;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int4 b = bx[i];
+        if (b.y > b.x && b.w > b.z) sboxes[(size_t)f * max_obj + atomicAdd(&cur[b.x], 1)] = b;
+    }
+}
+
+// marks the squares of sorted range [lo, hi) that cross source rows [sa, sb) in the bit plane `rsm` (rsw words per row; plane row
+// of source row sr: flip ? top - sr : sr - sa, with top = sb - 1)
+__device__ __forceinline__ void rs_mark(uint32_t *rsm, int rsw, const int4 *sb_, int lo, int hi, int sa, int sb, bool flip, int nthreads) {
+    for (int o = lo + threadIdx.x; o < hi; o += nthreads) {
+        const int4 bx = sb_[o]; // rows [x, y) x columns [z, w)
+        const int y0 = max(bx.x, sa), y1 = min(bx.y, sb);
+        if (y0 >= y1 || bx.w <= bx.z) continue;
+        const int wa = bx.z >> 5, wb = (bx.w - 1) >> 5;
+        for (int sr = y0; sr < y1; sr++) {
+            uint32_t *row = rsm + (flip ? sb - 1 - sr : sr - sa) * rsw;
+            for (int wq_ = wa; wq_ <= wb; wq_++) {
+                uint32_t m = 0xFFFFFFFFu;
+                if (wq_ == wa) m &= 0xFFFFFFFFu << (bx.z & 31);
+                if (wq_ == wb) m &= 0xFFFFFFFFu >> (31 - ((bx.w - 1) & 31));
+                atomicOr(&row[wq_], m);
+            }
+        }
+    }
+}
+
+#define RS_BAND_ROWS 8
+__global__ void __launch_bounds__(256)
+k_rs_fill_bands(float *frames, int h, int w, int max_obj, const int4 *sboxes, const int *rowstart, int hmax) { // w % 32 == 0, w <= RS_MAXW
+    const int f = blockIdx.y, ra = blockIdx.x * RS_BAND_ROWS, rb = min(ra + RS_BAND_ROWS, h);
+    __shared__ uint32_t rsm[RS_BAND_ROWS * (4096 / 32)];
+    const int rsw = w >> 5;
+    const int *rs_ = rowstart + (size_t)f * (h + 1);
+    const int lo = rs_[max(0, ra - hmax)], hi = rs_[rb];
+    if (lo >= hi) return; // (uniform: no square reaches this band)
+    for (int k = threadIdx.x; k < RS_BAND_ROWS * rsw; k += 256) rsm[k] = 0u;
+    __syncthreads();
+    rs_mark(rsm, rsw, sboxes + (size_t)f * max_obj, lo, hi, ra, rb, false, 256);
+    __syncthreads();
+    float *img = frames + (size_t)f * h * w;
+    const int groups = w >> 2; // four pixels per thread and step: a 16-byte store where all four are blotted
+    for (int k = threadIdx.x; k < (rb - ra) * groups; k += 256) {
+        const int r = k / groups, gq = k - r * groups;
+        const unsigned nib = (rsm[r * rsw + (gq >> 3)] >> (4 * (gq & 7))) & 0xFu;
+        if (!nib) continue;
+        float *p = img + (size_t)(ra + r) * w + 4 * gq;
+        if (nib == 0xFu) *(float4 *)p = make_float4(0.f, 0.f, 0.f, 0.f);
+        else for (int j = 0; j < 4; j++) if ((nib >> j) & 1u) p[j] = 0.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // prep: gray = saturate_u8(round_half_even(|mask(x)|)), rows optionally flipped, plus the
 // 256-bin histogram equalizeHist needs.  16 B per lane loads (4 x f32), packed 4 x u8 stores.
@@ -187,7 +279,8 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
             int prep_rows, // rows per workgroup: a divisor of CELLBM_ROWS (a workgroup's rows lie in one band)
             u64 *dbits = nullptr, int *hist2 = nullptr, float mf2 = 0.f, float af2 = 0.f, u64 *nzd = nullptr,
             int sky_fast = 0, // DELTA + MFPOS with fl(mf2 + af2) > 0.5 (host-checked): the all-sky shortcut below is exact
-            const int4 *rs_boxes = nullptr, const int *rs_count = nullptr, int rs_max_obj = 0) { // RS: w <= RS_MAXW, prep_rows <= RS_MAXROWS
+            const int4 *rs_boxes = nullptr, const int *rs_count = nullptr, int rs_max_obj = 0, // RS: w <= RS_MAXW, prep_rows <= RS_MAXROWS
+            const int *rs_rowstart = nullptr, int rs_hmax = 0) { // (crowded catalogues: rs_boxes sorted by first row, see k_rs_sort)
     int g = blockIdx.y;
     if (active && !active[g]) return;
     __shared__ int sh[DELTA ? 8 : 4][256];
@@ -200,6 +293,10 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
         const int ra = blockIdx.x * prep_rows, rb_ = min(ra + prep_rows, h); // this workgroup's output rows [ra, rb_)
         // ... which are the source rows [sa, sb) (k_rs_boxes' squares are in the frame's own orientation)
         const int sa = flip ? h - rb_ : ra, sb = flip ? h - ra : rb_;
+        if (rs_rowstart) {
+            const int *rs_ = rs_rowstart + (size_t)g * (h + 1);
+            rs_mark(rsm, rsw, rs_boxes + (size_t)g * rs_max_obj, rs_[max(0, sa - rs_hmax)], rs_[sb], sa, sb, flip != 0, 256);
+        } else {
         const int n_obj = min(rs_count[g], rs_max_obj);
         for (int o = threadIdx.x; o < n_obj; o += 256) {
             const int4 bx = rs_boxes[(size_t)g * rs_max_obj + o]; // rows [x, y) x columns [z, w)
@@ -216,6 +313,7 @@ k_prep_hist(const void *src, int dtype, int h, int w, int flip, int mode, double
                     atomicOr(&row[wq_], m);
                 }
             }
+        }
         }
     }
     __syncthreads();

@@ -135,6 +135,11 @@ struct lfdmi_ctx {
     bool worst = false;                // every table at its theoretical maximum (the spill workspace itself)
     lfdmi_ctx *spill = nullptr;
     long long n_spilled = 0;           // frames re-run through the spill workspace since creation
+    // lfdmi_get_stats: the other things that cost time without changing a result
+    long long n_scan_giveups = 0, n_general_reruns = 0, n_general_chunks = 0, n_chunks = 0, n_cap_growths = 0;
+    bool grow_on = true;               // LFDMI_GROW=0: overflowing frames always take the worst-case workspace, the tables never grow
+    bool scan_fused_cfg = true;        // the one-launch scan is wanted (scan_fused: ... and in use right now)
+    int scan_quiet = 0, scan_rearm = 64; // chunks since the look-back last gave up; chunks after which it is tried again (doubles per give-up)
     size_t bytes = 0;                  // device bytes of the workspace (dmalloc)
     double min_rho = 1.0;              // accumulators / peak lists sized for HoughLines rho >= min_rho
     void *scratch = nullptr;           // stand-alone HoughLines: sorted lines / untransposed accumulator
@@ -154,6 +159,12 @@ struct lfdmi_ctx {
     size_t feed_chunk_bytes = 800u << 20; // largest feed chunk (LFDMI_FEED_MB): 64 SDSS frames, 11 frames of 4096 x 4096
     std::vector<int> feed_cpus;        // CPUs local to the GPU (numa_cpus): feed / blot threads and the pinned buffers are bound to them
     int fail_chunk = -1;               // lfdmi_debug_fail_chunk: the next lfdmi_detect_batch call fails at the top of this chunk (tests)
+    int4 *rs_sboxes = nullptr;         // crowded catalogues: the squares sorted by first row + rowstart (k_rs_sort); rs_sorted: this chunk uses them
+    int *rs_rowstart = nullptr;
+    size_t rs_rowstart_cap = 0;
+    bool rs_sorted = false;
+    int rs_sort_min = RS_SORT_MIN;     // LFDMI_RS_SORT_MIN: catalogues with more objects per frame take the sorted path (tests: 0)
+    int rs_hmax = 0;
     int4 *rs_boxes = nullptr;          // remove_stars squares of the chunk (k_rs_boxes -> k_rs_fill, and the host's own blotting)
     size_t rs_boxes_cap = 0;
     void *stage = nullptr;
@@ -161,7 +172,7 @@ struct lfdmi_ctx {
     void *cat_dev = nullptr;
     size_t cat_bytes = 0;
     int key_cap = 0, slot_cap = 0;
-    size_t acc_cap = 0, peak_cap = 0, list_cap = 0;
+    size_t acc_cap = 0, peak_cap = 0, list_cap = 0, peak_worst = 0;
     // cached Hough tables: the last few (rho, theta, shape) combinations keep their device trig table, so a
     // multi-scale pass (rho = 20, 10, 5 on the same image) does not rebuild and re-upload tables per launch
     struct HoughTab {
@@ -363,6 +374,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     size_t peak_worst = next_pow2((size_t)na * nr);
     ctx->peak_cap = caps.peak_cap > 0 ? next_pow2((size_t)caps.peak_cap) : peak_worst;
     if (ctx->peak_cap > peak_worst) ctx->peak_cap = peak_worst;
+    ctx->peak_worst = peak_worst;
     ctx->worst = ctx->run_cap == wc.run_cap && ctx->key_cap == wc.key_cap && ctx->slot_cap == wc.slot_cap &&
                  ctx->list_cap == (size_t)wc.list_cap && ctx->peak_cap == peak_worst && ctx->min_rho <= 1.0;
     HIPCHK(hipSetDevice(device));
@@ -410,7 +422,11 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_VOTE_BALANCE")) ctx->vote_balance = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_RECTS_PREP")) ctx->rects_prep = atoi(e) != 0;
     if (const char *e = getenv("LFDMI_RS_FOLD")) ctx->rs_fold_on = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_RS_SORT_MIN")) ctx->rs_sort_min = atoi(e);
     if (const char *e = getenv("LFDMI_SCAN_FUSED")) ctx->scan_fused = atoi(e) != 0;
+    ctx->scan_fused_cfg = ctx->scan_fused;
+    if (const char *e = getenv("LFDMI_GROW")) ctx->grow_on = atoi(e) != 0;
+    if (const char *e = getenv("LFDMI_SCAN_REARM")) ctx->scan_rearm = std::max(1, atoi(e));
     if (const char *e = getenv("LFDMI_SCAN_SPIN")) ctx->scan_spin = std::max(0, atoi(e));
     if (const char *e = getenv("LFDMI_SCAN_EPOCH0")) ctx->scan_epoch = atoi(e) & ((1 << 22) - 1); // (tests: start next to the 22-bit wrap)
     if (const char *e = getenv("LFDMI_RS_FILL_AT")) ctx->rs_fill_at = atoi(e);
@@ -494,6 +510,118 @@ extern "C" int lfdmi_ctx_create_sized(int device, int max_h, int max_w, int max_
 }
 extern "C" int64_t lfdmi_ctx_bytes(lfdmi_ctx *ctx) { return ctx ? (int64_t)(ctx->bytes + (ctx->spill ? ctx->spill->bytes : 0)) : 0; }
 extern "C" int64_t lfdmi_spill_count(lfdmi_ctx *ctx) { return ctx ? ctx->n_spilled : 0; }
+extern "C" int lfdmi_get_stats(lfdmi_ctx *ctx, int64_t *out, int n) {
+    if (!ctx || !out || n < 0 || n > LFDMI_STAT_COUNT) return LFDMI_ERR_ARG;
+    const int64_t v[LFDMI_STAT_COUNT] = {ctx->n_spilled, ctx->n_scan_giveups, ctx->n_general_reruns, ctx->n_general_chunks, ctx->n_chunks,
+                                         ctx->n_cap_growths, ctx->scan_fused ? 1 : 0};
+    for (int i = 0; i < n; i++) out[i] = v[i];
+    return 0;
+}
+
+// The look-back of k_scan_fused gave up on a frame of this chunk (the GPU is shared with other work, see k_ccl.h): the context
+// goes back to three launches per scan and the chunk is run again -- cheaper than the worst-case rerun of every flagged frame.
+// The one-launch scan is tried again after scan_rearm quiet chunks (doubling with every give-up: a GPU that stays shared
+// settles on the three launches, one that was shared for a moment gets its fast scan back).
+static bool scan_gave_up(lfdmi_ctx *ctx, const int *flags, int nc) {
+    bool gave = false;
+    for (int i = 0; i < nc; i++) gave = gave || (flags[i] & PASS_FLAG_SCAN_GAVEUP);
+    if (!gave || !ctx->scan_fused) return false;
+    ctx->scan_fused = false;
+    ctx->n_scan_giveups++;
+    ctx->scan_quiet = 0;
+    ctx->scan_rearm = std::min(ctx->scan_rearm * 2, 1 << 16);
+    return true;
+}
+static void chunk_done(lfdmi_ctx *ctx) {
+    ctx->n_chunks++;
+    if (!ctx->scan_fused && ctx->scan_fused_cfg && ++ctx->scan_quiet >= ctx->scan_rearm) { ctx->scan_fused = true; ctx->scan_quiet = 0; }
+}
+
+// ---- growing the per-frame tables ----------------------------------------------------------------------------------------
+// The default capacities (lfdmi_default_caps) are ~10x what sky frames use; a crowded field, a noisy or saturated frame can
+// still overflow them.  Until round 4 every such frame was run again ALONE in the worst-case workspace (a whole pipeline of
+// launches for one frame: milliseconds instead of microseconds), every time.  Now the context enlarges the tables that were
+// asked for more than they hold (k_finalize leaves the frame's demands in its record) and runs the chunk again; the worst-case
+// workspace remains for what no growth can satisfy (memory, the theoretical maxima).  LFDMI_GROW=0 switches it off.
+template <typename T> static int regrow(lfdmi_ctx *ctx, T **p, size_t old_count, size_t new_count) {
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, new_count * sizeof(T)));
+    for (auto &a : ctx->allocs) if (a == (void *)*p) a = q;
+    (void)hipFree(*p);
+    ctx->bytes += (new_count - old_count) * sizeof(T);
+    *p = (T *)q;
+    return 0;
+}
+
+// true: tables were enlarged, run the chunk again
+static bool grow_caps(lfdmi_ctx *ctx, const lfdmi_result *rec, int nc, size_t rec_stride = 1, int n_scales = 1) {
+    if (!ctx->grow_on || ctx->worst) return false;
+    long long need_run = 0, need_key = 0, need_slot = 0, need_list = 0, need_peak = 0;
+    bool any = false;
+    for (int s = 0; s < n_scales; s++)
+        for (int i = 0; i < nc; i++) {
+            const lfdmi_result &r = rec[(size_t)s * rec_stride + i];
+            if (r.status != LFDMI_ERR_CAPACITY) continue;
+            any = true;
+            need_run = std::max<long long>(need_run, r.x1); need_key = std::max<long long>(need_key, r.y1);
+            need_slot = std::max<long long>(need_slot, r.x2); need_list = std::max<long long>(need_list, r.y2);
+            need_peak = std::max<long long>(need_peak, r.n_lines_equ);
+        }
+    if (!any) return false;
+    lfdmi_caps wc;
+    worst_caps(ctx->H, ctx->W, &wc);
+    const size_t peak_worst = ctx->peak_worst;
+    auto up = [](long long cap, long long need, long long worst, bool at_cap_means_more) -> long long {
+        if (need < cap || (need == cap && !at_cap_means_more)) return cap;
+        return std::min<long long>(worst, std::max<long long>(2 * cap, need + need / 4 + 64));
+    };
+    long long run = up(ctx->run_cap, need_run, wc.run_cap, false), key = up(ctx->key_cap, need_key, wc.key_cap, true);
+    long long slot = up(ctx->slot_cap, need_slot, wc.slot_cap, false), list = up((long long)ctx->list_cap, need_list, wc.list_cap, false);
+    long long peak = up((long long)ctx->peak_cap, need_peak, (long long)peak_worst, false);
+    if (peak > (long long)ctx->peak_cap) peak = (long long)std::min(peak_worst, next_pow2((size_t)peak));
+    // a frame that ran out of runs never reached its keys, slots and lists: those tables follow in proportion
+    if (run > ctx->run_cap) {
+        const double f = (double)run / ctx->run_cap;
+        key = std::max(key, std::min<long long>(wc.key_cap, (long long)(ctx->key_cap * f)));
+        slot = std::max(slot, std::min<long long>(wc.slot_cap, (long long)(ctx->slot_cap * f)));
+        list = std::max(list, std::min<long long>(wc.list_cap, (long long)(ctx->list_cap * f)));
+    }
+    if (run == ctx->run_cap && key == ctx->key_cap && slot == ctx->slot_cap && list == (long long)ctx->list_cap && peak == (long long)ctx->peak_cap)
+        return false; // (an overflow no table explains -- e.g. the look-back scan's flag: the worst-case workspace takes the frame)
+    const size_t G = (size_t)ctx->G;
+    const long long extra = (long long)G * ((run - ctx->run_cap) * 11 * 4 + (key - ctx->key_cap) * (16 + 4 + 4 + 32) + (slot - ctx->slot_cap) * 8 +
+                                            (list - (long long)ctx->list_cap) * 4 * 4 + (peak - (long long)ctx->peak_cap) * 2 * 8);
+    size_t mem_free = 0, mem_total = 0;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return false;
+    if (extra + (2ll << 30) > (long long)mem_free) return false; // (no room: the worst-case workspace, one frame at a time)
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+    (void)hipStreamSynchronize(ctx->side[0]); (void)hipStreamSynchronize(ctx->side[1]);
+    int rc = 0;
+    if (run > ctx->run_cap) {
+        for (int **p : {&ctx->Lf, &ctx->YMf, &ctx->FLf, &ctx->Lb, &ctx->YMb, &ctx->FLb, &ctx->SBf, &ctx->SBb, &ctx->PAb, &ctx->ROWf, &ctx->ROWb})
+            rc = rc ? rc : regrow(ctx, p, G * ctx->run_cap, G * (size_t)run);
+        if (!rc) ctx->run_cap = (int)run;
+    }
+    if (!rc && key > ctx->key_cap) {
+        rc = regrow(ctx, &ctx->keys, G * ctx->key_cap, G * (size_t)key);
+        rc = rc ? rc : regrow(ctx, &ctx->bigkeys, G * ctx->key_cap, G * (size_t)key);
+        rc = rc ? rc : regrow(ctx, &ctx->medkeys, G * ctx->key_cap, G * (size_t)key);
+        rc = rc ? rc : regrow(ctx, &ctx->quads, G * ctx->key_cap * 8, G * (size_t)key * 8);
+        if (!rc) ctx->key_cap = (int)key;
+    }
+    if (!rc && slot > ctx->slot_cap) { rc = regrow(ctx, &ctx->rowext, G * ctx->slot_cap, G * (size_t)slot); if (!rc) ctx->slot_cap = (int)slot; }
+    if (!rc && list > (long long)ctx->list_cap) {
+        rc = regrow(ctx, &ctx->pix_equ, G * 2 * ctx->list_cap, G * 2 * (size_t)list);
+        rc = rc ? rc : regrow(ctx, &ctx->pix_box, G * 2 * ctx->list_cap, G * 2 * (size_t)list);
+        if (!rc) ctx->list_cap = (size_t)list;
+    }
+    if (!rc && peak > (long long)ctx->peak_cap) { rc = regrow(ctx, &ctx->peaks, G * 2 * ctx->peak_cap, G * 2 * (size_t)peak); if (!rc) ctx->peak_cap = (size_t)peak; }
+    if (rc) return false; // (an allocation failed half way: the tables that did grow stay grown, the frame takes the worst-case workspace)
+    ctx->worst = ctx->run_cap == wc.run_cap && ctx->key_cap == wc.key_cap && ctx->slot_cap == wc.slot_cap && ctx->list_cap == (size_t)wc.list_cap &&
+                 ctx->peak_cap == peak_worst && ctx->min_rho <= 1.0;
+    ctx->n_cap_growths++;
+    return true;
+}
 
 // the worst-case single-frame workspace behind a compact context (nullptr: ctx is worst-case itself, or no memory)
 static lfdmi_ctx *get_spill(lfdmi_ctx *ctx) {
@@ -510,6 +638,7 @@ static lfdmi_ctx *get_spill(lfdmi_ctx *ctx) {
         }
         sp->timing = false;
         sp->scan_fused = false; // (one frame at a time, rarely: nothing to gain from the look-back scan)
+        sp->scan_fused_cfg = false;
         ctx->spill = sp;
     }
     return ctx->spill;
@@ -532,6 +661,8 @@ extern "C" void lfdmi_ctx_destroy(lfdmi_ctx *ctx) {
     if (ctx->feed_mid) hipEventDestroy(ctx->feed_mid);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->rs_boxes) hipFree(ctx->rs_boxes);
+    if (ctx->rs_sboxes) hipFree(ctx->rs_sboxes);
+    if (ctx->rs_rowstart) hipFree(ctx->rs_rowstart);
     if (ctx->cat_dev) hipFree(ctx->cat_dev);
     for (auto e : ctx->ev_pool) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -655,8 +786,12 @@ static int rs_fill_point(lfdmi_ctx *ctx, int k) {
     HIPCHK(hipStreamWaitEvent(sd, ctx->ev_rsfill, 0));
     {
         Span sp(ctx, KID_REMOVESTARS, 0, sd);
-        k_rs_fill<<<dim3((ctx->rs_max_obj + 3) / 4, ctx->rs_fill_nc), 256, 0, sd>>>(fr, ctx->rs_fill_h, ctx->rs_fill_w, ctx->rs_max_obj,
-                                                                                        ctx->rs_count_dev, ctx->rs_boxes);
+        if (ctx->rs_sorted)
+            k_rs_fill_bands<<<dim3((ctx->rs_fill_h + RS_BAND_ROWS - 1) / RS_BAND_ROWS, ctx->rs_fill_nc), 256, 0, sd>>>(
+                fr, ctx->rs_fill_h, ctx->rs_fill_w, ctx->rs_max_obj, ctx->rs_sboxes, ctx->rs_rowstart, ctx->rs_hmax);
+        else
+            k_rs_fill<<<dim3((ctx->rs_max_obj + 3) / 4, ctx->rs_fill_nc), 256, 0, sd>>>(fr, ctx->rs_fill_h, ctx->rs_fill_w, ctx->rs_max_obj,
+                                                                                            ctx->rs_count_dev, ctx->rs_boxes);
         KCHK("k_rs_fill");
     }
     HIPCHK(hipEventRecord(ctx->ev_rsfill, sd));
@@ -690,7 +825,8 @@ static int run_prep(lfdmi_ctx *ctx, const void *src, int dtype, int nc, int h, i
     k_prep_hist<1, true, P_, RS_><<<pgrid, 256, 0, ctx->stream>>>(src, dtype, h, w, flip, mode, minFlux, addFlux, ctx->gray, ctx->hist, \
                                                               ctx->cellbm, ctx->bm_bands, active, fullbits, prep_rows, ctx->dbits,    \
                                                               ctx->hist2, (float)delta_dim->minFlux, (float)delta_dim->addFlux, ctx->nzd, sky_fast, \
-                                                              ctx->rs_boxes, ctx->rs_count_dev, ctx->rs_max_obj)
+                                                              ctx->rs_sorted ? ctx->rs_sboxes : ctx->rs_boxes, ctx->rs_count_dev, ctx->rs_max_obj, \
+                                                              ctx->rs_sorted ? ctx->rs_rowstart : nullptr, ctx->rs_hmax)
             // (all-sky shortcut of the sweep: exact when the smallest kept value already rounds to 1, see k_prep_hist)
             const bool sky_on = ctx->sky_fast; // (developer switch LFDMI_SKY_FAST)
             const float mfa = (float)delta_dim->minFlux + (float)delta_dim->addFlux;
@@ -1518,17 +1654,21 @@ extern "C" int lfdmi_canny(lfdmi_ctx *ctx, const uint8_t *src, int n, int h, int
     RET(check_shape(ctx, n, h, w));
     if (!src || !dst) return fail(ctx, LFDMI_ERR_ARG, "NULL image");
     size_t N = (size_t)h * w;
-    std::vector<int> cnt((size_t)ctx->G * C_COUNT);
+    std::vector<int> cnt((size_t)ctx->G * C_COUNT), pflags((size_t)ctx->G);
     for (int c0 = 0; c0 < n; c0 += ctx->G) {
         int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
         const void *d;
         RET(in_ptr(ctx, src, (size_t)c0 * N, (size_t)nc * N, loc, &d));
         RET(zero_counters(ctx, nc));
+        HIPCHK(hipMemsetAsync(ctx->pass_flags, 0, (size_t)nc * sizeof(int), ctx->stream));
         RET(run_canny(ctx, (const uint8_t *)d, nc, h, w, low, high, nullptr));
         RET(expand_bits(ctx, ctx->edgeb, ctx->tmp, nc, h, w));
         RET(out_copy(ctx, dst, (size_t)c0 * N, ctx->tmp, (size_t)nc * N, loc));
         HIPCHK(hipMemcpyAsync(cnt.data(), ctx->counters, (size_t)nc * C_COUNT * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(pflags.data(), ctx->pass_flags, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         RET(sync(ctx, nc));
+        if (scan_gave_up(ctx, pflags.data(), nc)) { c0 -= ctx->G; continue; } // the look-back scan gave up: this chunk again, three launches per scan
+        chunk_done(ctx);
         for (int i = 0; i < nc; i++)
             if (cnt[(size_t)i * C_COUNT + C_OVERFLOW]) { // more runs than this workspace's tables hold: the worst-case one takes the image
                 lfdmi_ctx *sp = get_spill(ctx);
@@ -1547,12 +1687,13 @@ extern "C" int lfdmi_fit_min_area_rect(lfdmi_ctx *ctx, const uint8_t *img, int n
     RET(check_shape(ctx, n, h, w));
     if (!img) return fail(ctx, LFDMI_ERR_ARG, "NULL image");
     size_t N = (size_t)h * w;
-    std::vector<int> cnt((size_t)ctx->G * C_COUNT);
+    std::vector<int> cnt((size_t)ctx->G * C_COUNT), pflags((size_t)ctx->G);
     for (int c0 = 0; c0 < n; c0 += ctx->G) {
         int nc = n - c0 < ctx->G ? n - c0 : ctx->G;
         const void *d;
         RET(in_ptr(ctx, img, (size_t)c0 * N, (size_t)nc * N, loc, &d));
         RET(zero_counters(ctx, nc));
+        HIPCHK(hipMemsetAsync(ctx->pass_flags, 0, (size_t)nc * sizeof(int), ctx->stream));
         RET(run_canny(ctx, (const uint8_t *)d, nc, h, w, 0, 255, nullptr, false, true));
         RET(run_rects(ctx, nc, h, w, contoursMode, contoursMethod, minAreaRectMinLen, lwTresh, nullptr));
         if (box_img) {
@@ -1560,7 +1701,10 @@ extern "C" int lfdmi_fit_min_area_rect(lfdmi_ctx *ctx, const uint8_t *img, int n
             RET(out_copy(ctx, box_img, (size_t)c0 * N, ctx->tmp, (size_t)nc * N, loc));
         }
         HIPCHK(hipMemcpyAsync(cnt.data(), ctx->counters, (size_t)nc * C_COUNT * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(pflags.data(), ctx->pass_flags, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         RET(sync(ctx, nc));
+        if (scan_gave_up(ctx, pflags.data(), nc)) { c0 -= ctx->G; continue; } // (see lfdmi_canny)
+        chunk_done(ctx);
         for (int i = 0; i < nc; i++) {
             if (cnt[(size_t)i * C_COUNT + C_OVERFLOW]) { // a table of this workspace is too small for the image: the worst-case one takes it
                 lfdmi_ctx *sp = get_spill(ctx);
@@ -1710,8 +1854,22 @@ static int run_removestars(lfdmi_ctx *ctx, float *frames_dev, int f0, int nc, in
     size_t need = (size_t)nc * cat->max_obj;
     if (ctx->rs_boxes_cap < need) {
         if (ctx->rs_boxes) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(ctx->rs_boxes)); ctx->rs_boxes = nullptr; ctx->rs_boxes_cap = 0; }
+        if (ctx->rs_sboxes) { HIPCHK(hipFree(ctx->rs_sboxes)); ctx->rs_sboxes = nullptr; }
         HIPCHK(hipMalloc(&ctx->rs_boxes, need * sizeof(int4)));
         ctx->rs_boxes_cap = need;
+    }
+    // crowded catalogues: squares sorted by first row, so that the sweep's fold and the zero fill only look at the squares near
+    // their rows and every pixel is blotted once (k_image.h: k_rs_sort)
+    ctx->rs_sorted = cat->max_obj > ctx->rs_sort_min && h < RS_SORT_MAXH && (w % 32) == 0 && w <= RS_MAXW;
+    if (ctx->rs_sorted) {
+        if (!ctx->rs_sboxes) HIPCHK(hipMalloc(&ctx->rs_sboxes, ctx->rs_boxes_cap * sizeof(int4)));
+        const size_t nrs = (size_t)nc * (h + 1);
+        if (ctx->rs_rowstart_cap < nrs) {
+            if (ctx->rs_rowstart) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(ctx->rs_rowstart)); ctx->rs_rowstart = nullptr; }
+            HIPCHK(hipMalloc(&ctx->rs_rowstart, nrs * sizeof(int)));
+            ctx->rs_rowstart_cap = nrs;
+        }
+        ctx->rs_hmax = 2 * std::max(rs->maxxy, rs->defaultxy); // a square's side: 2 dxy, dxy <= maxxy or the default
     }
     int4 *boxes = ctx->rs_boxes;
     if (host_boxes) host_boxes->resize(need); // the blotted squares come back instead of the blotted frames
@@ -1722,8 +1880,16 @@ static int run_removestars(lfdmi_ctx *ctx, float *frames_dev, int f0, int nc, in
         KCHK("k_rs_boxes");
         ctx->rs_count_dev = dev.count;
         ctx->rs_max_obj = cat->max_obj;
+        if (ctx->rs_sorted) {
+            k_rs_sort<<<nc, 1024, 0, ctx->stream>>>(h, cat->max_obj, dev.count, boxes, ctx->rs_sboxes, ctx->rs_rowstart);
+            KCHK("k_rs_sort");
+        }
         if (fill) {
-            k_rs_fill<<<dim3((cat->max_obj + 3) / 4, nc), 256, 0, ctx->stream>>>(frames_dev, h, w, cat->max_obj, dev.count, boxes);
+            if (ctx->rs_sorted)
+                k_rs_fill_bands<<<dim3((h + RS_BAND_ROWS - 1) / RS_BAND_ROWS, nc), 256, 0, ctx->stream>>>(frames_dev, h, w, cat->max_obj, ctx->rs_sboxes,
+                                                                                                     ctx->rs_rowstart, ctx->rs_hmax);
+            else
+                k_rs_fill<<<dim3((cat->max_obj + 3) / 4, nc), 256, 0, ctx->stream>>>(frames_dev, h, w, cat->max_obj, dev.count, boxes);
             KCHK("k_rs_fill");
         }
     }
@@ -1786,6 +1952,7 @@ struct GeneralGuard {
         bool need = false;
         for (int i = 0; i < n; i++) need = need || (flags[i] & PASS_FLAG_GENERAL);
         if (c->general_on) {
+            c->n_general_chunks++;
             // the ~22 extra launches per pass are dropped again once GENERAL_QUIET_CHUNKS chunks in a row did without them
             if (need) c->quiet_chunks = 0;
             else if (c->frame_ccl && ++c->quiet_chunks >= GENERAL_QUIET_CHUNKS) { c->general_seen = false; c->quiet_chunks = 0; }
@@ -1795,6 +1962,7 @@ struct GeneralGuard {
         c->general_seen = true;
         c->general_on = true;
         c->quiet_chunks = 0;
+        c->n_general_reruns++;
         return true;
     }
 };
@@ -1834,6 +2002,7 @@ static int pass_api(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, in
         const void *d;
         RET(in_ptr(ctx, img, (size_t)c0 * N * es, (size_t)nc * N * es, loc, &d));
         GeneralGuard gg(ctx);
+        int grow_tries = 0;
         for (;;) { // (again, with the general run kernels, if a frame turned out to need them)
             for (int s = 0; s < n_scales; s++) {
                 k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev + s * G, ctx->pass_flags, nc);
@@ -1847,13 +2016,11 @@ static int pass_api(lfdmi_ctx *ctx, const void *img, int dtype, int n, int h, in
             HIPCHK(hipMemcpyAsync(hl.data(), ctx->lines, (size_t)nc * 2 * K * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipMemcpyAsync(flags.data(), ctx->pass_flags, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            {
-                bool gave = false;
-                for (int i = 0; i < nc; i++) gave = gave || (flags[i] & PASS_FLAG_SCAN_GAVEUP);
-                if (gave && ctx->scan_fused) { ctx->scan_fused = false; continue; } // (see lfdmi_detect_batch)
-            }
+            if (scan_gave_up(ctx, flags.data(), nc)) continue; // (see lfdmi_detect_batch)
+            if (grow_tries < 4 && grow_caps(ctx, host.data(), nc, G, n_scales)) { grow_tries++; continue; } // tables enlarged: once more
             if (!gg.again(flags.data(), nc)) break;
         }
+        chunk_done(ctx);
         {
             int na[2] = {nc, 0}, nd[2] = {0, 0};
             for (int i = 0; i < nc; i++) nd[0] += (flags[i] & (dim ? 4 : 1)) != 0;
@@ -2275,6 +2442,7 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
         }
         bool blotted = false;
         GeneralGuard gg(ctx);
+        int grow_tries = 0;
         for (;;) { // (again, with the general run kernels, if a frame turned out to need them)
         k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, ctx->pass_flags, nc);
         KCHK("k_init_results");
@@ -2304,12 +2472,12 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
         if (t0_ > 0) fprintf(stderr, "[feed] chunk %d (%d frames): passes synced after %.2f ms (t=%.2f)\n", kc, nc, feed_now() - t0_, feed_now()); }
         { // the look-back scan gave up on a frame (the GPU is shared with another process: see k_scan_fused): three launches from
           // now on, and this chunk once more (cheaper than the worst-case rerun of every frame that was flagged)
-            bool gave = false;
-            for (int i = 0; i < nc; i++) gave = gave || (flags[i] & PASS_FLAG_SCAN_GAVEUP);
-            if (gave && ctx->scan_fused) { ctx->scan_fused = false; continue; }
+            if (scan_gave_up(ctx, flags, nc)) continue;
         }
+        if (grow_tries < 4 && grow_caps(ctx, host, nc)) { grow_tries++; continue; } // tables enlarged for this chunk's frames: once more
         if (!gg.again(flags, nc)) break;
         }
+        chunk_done(ctx);
         {
             int na[2] = {nc, 0}, nd[2] = {0, 0};
             for (int i = 0; i < nc; i++) { nd[0] += flags[i] & 1; na[1] += (flags[i] >> 1) & 1; nd[1] += (flags[i] >> 2) & 1; }
@@ -2398,6 +2566,47 @@ extern "C" int lfdmi_debug_frame_profile(lfdmi_ctx *ctx, int n, long long *dst) 
     if (!ctx || !ctx->prof || n < 0 || n > ctx->G) return LFDMI_ERR_ARG;
     HIPCHK(hipMemcpyAsync(dst, ctx->prof, (size_t)n * 16 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// developer / test entry point: the tail of a pass on line sets handed in from outside -- k_finalize (the device's check_theta,
+// processfield.py:36-150, with the zero fill of processfield.py:89-102) and the host-side dictify_hough (processfield.py:266-288)
+// exactly as lfdmi_detect_batch runs them.  h1 / h2: [n][kmax][2] float32 (rho, theta), n1 / n2: lines per set (<= kmax);
+// out[i].rejected_by_theta = check_theta's True, .found = `which` when it returns None, then rho / theta / x1 .. y2.
+extern "C" int lfdmi_debug_tail(lfdmi_ctx *ctx, int n, int kmax, const float *h1, const int32_t *n1, const float *h2, const int32_t *n2,
+                                int navg, double dro, double thetaTresh, double lineSetTresh, int which, int h, int w, lfdmi_result *out) {
+    if (!ctx || n < 0 || !h1 || !h2 || !n1 || !n2 || !out || kmax < 1 || navg < 1 || navg > LFDMI_MAX_SET_LINES || (which != 1 && which != 2))
+        return fail(ctx, LFDMI_ERR_ARG, "lfdmi_debug_tail: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int G = ctx->G, K = navg;
+    std::vector<float> lines((size_t)G * 2 * K * 2);
+    std::vector<int> cnt((size_t)G * C_COUNT);
+    for (int c0 = 0; c0 < n; c0 += G) {
+        const int nc = std::min(G, n - c0);
+        std::fill(lines.begin(), lines.end(), 0.f);
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (int i = 0; i < nc; i++) {
+            const int a = n1[c0 + i], b = n2[c0 + i];
+            if (a < 0 || a > kmax || b < 0 || b > kmax) return fail(ctx, LFDMI_ERR_ARG, "lfdmi_debug_tail: line count");
+            // (what k_hough_topk leaves: the first K lines of each set, zero-filled)
+            for (int k = 0; k < K && k < a; k++) { lines[((size_t)i * 2 + 0) * K * 2 + 2 * k] = h1[((size_t)(c0 + i) * kmax + k) * 2]; lines[((size_t)i * 2 + 0) * K * 2 + 2 * k + 1] = h1[((size_t)(c0 + i) * kmax + k) * 2 + 1]; }
+            for (int k = 0; k < K && k < b; k++) { lines[((size_t)i * 2 + 1) * K * 2 + 2 * k] = h2[((size_t)(c0 + i) * kmax + k) * 2]; lines[((size_t)i * 2 + 1) * K * 2 + 2 * k + 1] = h2[((size_t)(c0 + i) * kmax + k) * 2 + 1]; }
+            cnt[(size_t)i * C_COUNT + C_DETECT] = 1;
+            cnt[(size_t)i * C_COUNT + C_NPEAK_EQU] = a;
+            cnt[(size_t)i * C_COUNT + C_NPEAK_BOX] = b;
+        }
+        HIPCHK(hipMemcpyAsync(ctx->lines, lines.data(), (size_t)nc * 2 * K * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->counters, cnt.data(), (size_t)nc * C_COUNT * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        k_init_results<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->res_dev, ctx->pass_flags, nc);
+        KCHK("k_init_results");
+        TailParams tp;
+        tp.navg = navg; tp.dro = dro; tp.thetaTresh = thetaTresh; tp.lineSetTresh = lineSetTresh; tp.which = which;
+        k_finalize<<<(nc + 63) / 64, 64, 0, ctx->stream>>>(ctx->lines, ctx->counters, ctx->res_dev, nullptr, ctx->pass_flags, nullptr, tp, nc);
+        KCHK("k_finalize");
+        HIPCHK(hipMemcpyAsync(out + c0, ctx->res_dev, (size_t)nc * sizeof(lfdmi_result), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < nc; i++) dictify(h, w, &out[c0 + i]);
+    }
     return 0;
 }
 

@@ -42,13 +42,17 @@ def _add_streak(img, y0, x0, angle_deg, peak, sigma):
     img += (np.float32(peak) * np.exp(-(d * d) / np.float32(2 * sigma * sigma))).astype(np.float32)
 
 
-def make_frame(k, shape=SDSS_SHAPE, n_star=None, with_catalog=True):
-    """Returns (float32 image, catalogue dict or None, truth dict)."""
+def make_frame(k, shape=SDSS_SHAPE, n_star=None, with_catalog=True, sky_sigma=0.025, bleed=False):
+    """Returns (float32 image, catalogue dict or None, truth dict).
+
+    ``n_star``, ``sky_sigma`` and ``bleed`` are the knobs of the stress workloads (bench.py ``stress`` leg, tests): crowded fields,
+    noisier sky, a saturated star with a full-height bleed column.  The defaults are the benchmark recipe of SURVEY.md 8(d); the
+    extra draws of ``bleed`` come after every other draw, so the default frames are unchanged."""
     h, w = shape
     if n_star is None:
         n_star = 400 if shape == SDSS_SHAPE else int(round(400 * (h * w) / (1489 * 2048)))
     rng = np.random.default_rng(np.random.PCG64(SEED0 + int(k)))
-    img = rng.normal(0.0, 0.025, (h, w)).astype(np.float32)
+    img = rng.normal(0.0, sky_sigma, (h, w)).astype(np.float32)
     ys = rng.uniform(0, h, n_star)
     xs = rng.uniform(0, w, n_star)
     flux = np.exp(rng.uniform(np.log(1.0), np.log(2000.0), n_star))
@@ -91,6 +95,17 @@ def make_frame(k, shape=SDSS_SHAPE, n_star=None, with_catalog=True):
                 psf[n_star + j, int(rng.integers(0, 5))] = -9999.0
         cat = {"ROWC": rowc, "COLC": colc, "PSFMAG": psf, "PETROTH90": pet, "NOBSERVE": nob,
                "NDETECT": nde}
+    if bleed:
+        # a saturated star: flat-topped core of 12 px radius at the CCD's full well and a 3-px bleed trail down its whole
+        # column (what a 6th-magnitude star does to an SDSS frame); it is not in the catalogue (saturated objects are flagged
+        # out of photoObj's clean sample), so remove_stars leaves it alone
+        by, bx = float(rng.uniform(0.1 * h, 0.9 * h)), int(rng.integers(16, w - 16))
+        yy = np.arange(h, dtype=np.float32)[:, None]
+        xx = np.arange(w, dtype=np.float32)[None, :]
+        core = (yy - np.float32(by)) ** 2 + (xx - np.float32(bx)) ** 2 <= np.float32(144.0)
+        img[core] = np.float32(1200.0)
+        img[:, bx - 1:bx + 2] = np.float32(1200.0)
+        truth["bleed_x"] = bx
     return img, cat, truth
 
 
@@ -237,11 +252,13 @@ def _worker_main(argv):
     i0 .. i0+count-1 of the shared [n, h, w] float32 array with frames k_first .., pickles the catalogues to stdout."""
     import pickle
     import sys
+    import json
     name, n, h, w, i0, k_first, count, with_cat = argv[0], *[int(x) for x in argv[1:8]]
+    recipes = json.loads(argv[8]) if len(argv) > 8 else None      # per-frame keyword arguments of make_frame (stress workloads)
     out = np.memmap(name, np.float32, "r+", shape=(n, h, w))
     cats = []
     for j in range(count):
-        img, cat, _ = make_frame(k_first + j, (h, w), with_catalog=bool(with_cat))
+        img, cat, _ = make_frame(k_first + j, (h, w), with_catalog=bool(with_cat), **(recipes[j] if recipes else {}))
         out[i0 + j] = img
         cats.append(cat)
     out.flush()
@@ -250,9 +267,27 @@ def _worker_main(argv):
     sys.stdout.buffer.flush()
 
 
-def make_frames(k0, n, shape=SDSS_SHAPE, workers=None, with_catalog=True):
+# The stress workloads of bench.py's `stress` leg and tests/test_gpu_stress.py: what the benchmark's sky (400 stars, sigma 0.025)
+# does not exercise -- crowded fields, noisier sky (half of it survives the dim pass's minFlux at sigma 0.1), a saturated star
+# with a full-height bleed column, one crowded frame (more candidate runs than the per-frame kernels' LDS table holds) in an
+# otherwise quiet chunk.  name -> per-frame keyword arguments of make_frame (a function of the frame's position in the batch).
+STRESS = {
+    "stars4000": lambda i: {"n_star": 4000},
+    "stars20000": lambda i: {"n_star": 20000},
+    "sky0.05": lambda i: {"sky_sigma": 0.05},
+    "sky0.1": lambda i: {"sky_sigma": 0.1},
+    "bleed": lambda i: {"bleed": True},
+    "one_crowded": lambda i: {"n_star": 8000} if i % 16 == 5 else {},
+}
+
+
+def stress_recipes(name, n):
+    return [STRESS[name](i) for i in range(n)]
+
+
+def make_frames(k0, n, shape=SDSS_SHAPE, workers=None, with_catalog=True, recipes=None):
     """Frames k0 .. k0+n-1 as one float32 array [n, h, w] plus their catalogues, generated by ``workers`` child
-    processes that write into shared memory.
+    processes that write into shared memory.  ``recipes``: per-frame keyword arguments of make_frame (stress workloads).
 
     The workers are separate ``python -m lfd_amd.synth`` programs started as child processes, never forked copies of
     the caller: the caller may already have initialised the GPU -- under rocprofv3 the profiler's preloaded tool
@@ -271,7 +306,7 @@ def make_frames(k0, n, shape=SDSS_SHAPE, workers=None, with_catalog=True):
         out = np.empty((n, h, w), np.float32)
         cats = []
         for i in range(n):
-            img, cat, _ = make_frame(k0 + i, shape, with_catalog=with_catalog)
+            img, cat, _ = make_frame(k0 + i, shape, with_catalog=with_catalog, **(recipes[i] if recipes else {}))
             out[i] = img
             cats.append(cat)
         return out, cats
@@ -294,6 +329,9 @@ def make_frames(k0, n, shape=SDSS_SHAPE, workers=None, with_catalog=True):
             if b > a:
                 cmd = [sys.executable, "-m", "lfd_amd.synth", path, str(n), str(h), str(w), str(a), str(k0 + a),
                        str(b - a), str(int(with_catalog))]
+                if recipes:
+                    import json
+                    cmd.append(json.dumps(recipes[a:b]))
                 procs.append((a, b, subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, cwd=root)))
         cats = [None] * n
         for a, b, p in procs:

@@ -56,11 +56,12 @@ def test_lsst_batch_multiscale_vs_oracle(oracle):
     assert found == {0, 2}                                          # bright streaks survive a 9x9 erosion, dim ones do not
 
 
-def test_tiny_capacities_spill_to_the_worst_case_workspace(oracle):
-    """A workspace whose tables are far too small for the frames: every overflow (run tables, contour keys, row slots,
-    Hough chunk lists, peak lists) is flagged on the device before any table is indexed past its end, and the frame is
-    run again through the worst-case workspace: records equal those of a default context and of the oracle."""
+def test_tiny_capacities_spill_to_the_worst_case_workspace(oracle, monkeypatch):
+    """A workspace whose tables are far too small for the frames and may not grow (LFDMI_GROW=0): every overflow (run tables,
+    contour keys, row slots, Hough chunk lists, peak lists) is flagged on the device before any table is indexed past its end,
+    and the frame is run again through the worst-case workspace: records equal those of a default context and of the oracle."""
     from lfd_amd import _native, synth
+    monkeypatch.setenv("LFDMI_GROW", "0")
     pb, pd, prs = params()
     kw = {k: v for k, v in prs.items() if k != "debug"}
     rs_g, rs_o = _native.make_rs_params("r", **kw), oracle.rs_params("r", **kw)
@@ -87,11 +88,43 @@ def test_tiny_capacities_spill_to_the_worst_case_workspace(oracle):
         assert res.tobytes() == ref[:2].tobytes() and ctx.spill_count() == 0
 
 
-def test_spilled_big_endian_frames_keep_their_catalogue_entry():
+def test_tables_grow_instead_of_spilling_every_time(oracle):
+    """Round 4: a context whose tables overflow enlarges them (k_finalize leaves each frame's demands in its record) and runs
+    the chunk again, instead of sending every such frame alone through the worst-case workspace on every call: same records,
+    the growth happens once, later calls are plain fast-path calls."""
+    from lfd_amd import _native, synth
+    pb, pd, prs = params()
+    kw = {k: v for k, v in prs.items() if k != "debug"}
+    rs_g = _native.make_rs_params("r", **kw)
+    frames, cats = zip(*[synth.make_frame(k)[:2] for k in range(6)])
+    batch = np.stack(frames)
+    packed = synth.pack_catalogs(list(cats))
+    with _native.Context(0, 1489, 2048, 6) as ref_ctx:
+        ref = ref_ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g)
+        ref_bytes = ref_ctx.workspace_bytes()
+    for caps in ({"run_cap": 3000}, {"key_cap": 64}, {"slot_cap": 2000}, {"list_cap": 1500}, {"peak_cap": 256},
+                 {"run_cap": 3000, "key_cap": 64, "slot_cap": 2000, "list_cap": 1500, "peak_cap": 256}):
+        with _native.Context(0, 1489, 2048, 6, caps=caps) as ctx:
+            small = ctx.workspace_bytes()
+            res = ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g)
+            assert res.tobytes() == ref.tobytes(), caps
+            st = ctx.stats()
+            assert st["cap_growths"] >= 1 and st["spilled_frames"] == 0, (caps, st)
+            assert small < ctx.workspace_bytes() < 4 * ref_bytes, caps          # grown to what the frames asked for, not to the worst case
+            res = ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g)          # the second call finds its tables large enough
+            st2 = ctx.stats()
+            assert res.tobytes() == ref.tobytes() and st2["cap_growths"] == st["cap_growths"] and st2["chunks"] == st["chunks"] + 1, (caps, st, st2)
+            rb, _, _ = ctx.process_bright(np.ascontiguousarray(batch[:2, ::-1]), pb)   # the per-pass entry points share the tables
+            for i in range(2):
+                assert same(rb[i], oracle.process_bright(np.ascontiguousarray(batch[i, ::-1]), pb)), caps
+
+
+def test_spilled_big_endian_frames_keep_their_catalogue_entry(monkeypatch):
     """A raw big-endian frame is a read-only input: what the worst-case rerun of a spilled frame uploads is not blotted, so
     the rerun takes the frame's own catalogue entry (frames 1 .. 5 of a batch: the entry is not the first one); native host
     frames, blotted by then, go without.  Records equal those of a context that never spills."""
     from lfd_amd import _native, synth
+    monkeypatch.setenv("LFDMI_GROW", "0")
     pb, pd, prs = params()
     rs_g = _native.make_rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
     frames, cats = zip(*[synth.make_frame(k)[:2] for k in range(6)])

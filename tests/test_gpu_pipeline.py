@@ -359,8 +359,10 @@ def test_remove_stars_masked_in_the_sweep_or_filled_before_it(oracle, monkeypatc
     batch = np.stack(frames)
     packed = synth.pack_catalogs(cats)
     outs = []
-    for env in ({}, {"LFDMI_RS_FOLD": "0"}, {"LFDMI_RS_FILL_AT": "1"}, {"LFDMI_RS_FILL_AT": "3"}, {"LFDMI_RS_FILL_AT": "5"}, {"LFDMI_RS_FILL_AT": "9"}):
-        for k in ("LFDMI_RS_FOLD", "LFDMI_RS_FILL_AT"):
+    # (LFDMI_RS_SORT_MIN=0: the path of crowded catalogues -- squares sorted by first row, band-wise fold and fill -- on this one)
+    for env in ({}, {"LFDMI_RS_FOLD": "0"}, {"LFDMI_RS_FILL_AT": "1"}, {"LFDMI_RS_FILL_AT": "3"}, {"LFDMI_RS_FILL_AT": "5"}, {"LFDMI_RS_FILL_AT": "9"},
+                {"LFDMI_RS_SORT_MIN": "0"}, {"LFDMI_RS_SORT_MIN": "0", "LFDMI_RS_FOLD": "0"}):
+        for k in ("LFDMI_RS_FOLD", "LFDMI_RS_FILL_AT", "LFDMI_RS_SORT_MIN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -401,13 +403,70 @@ def test_fused_run_scan_gives_up_gracefully(oracle, monkeypatch):
         wb, _, _ = ctx.process_bright(np.ascontiguousarray(batch[:2, ::-1]), pb)
     monkeypatch.setenv("LFDMI_SCAN_SPIN", "0")
     with _native.Context(0, 1489, 2048, 4) as ctx:
+        assert ctx.stats()["scan_fused_on"] == 1
         for _ in range(2):
             assert ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g).tobytes() == want.tobytes()
-        assert ctx.spill_count() == 0
+        st = ctx.stats()                                  # the switch is visible (lfdmi_get_stats), not a silent slowdown
+        assert ctx.spill_count() == 0 and st["scan_giveups"] == 1 and st["scan_fused_on"] == 0 and st["chunks"] == 2, st
     with _native.Context(0, 1489, 2048, 4) as ctx:
         rb, _, _ = ctx.process_bright(np.ascontiguousarray(batch[:2, ::-1]), pb)
-        assert rb.tobytes() == wb.tobytes() and ctx.spill_count() == 0
+        assert rb.tobytes() == wb.tobytes() and ctx.spill_count() == 0 and ctx.stats()["scan_giveups"] == 1
+    with _native.Context(0, 300, 400, 2) as ctx:          # the operator entry points rerun the chunk too (round 3: one worst-case rerun per image)
+        from scipy import ndimage as ndi
+        rng = np.random.default_rng(3)
+        smooth = np.stack([(ndi.gaussian_filter(rng.random((300, 400)), 3.0) * 900).clip(0, 255).astype(np.uint8) for _ in range(2)])
+        assert np.array_equal(ctx.canny(smooth, 50, 150)[1], oracle.canny(smooth[1], 50, 150))
+        det, box, nb = ctx.fit_min_area_rect(smooth[0])
+        det_o, box_o, nb_o = oracle.fit_min_area_rect(smooth[0])
+        assert det == det_o and nb == nb_o and np.array_equal(box, box_o)
+        assert ctx.spill_count() == 0 and ctx.stats()["scan_giveups"] == 1, ctx.stats()
+    # the one-launch scan is tried again after a while (here: after one quiet chunk, then two, ...) and gives up again
+    monkeypatch.setenv("LFDMI_SCAN_REARM", "1")
+    with _native.Context(0, 1489, 2048, 4) as ctx:
+        for _ in range(5):
+            assert ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g).tobytes() == want.tobytes()
+        assert ctx.stats()["scan_giveups"] >= 2 and ctx.spill_count() == 0, ctx.stats()
+    monkeypatch.delenv("LFDMI_SCAN_REARM")
+    # a bound of a few polls: some workgroups of a launch see their predecessors in time, others give up
+    for spin in ("1", "3"):
+        monkeypatch.setenv("LFDMI_SCAN_SPIN", spin)
+        with _native.Context(0, 1489, 2048, 4) as ctx:
+            for _ in range(2):
+                assert ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g).tobytes() == want.tobytes(), spin
+            assert ctx.spill_count() == 0
     assert same(want[1], oracle.detect_frame(frames[1].copy(), pb, pd, cats[1], rs_o))
+
+
+def test_two_contexts_of_one_process_at_the_same_time(oracle):
+    """Two contexts (own streams, own workspaces) driven by two host threads at once -- what BatchDetector(lanes=2) does: the
+    look-back scans of the two can hold each other's CU slots like two processes do; whatever the scans decide (wait, give up,
+    three launches), the records are those of a context working alone."""
+    import threading
+    from lfd_amd import _native, synth
+    pb, pd, prs = params()
+    rs_g, rs_o = rs_pair(oracle, prs)
+    frames, cats = zip(*[synth.make_frame(k)[:2] for k in range(8)])
+    batch = np.stack(frames)
+    packed = synth.pack_catalogs(list(cats))
+    with _native.Context(0, 1489, 2048, 8) as ctx:
+        want = ctx.detect_batch(batch.copy(), pb, pd, packed, rs_g)
+    a, b = _native.Context(0, 1489, 2048, 4), _native.Context(0, 1489, 2048, 4)
+    got = [None, None]
+
+    def work(k, ctx):
+        sl = slice(4 * k, 4 * k + 4)
+        for _ in range(6):
+            got[k] = ctx.detect_batch(batch[sl].copy(), pb, pd, {n: v[sl] for n, v in packed.items()}, rs_g)
+
+    th = [threading.Thread(target=work, args=(k, c)) for k, c in enumerate((a, b))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert np.concatenate(got).tobytes() == want.tobytes()
+    assert a.spill_count() == 0 and b.spill_count() == 0
+    a.close(); b.close()
+    assert same(want[5], oracle.detect_frame(frames[5].copy(), pb, pd, cats[5], rs_o))
 
 
 def test_fused_run_scan_survives_the_wrap_of_its_epoch(monkeypatch):
@@ -431,7 +490,7 @@ def test_dense_noise_frames_take_the_general_kernels_and_match_the_oracle(oracle
     """Frames the per-frame LDS kernels cannot hold (noise everywhere: far more than 32 768 runs) are
     flagged on the device, the chunk is run again with the general multi-workgroup kernels, and the records
     still equal the oracle's; later chunks of the same context launch the general kernels right away.  With the default
-    (compact) capacities such frames exceed the run tables first and take the worst-case workspace instead."""
+    (compact) capacities such frames exceed the run tables first: the context enlarges them and runs the chunk again."""
     from lfd_amd import _native
     pb, pd, prs = params()
     rng = np.random.default_rng(7)
@@ -449,8 +508,9 @@ def test_dense_noise_frames_take_the_general_kernels_and_match_the_oracle(oracle
         runs = ctx.get_counters(0, 4)[:, 12]
         assert runs[:3].min() > 32768, runs               # really beyond the LDS tables
         assert ctx.spill_count() == 0
-    else:
-        assert ctx.spill_count() == 3                     # beyond the default run tables (N / 16): worst-case workspace
+    else:                                                 # beyond the default run tables (N / 16): the tables grow (round 4; before: three
+        st = ctx.stats()                                  # frames through the worst-case workspace on every call)
+        assert st["cap_growths"] >= 1 and st["spilled_frames"] == 0, st
     for i in range(4):
         want = oracle.detect_frame(frames[i].copy(), pb, pd)
         assert same(res[i], want), (i, want, res[i])

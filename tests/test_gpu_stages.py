@@ -233,6 +233,36 @@ def test_remove_stars(gpu_ctx, oracle):
         assert np.array_equal(again, batch)                  # idempotent
 
 
+def test_remove_stars_crowded_catalogue(oracle, monkeypatch):
+    """Thousands of objects per frame take another route (squares sorted by first row, every band of rows blotted once through
+    an LDS bit plane: k_rs_sort / k_rs_fill_bands): same frames as the oracle, overlapping squares, squares clipped at every
+    edge, objects that stay; and the same route forced on a small catalogue (LFDMI_RS_SORT_MIN=0)."""
+    from lfd_amd import _native, synth
+    rng = np.random.default_rng(23)
+    kw = dict(defaultxy=6, maxxy=25, pixscale=0.396, magcount=3, maxmagdiff=3,
+              filter_caps={'u': 22.0, 'g': 22.2, 'r': 22.2, 'i': 21.3, 'z': 20.5})
+    for (h, w, n), env in (((200, 256, 3000), None), ((97, 160, 50), "0"), ((64, 96, 0), "0")):
+        if env is not None:
+            monkeypatch.setenv("LFDMI_RS_SORT_MIN", env)
+        frames, cats = [], []
+        for _ in range(2):
+            cats.append({"ROWC": rng.uniform(-5, w + 5, (n, 5)).astype(np.float32),
+                         "COLC": rng.uniform(-5, w + 5, (n, 5)).astype(np.float32),
+                         "PSFMAG": rng.uniform(14, 24, (n, 5)).astype(np.float32),
+                         "PETROTH90": rng.uniform(-2, 30, (n, 5)).astype(np.float32),
+                         "NOBSERVE": rng.integers(1, 3, n).astype(np.int32), "NDETECT": rng.integers(1, 3, n).astype(np.int32)})
+            frames.append(rng.normal(1, 1, (h, w)).astype(np.float32))
+        if n == 0:
+            continue                                         # (an empty catalogue packs to nothing: covered by the pipeline tests)
+        with _native.Context(0, h, w, 2) as ctx:
+            for flt in "ri":
+                batch = np.stack(frames).copy()
+                ctx.remove_stars(batch, synth.pack_catalogs(cats), _native.make_rs_params(flt, **kw))
+                for i in range(2):
+                    want = oracle.remove_stars(frames[i].copy(), cats[i], oracle.rs_params(flt, **kw))
+                    assert np.array_equal(batch[i], want), (h, w, n, flt, i)
+
+
 def test_optional_gaussian_stage(gpu_ctx, oracle):
     """The Gaussian smoothing north_star lists inside Canny -- off by default, because cv2.Canny has none
     (processfield.py:236): the operator against the oracle's definition, and a pass with gaussKernel set."""
@@ -256,3 +286,53 @@ def test_optional_gaussian_stage(gpu_ctx, oracle):
         assert all(res[k].item() == v for k, v in want.items()), (want, res)
     off = gpu_ctx.process_bright(img, pb)[0]
     assert off.tobytes() == gpu_ctx.process_bright(img, dict(pb, gaussKernel=0))[0].tobytes()
+
+
+def test_device_check_theta_and_host_dictify_against_the_reference_vectors():
+    """The only arithmetic the reference itself pins (tests/golden/tail_fixtures.json: 309 check_theta and 206 dictify_hough
+    vectors produced by processfield.py:36-150 / :266-288): fed straight to k_finalize (the device's check_theta, float64,
+    numpy's summation order, the zero fill of :89-102) and to the library's host-side dictify -- until round 4 these two were
+    only checked through the oracle."""
+    import json
+    import os
+    from lfd_amd import _native as N
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tail_fixtures.json")))
+    with N.Context(0, 64, 64, 32) as ctx:                             # (several chunks of 32)
+        # check_theta: one call per parameter set
+        groups = {}
+        for c in fx["check_theta"]:
+            groups.setdefault((c["navg"], c["dro"], c["thetaTresh"], c["lineSetTresh"]), []).append(c)
+        checked = 0
+        for (navg, dro, tt, lt), cases in groups.items():
+            kmax = max(max(len(c["h1"]), len(c["h2"])) for c in cases)
+            h1 = np.zeros((len(cases), kmax, 2), np.float32)
+            h2 = np.zeros_like(h1)
+            n1 = np.array([len(c["h1"]) for c in cases], np.int32)
+            n2 = np.array([len(c["h2"]) for c in cases], np.int32)
+            for i, c in enumerate(cases):
+                h1[i, :n1[i]] = np.asarray(c["h1"], np.float32).reshape(-1, 2)
+                h2[i, :n2[i]] = np.asarray(c["h2"], np.float32).reshape(-1, 2)
+            for which in (1, 2):
+                rec = ctx.debug_tail(h1, n1, h2, n2, navg, dro, tt, lt, which, (1489, 2048))
+                for i, c in enumerate(cases):
+                    rejected = c["out"] is True                      # check_theta: True = reject, None = accept
+                    assert bool(rec["rejected_by_theta"][i]) == rejected, c
+                    assert rec["found"][i] == (0 if rejected else which), c
+                    if not rejected:
+                        assert rec["rho"][i] == np.float32(c["h1"][0][0]) and rec["theta"][i] == np.float32(c["h1"][0][1])
+                    checked += 1
+        assert checked == 2 * len(fx["check_theta"]) == 618
+        # dictify_hough: a single accepted line per record, per image shape
+        by_shape = {}
+        for c in fx["dictify_hough"]:
+            by_shape.setdefault(tuple(c["shape"]), []).append(c)
+        done = 0
+        for shape, cases in by_shape.items():
+            h = np.array([[[c["rho"], c["theta"]]] for c in cases], np.float32)
+            ones = np.ones(len(cases), np.int32)
+            rec = ctx.debug_tail(h, ones, h, ones, 1, 25.0, 0.15, 0.15, 1, shape)
+            for i, c in enumerate(cases):
+                assert rec["found"][i] == 1
+                assert {k: int(rec[k][i]) for k in ("x1", "y1", "x2", "y2")} == c["out"], c
+                done += 1
+        assert done == len(fx["dictify_hough"]) == 206
