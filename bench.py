@@ -185,6 +185,91 @@ def host_cores(world):
     return max(1, min(avail, per_gpu * max(1, world))), avail
 
 
+def detection_quality(res, truths, h):
+    """Detections against what lfd_amd.synth injected (the third value of make_frame): a kernel change that stays oracle-equal
+    cannot move these, a change of the synthetic recipe that breaks the workload does.  Lines are compared in the flipped
+    frame the pipe works on (detecttrails.py:124): a streak through (x0, y0) at angle_deg has theta = 90 deg - angle (mod 180)."""
+    with_streak = [i for i, t in enumerate(truths) if t["streak"] != "none"]
+    without = [i for i, t in enumerate(truths) if t["streak"] == "none"]
+    found = res["found"] > 0
+    dth, dist = [], []
+    for i in with_streak:
+        if not found[i]:
+            continue
+        t = truths[i]
+        th = float(res["theta"][i])
+        want = np.deg2rad((90.0 - t["angle_deg"]) % 180.0)
+        d = abs(th - want) % np.pi
+        dth.append(np.rad2deg(min(d, np.pi - d)))
+        dist.append(abs(t["x0"] * np.cos(th) + (h - 1 - t["y0"]) * np.sin(th) - float(res["rho"][i])))
+    out = {"frames_with_streak": len(with_streak), "of_those_found": int(found[with_streak].sum()) if with_streak else 0,
+           "bright_streaks_found_by_bright_pass": int(sum(1 for i in with_streak if truths[i]["streak"] == "bright" and res["found"][i] == 1)),
+           "frames_without_streak": len(without), "of_those_found_false_positives": int(found[without].sum()) if without else 0}
+    if dth:
+        out["median_abs_dtheta_deg"] = round(float(np.median(dth)), 3)
+        out["median_distance_of_injected_point_from_line_px"] = round(float(np.median(dist)), 2)
+        out["note"] = "HoughLines at rho = 20 px, theta = 1 deg: a line is known to +-10 px / +-0.5 deg by construction"
+    return out
+
+
+def load_util(workload):
+    """Per-kernel utilisation figures derived from the committed SQ / GRBM / TCC counters of the newest profiles/r*_util_<workload>.json
+    (tools/make_util.py; formulas in that file): {timing slot: {...}}, the file name, or ({}, None)."""
+    import glob
+    best = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_util_%s.json" % workload)))
+    if not best:
+        return {}, None, None
+    with open(best[-1]) as f:
+        d = json.load(f)
+    return d.get("slots", {}), os.path.basename(best[-1]), d.get("top_kernel")
+
+
+def stress_leg(args, env, headline):
+    """The full pipe on the stress workloads of lfd_amd.synth.STRESS (crowded fields, noisier sky, a saturated star, one crowded
+    frame in a quiet chunk): frames/s for a 256-frame batch (16 distinct frames, each 16 times), the share of the headline rate,
+    and what the context did besides the fast path.  tests/test_gpu_stress.py checks the same workloads against the oracle."""
+    import torch
+    from lfd_amd import _native, synth
+    from lfd_amd.batch import BatchDetector
+    from lfd_amd.detecttrails import default_params
+    dev, dev_index = env["dev"], env["dev_index"]
+    pb, pd, prs = default_params()
+    rs = _native.make_rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
+    n, nd = 256, 16
+    out = {"batch": n, "distinct_frames": nd, "note": "secondary leg, never `value`; percent = of this run's headline frames/s"}
+    for name in synth.STRESS:
+        host, cats = synth.make_frames(0, nd, synth.SDSS_SHAPE, min(16, max(1, (os.cpu_count() or 2) // 2)), True, synth.stress_recipes(name, nd))
+        idx = torch.arange(n, device=dev) % nd
+        frames = torch.from_numpy(host).to(dev)[idx].contiguous()
+        packed = synth.pack_catalogs([cats[i % nd] for i in range(n)])
+        cat = {k: torch.from_numpy(v).to(dev) for k, v in packed.items()}
+        det = BatchDetector(dev_index, synth.SDSS_SHAPE, n, stream=torch.cuda.current_stream().cuda_stream)
+        work = frames.clone()
+        res = det.detect(work, pb, pd, cat, rs)                  # first call: tables grow, kernels switch
+        torch.cuda.synchronize()
+        first = det.stats()
+        best = None
+        for _ in range(3):
+            work.copy_(frames)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = det.detect(work, pb, pd, cat, rs)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        st = det.stats()
+        cnt = det.get_counters()[:n]
+        out[name] = {"frames_per_s": round(n / best, 1), "percent_of_headline": round(100.0 * (n / best) / headline, 1),
+                     "ms_per_batch": round(1e3 * best, 2), "found": int((res["found"] > 0).sum()),
+                     "max_candidate_runs_per_frame": int(cnt[:, 12].max()), "catalogue_objects_per_frame": int(packed["count"].max()),
+                     "first_call": {k: v for k, v in first.items() if v and k not in ("chunks", "scan_fused_on")},
+                     "per_call_after_that": {k: (st[k] - first[k]) // 3 for k in st if k not in ("chunks", "scan_fused_on") and st[k] != first[k]}}
+        det.close()
+        del frames, work, cat
+        torch.cuda.empty_cache()
+    return out
+
+
 def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True, sustained_s=0.0):
     """One workload on this rank's GPU: generation, upload, warm-up, the timed region, the per-kernel table.  Returns
     (out dict for rank 0 or None, state for the follow-up legs)."""
@@ -204,7 +289,7 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
     t0 = time.time()
     # child processes (never forks of this one: safe under a profiler's preloaded library), frames into shared memory
     nd = min(n, distinct or n)
-    host, cats = synth.make_frames(k0 if nd == n else 0, nd, shape, workers, with_catalog=not lsst)
+    host, cats, truths = synth.make_frames(k0 if nd == n else 0, nd, shape, workers, with_catalog=not lsst, with_truth=True)
     t_gen = time.time() - t0
 
     pb, pd, prs = default_params()
@@ -218,6 +303,7 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
         idx = torch.arange(n, device=dev) % nd
         dframes = dframes[idx].contiguous()
         cats = [cats[i % nd] for i in range(n)]
+        truths = [truths[i % nd] for i in range(n)]
     cat = packed = None
     if not lsst and not args.no_removestars:
         packed = synth.pack_catalogs(cats)
@@ -349,6 +435,13 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
         traffic, traffic_src = load_traffic(name, (workload, n, inflight, args.lanes, [h, w]))
         kern = {k: {"ms_per_step": round(v[0], 4), "launches_per_step": v[1], "frames_per_step": v[2]}
                 for k, v in table.items() if v[1]}  # one fully bracketed step after the timed region
+        # what bounds each kernel, from the committed SQ / GRBM / TCC counter passes of the same command (tools/make_util.py): shares of
+        # the vector pipe, the scalar unit, the LDS and the HBM peak, occupancy, parked / issue-stalled shares of a wave's life
+        util, util_src, top_rocprof = load_util(workload)
+        for k in kern:
+            u = util.get("k_scan_fused" if k.startswith("k_runs_init") else k)
+            if u:
+                kern[k]["util"] = u
         # per-stage view of that step: every stage's algorithmic bytes once, over the summed time of its kernels
         stages = {}
         for sname, (bpp, ks) in STAGES.items():
@@ -419,6 +512,8 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
                        "hough_nnz_equ_median": int(np.median(nnz_equ)) if len(nnz_equ) else 0,
                        "hough_nnz_box_median": int(np.median(nnz_box)) if len(nnz_box) else 0,
                        "workspace_GB": round(det.workspace_bytes() / 1e9, 2), "frames_spilled_to_worst_case_workspace": det.spill_count(),
+                       "beside_the_fast_path": {k: v for k, v in det.stats().items() if k != "spilled_frames"},
+                       "detection_vs_injected_truth": detection_quality(res0, truths, h),
                        "gen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
@@ -433,6 +528,9 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
                          "algorithmic_bytes_per_px": round(bpp_dom, 3),
                          "canny_hough": ch,
                          "hough_votes": hv,
+                         "kernel_is": "a timing SLOT of the library (the fused tile kernel's three launches); the largest single rocprof kernel is kernel_rocprof",
+                         "kernel_rocprof": top_rocprof,
+                         "util_source": util_src,
                          "note": "algorithmic bytes as SURVEY 8(d) prescribes, each stage charged once across its kernels; "
                                  "measured_traffic_frac = PMC HBM bytes per launch / launch time / peak: a kernel whose measured "
                                  "fraction is far below 1 is limited by vector-unit issue / LDS round trips, not by HBM"},
@@ -644,6 +742,10 @@ def main():
             except Exception as e:  # noqa: BLE001 - a secondary leg must not cost the headline line
                 out["dropin"] = {"error": "%s: %s" % (type(e).__name__, e)}
             del state
+            try:
+                out["stress"] = stress_leg(args, env, out["value"])
+            except Exception as e:  # noqa: BLE001
+                out["stress"] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:
                 a2 = argparse.Namespace(**vars(args))
                 a2.inflight = None

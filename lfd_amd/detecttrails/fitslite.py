@@ -96,7 +96,8 @@ def _load(path):
     with open(path, "rb") as f:
         raw = f.read()
     if str(path).endswith(".bz2"):
-        raw = bz2.decompress(raw)
+        from . import bz2blocks
+        raw = bz2blocks.decompress(raw, bz2blocks.shared_pool())   # (the blocks of the stream side by side)
     return raw
 
 

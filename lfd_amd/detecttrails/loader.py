@@ -24,7 +24,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from .. import _native
-from . import fitslite, sdssfiles
+from . import bz2blocks, fitslite, sdssfiles
 
 BLOCK = fitslite.BLOCK
 _END = b"END" + b" " * 77
@@ -117,7 +117,9 @@ class FrameLoader:
             cores = len(os.sched_getaffinity(0))
         except (AttributeError, OSError):
             cores = os.cpu_count() or 1
-        self.threads = int(threads or os.environ.get("LFD_LOADER_THREADS", 0) or max(2, min(16, cores)))
+        # this rank's share of the host: every core it may run on, divided among the ranks torchrun started on this node
+        share = max(1, cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", 1))))
+        self.threads = int(threads or os.environ.get("LFD_LOADER_THREADS", 0) or max(2, min(64, share)))
         self.lib = _native.lib()
         self.pins = [ctx.pinned_buffer(self.slots * self.frame_bytes) for _ in range(2)]
         self.views = [p.array.view(">f4").reshape(self.slots, h, w) for p in self.pins]
@@ -128,10 +130,15 @@ class FrameLoader:
             c["count"] = np.zeros(self.slots, np.int32)
             self.cats.append(c)
         self.hdrs = [np.zeros((self.slots, HDR_CAP), np.uint8) for _ in range(2)]
-        self.pool = ThreadPoolExecutor(max(2, min(self.threads, 16)), thread_name_prefix="lfd-bz2")   # .bz2 frames and other exceptions
+        # .bz2 frames and other exceptions to the fast path: a few files at a time, the ~14 bzip2 blocks of each decoded side by side
+        # on all of the rank's cores (bz2blocks; libbz2 releases the interpreter lock) -- round 3 decoded whole files on at most
+        # 16 threads: a small selection waited ~0.4 s per frame on one core, and half of a rank's 32 cores idled
+        self.pool = ThreadPoolExecutor(max(2, min(self.threads, 8)), thread_name_prefix="lfd-slow")
+        self.block_pool = ThreadPoolExecutor(max(2, self.threads), thread_name_prefix="lfd-bz2")
 
     def close(self):
         self.pool.shutdown(wait=True)
+        self.block_pool.shutdown(wait=True)
         self.views = None
         for p in self.pins:
             p.close()
@@ -160,7 +167,7 @@ class FrameLoader:
                     raise FileNotFoundError(("File {0} or its bz2 compressed version not found. "
                                              "Are you sure they exist?").format(path))
                 with open(path + ".bz2", "rb", buffering=0) as f:
-                    raw = bz2.decompress(f.read())           # in memory; no $FITS_DUMP round trip (detecttrails.py:88-109)
+                    raw = bz2blocks.decompress(f.read(), self.block_pool)   # in memory; no $FITS_DUMP round trip (detecttrails.py:88-109)
                 end = header_end(raw)
                 if end < 0 or len(raw) < end:
                     raise ValueError("truncated FITS header")

@@ -258,9 +258,9 @@ def _worker_main(argv):
     out = np.memmap(name, np.float32, "r+", shape=(n, h, w))
     cats = []
     for j in range(count):
-        img, cat, _ = make_frame(k_first + j, (h, w), with_catalog=bool(with_cat), **(recipes[j] if recipes else {}))
+        img, cat, truth = make_frame(k_first + j, (h, w), with_catalog=bool(with_cat), **(recipes[j] if recipes else {}))
         out[i0 + j] = img
-        cats.append(cat)
+        cats.append((cat, truth))
     out.flush()
     del out
     sys.stdout.buffer.write(pickle.dumps(cats))
@@ -285,9 +285,10 @@ def stress_recipes(name, n):
     return [STRESS[name](i) for i in range(n)]
 
 
-def make_frames(k0, n, shape=SDSS_SHAPE, workers=None, with_catalog=True, recipes=None):
+def make_frames(k0, n, shape=SDSS_SHAPE, workers=None, with_catalog=True, recipes=None, with_truth=False):
     """Frames k0 .. k0+n-1 as one float32 array [n, h, w] plus their catalogues, generated by ``workers`` child
     processes that write into shared memory.  ``recipes``: per-frame keyword arguments of make_frame (stress workloads).
+    ``with_truth``: also return the frames' truth dicts (what was injected where), as a third value.
 
     The workers are separate ``python -m lfd_amd.synth`` programs started as child processes, never forked copies of
     the caller: the caller may already have initialised the GPU -- under rocprofv3 the profiler's preloaded tool
@@ -304,12 +305,13 @@ def make_frames(k0, n, shape=SDSS_SHAPE, workers=None, with_catalog=True, recipe
     workers = max(1, min(workers, n // 2))
     if workers <= 1:
         out = np.empty((n, h, w), np.float32)
-        cats = []
+        cats, truths = [], []
         for i in range(n):
-            img, cat, _ = make_frame(k0 + i, shape, with_catalog=with_catalog, **(recipes[i] if recipes else {}))
+            img, cat, truth = make_frame(k0 + i, shape, with_catalog=with_catalog, **(recipes[i] if recipes else {}))
             out[i] = img
             cats.append(cat)
-        return out, cats
+            truths.append(truth)
+        return (out, cats, truths) if with_truth else (out, cats)
     import tempfile
     env = {k: v for k, v in os.environ.items()
            if k not in _TOOL_ENV and not k.startswith("ROCPROF") and not k.startswith("ROCTX")}
@@ -339,13 +341,15 @@ def make_frames(k0, n, shape=SDSS_SHAPE, workers=None, with_catalog=True, recipe
             if p.returncode:
                 raise RuntimeError(f"frame generator worker failed with exit code {p.returncode}")
             cats[a:b] = pickle.loads(blob)
+        truths = [c[1] for c in cats]
+        cats = [c[0] for c in cats]
         out = np.fromfile(path, np.float32).reshape(n, h, w)
     finally:
         for _, _, p in procs:
             if p.poll() is None:
                 p.kill()
         os.unlink(path)
-    return out, cats
+    return (out, cats, truths) if with_truth else (out, cats)
 
 
 if __name__ == "__main__":
