@@ -177,10 +177,8 @@ def gpu_clock_mhz(index=0):
 def host_cores(world):
     """(threads the CPU legs may use, cores the process may run on): this rank's share of the node -- an MI355X node has 8
     GPUs, so 1/8 of its cores per rank (256 / 8 = 32 on the pool's hosts; $LFD_CORES_PER_GPU overrides)."""
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        avail = os.cpu_count() or 1
+    from lfd_amd import usable_cores
+    avail = usable_cores()   # (affinity mask cut down to the cgroup's CPU quota: the pool's one-GPU boxes show 256 CPUs and grant 16 cores)
     per_gpu = int(os.environ.get("LFD_CORES_PER_GPU", 0)) or max(1, (os.cpu_count() or avail) // 8)
     return max(1, min(avail, per_gpu * max(1, world))), avail
 
@@ -238,7 +236,7 @@ def stress_leg(args, env, headline):
     n, nd = 256, 16
     out = {"batch": n, "distinct_frames": nd, "note": "secondary leg, never `value`; percent = of this run's headline frames/s"}
     for name in synth.STRESS:
-        host, cats = synth.make_frames(0, nd, synth.SDSS_SHAPE, min(16, max(1, (os.cpu_count() or 2) // 2)), True, synth.stress_recipes(name, nd))
+        host, cats = synth.make_frames(0, nd, synth.SDSS_SHAPE, min(16, host_cores(1)[0]), True, synth.stress_recipes(name, nd))
         idx = torch.arange(n, device=dev) % nd
         frames = torch.from_numpy(host).to(dev)[idx].contiguous()
         packed = synth.pack_catalogs([cats[i % nd] for i in range(n)])
@@ -653,6 +651,21 @@ def dropin_leg(state, args, dev_index):
                           "setup_s": round(st["setup_s"], 3), "steady_state_frames_per_s": steady, "frames_per_gpu_call": st["chunk_frames"],
                           "rows": len(rows), "rows_equal_device_resident_run": rows == want, "errors_logged": errs,
                           "tree_write_s": round(t_write, 1)}
+            if bz:
+                # a .fits.bz2 is decoded by the host's cores and nothing else: frames/s = usable cores x frames/s per core.  The small
+                # selection (fewer files than cores) is where the blocks of a file are decoded side by side (bz2blocks)
+                from lfd_amd import usable_cores
+                from lfd_amd.detecttrails import bz2blocks, sdssfiles
+                cores = usable_cores()
+                out[label]["usable_cores"] = cores
+                out[label]["frames_per_s_per_core"] = round(total / el / cores, 2)
+                blob = open(sdssfiles.filename("frame", run=94, camcol=1, field=100, filter="r") + ".bz2", "rb").read()
+                import bz2 as _bz2
+                t0 = time.perf_counter(); a = _bz2.decompress(blob); t_whole = time.perf_counter() - t0
+                bz2blocks.decompress(blob, bz2blocks.shared_pool())
+                t0 = time.perf_counter(); b = bz2blocks.decompress(blob, bz2blocks.shared_pool()); t_blocks = time.perf_counter() - t0
+                out[label]["one_frame_latency_s"] = {"whole_file_one_core": round(t_whole, 3), "blocks_side_by_side": round(t_blocks, 3),
+                                                     "equal": a == b, "threads": min(16, cores)}
             shutil.rmtree(tree, ignore_errors=True)
     finally:
         for k, v in old_env.items():

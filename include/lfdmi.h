@@ -270,6 +270,10 @@ int lfdmi_fits_read_frames(const char *const *paths, int n, int h, int w, void *
 int lfdmi_fits_read_photoobj(const char *const *paths, int n, int max_obj, float *rowc, float *colc, float *psfmag,
                              float *petro90, int32_t *nobserve, int32_t *ndetect, int32_t *count, int threads,
                              int32_t *status);
+/* lfdmi_bz2_find_blocks: bit offsets of the block magics and the end-of-stream magic of a bzip2 file in host memory
+ * (out[i] = bit offset * 2 + 1 for the end-of-stream magic; returns their number, the first `cap` stored) -- the blocks of a
+ * .fits.bz2 frame are then decoded side by side (the reference pipes the file through bunzip2: detecttrails.py:81-109). */
+int64_t lfdmi_bz2_find_blocks(const uint8_t *data, uint64_t n, uint64_t *out, int64_t cap);
 /* Which calls keep the 8-bit stage images (gray, eroded, equalised+dilated: what the reference's debug PNGs show) for
  * lfdmi_get_stage.  mode -1 (default): the per-pass entry points (lfdmi_process_bright / _dim / _multiscale) do,
  * lfdmi_detect_batch does not; 0: no call does (batches through the per-pass entry points: an image per frame less to

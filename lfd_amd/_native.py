@@ -31,7 +31,7 @@ SYMBOLS = (
     "lfdmi_max_inflight", "lfdmi_prep_u8", "lfdmi_equalize_hist", "lfdmi_dilate", "lfdmi_erode",
     "lfdmi_canny", "lfdmi_gaussian_blur", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
     "lfdmi_hough_dims", "lfdmi_remove_stars", "lfdmi_process_bright", "lfdmi_process_dim",
-    "lfdmi_detect_batch", "lfdmi_detect_batch_raw", "lfdmi_host_alloc", "lfdmi_host_free", "lfdmi_fits_read_frames", "lfdmi_fits_read_photoobj", "lfdmi_set_stage_images", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_timing_select", "lfdmi_get_timing",
+    "lfdmi_detect_batch", "lfdmi_detect_batch_raw", "lfdmi_host_alloc", "lfdmi_host_free", "lfdmi_fits_read_frames", "lfdmi_fits_read_photoobj", "lfdmi_bz2_find_blocks", "lfdmi_set_stage_images", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_timing_select", "lfdmi_get_timing",
     "lfdmi_timing_slots", "lfdmi_timing_name",
 )
 
@@ -107,6 +107,8 @@ def lib():
         _lib.lfdmi_spill_count.restype = C.c_int64
         _lib.lfdmi_spill_count.argtypes = [C.c_void_p]
         _lib.lfdmi_timing_name.restype = C.c_char_p
+        _lib.lfdmi_bz2_find_blocks.restype = C.c_int64
+        _lib.lfdmi_bz2_find_blocks.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64]
     return _lib
 
 

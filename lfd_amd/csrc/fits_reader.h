@@ -308,3 +308,40 @@ extern "C" int lfdmi_fits_read_photoobj(const char *const *paths, int n, int max
     });
     return 0;
 }
+
+// Bit offsets of every 48-bit bzip2 block magic (0x314159265359) and end-of-stream magic (0x177245385090) in data[0 .. n):
+// out[i] = bit offset * 2 + (1 for an end-of-stream magic), ascending; returns how many there are (only the first `cap` are
+// stored).  Host code, no GPU: the first step of decoding the blocks of a .fits.bz2 frame side by side
+// (lfd_amd/detecttrails/bz2blocks.py; the reference shells out to bunzip2, detecttrails.py:81-109).  A 64-bit window slides
+// over the file one byte at a time; the magic can start at any of the eight bit positions of a byte.
+extern "C" int64_t lfdmi_bz2_find_blocks(const uint8_t *data, uint64_t n, uint64_t *out, int64_t cap) {
+    if (!data || (!out && cap > 0) || cap < 0) return LFDMI_ERR_ARG;
+    const uint64_t BLK = 0x314159265359ull, EOS = 0x177245385090ull, M48 = 0xFFFFFFFFFFFFull;
+    int64_t found = 0;
+    // A magic whose last bit lies in byte i (k bits before the byte's end, k = 0 .. 7) covers byte i - 1 completely when k >= 1 and
+    // byte i when k == 0: that byte's value is known per alignment, so one table look-up per byte says which of the eight
+    // alignments are worth the full 48-bit comparison (3 % of the bytes: eight candidates of 1 / 256 each).
+    uint8_t cand_prev[256] = {0}, cand_cur[256] = {0}; // bit k set: alignment k is possible given byte i - 1 / byte i
+    for (uint64_t m : {BLK, EOS}) {
+        cand_cur[m & 0xFF] |= 1;                                   // k = 0: byte i is the magic's last byte
+        for (int k = 1; k < 8; k++) cand_prev[(m >> (8 - k)) & 0xFF] |= (uint8_t)(1u << k); // byte i - 1 = magic bits [8 - k, 16 - k) from its end
+    }
+    uint64_t acc = 0; // the last 8 bytes read, big-endian
+    for (uint64_t i = 0; i < n; i++) {
+        acc = (acc << 8) | data[i];
+        if (i < 6) continue;
+        unsigned ks = cand_cur[acc & 0xFF] | cand_prev[(acc >> 8) & 0xFF];
+        while (ks) {
+            const int k = __builtin_ctz(ks);
+            ks &= ks - 1;
+            const uint64_t v = (acc >> k) & M48; // 48 bits ending k bits before the end of byte i
+            if (v == BLK || v == EOS) {
+                const uint64_t end_bit = (i + 1) * 8 - k; // bit offset just past the magic
+                if (end_bit < 48) continue;
+                if (found < cap) out[found] = ((end_bit - 48) << 1) | (v == EOS ? 1u : 0u);
+                found++;
+            }
+        }
+    }
+    return found;
+}

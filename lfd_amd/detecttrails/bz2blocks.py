@@ -55,13 +55,29 @@ def _find_all(data, pattern):
     return sorted(out)
 
 
+def _find_magics(data, a):
+    """(block starts, end-of-stream marks) as bit offsets: the library's native scan (no interpreter lock held), or the
+    pure-Python search where the library cannot be loaded (it is host code: no GPU needed)."""
+    try:
+        from .. import _native
+        lib = _native.lib()
+    except (ImportError, OSError):
+        return _find_all(data, _BLOCK), _find_all(data, _EOS)
+    cap = 4096
+    out = np.zeros(cap, np.uint64)
+    n = lib.lfdmi_bz2_find_blocks(a.ctypes.data, len(data), out.ctypes.data, cap)
+    if n < 0 or n > cap:
+        return _find_all(data, _BLOCK), _find_all(data, _EOS)
+    v = out[:n]
+    return [int(x >> 1) for x in v if not (int(x) & 1)], [int(x >> 1) for x in v if int(x) & 1]
+
+
 def split_blocks(data):
     """[(one-block bzip2 stream), ...] of a single-stream bzip2 file, or None when the file is not one plain stream."""
     if len(data) < 14 or data[:3] != b"BZh" or not (0x31 <= data[3] <= 0x39):
         return None
     a = np.frombuffer(data, np.uint8)
-    starts = _find_all(data, _BLOCK)
-    ends = _find_all(data, _EOS)
+    starts, ends = _find_magics(data, a)
     if not starts or starts[0] != 32 or len(ends) != 1 or ends[0] < starts[-1]:   # (several end marks: concatenated streams)
         return None
     eos = ends[0]
@@ -113,11 +129,8 @@ def shared_pool():
     on up to 16 of the cores this process may run on)."""
     global _POOL
     if _POOL is None:
-        import os
         from concurrent.futures import ThreadPoolExecutor
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except (AttributeError, OSError):
-            cores = os.cpu_count() or 1
+        from .. import usable_cores
+        cores = usable_cores()
         _POOL = ThreadPoolExecutor(max(2, min(16, cores)), thread_name_prefix="lfd-bz2")
     return _POOL

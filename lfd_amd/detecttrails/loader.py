@@ -113,11 +113,9 @@ class FrameLoader:
         self.max_obj = int(max_obj)
         h, w = self.shape
         self.frame_bytes = h * w * 4
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except (AttributeError, OSError):
-            cores = os.cpu_count() or 1
-        # this rank's share of the host: every core it may run on, divided among the ranks torchrun started on this node
+        from .. import usable_cores
+        cores = usable_cores()
+        # this rank's share of the host: every core it may use (affinity mask and cgroup quota), divided among the ranks torchrun started on this node
         share = max(1, cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", 1))))
         self.threads = int(threads or os.environ.get("LFD_LOADER_THREADS", 0) or max(2, min(64, share)))
         self.lib = _native.lib()
@@ -130,11 +128,13 @@ class FrameLoader:
             c["count"] = np.zeros(self.slots, np.int32)
             self.cats.append(c)
         self.hdrs = [np.zeros((self.slots, HDR_CAP), np.uint8) for _ in range(2)]
-        # .bz2 frames and other exceptions to the fast path: a few files at a time, the ~14 bzip2 blocks of each decoded side by side
-        # on all of the rank's cores (bz2blocks; libbz2 releases the interpreter lock) -- round 3 decoded whole files on at most
-        # 16 threads: a small selection waited ~0.4 s per frame on one core, and half of a rank's 32 cores idled
-        self.pool = ThreadPoolExecutor(max(2, min(self.threads, 8)), thread_name_prefix="lfd-slow")
+        # .bz2 frames and other exceptions to the fast path, one thread per usable core (libbz2 releases the interpreter lock).  A
+        # chunk with at least as many .bz2 frames as threads decodes whole files, one per thread (nothing is cheaper per frame);
+        # a smaller selection has the ~14 bzip2 blocks of each file decoded side by side (bz2blocks), so that one frame does not
+        # wait ~0.4 s on one core while the others idle.  (Round 3 capped the pool at 16 threads whatever the rank's share.)
+        self.pool = ThreadPoolExecutor(max(2, self.threads), thread_name_prefix="lfd-slow")
         self.block_pool = ThreadPoolExecutor(max(2, self.threads), thread_name_prefix="lfd-bz2")
+        self.split_blocks = True
 
     def close(self):
         self.pool.shutdown(wait=True)
@@ -167,7 +167,8 @@ class FrameLoader:
                     raise FileNotFoundError(("File {0} or its bz2 compressed version not found. "
                                              "Are you sure they exist?").format(path))
                 with open(path + ".bz2", "rb", buffering=0) as f:
-                    raw = bz2blocks.decompress(f.read(), self.block_pool)   # in memory; no $FITS_DUMP round trip (detecttrails.py:88-109)
+                    # in memory; no $FITS_DUMP round trip (detecttrails.py:88-109)
+                    raw = bz2blocks.decompress(f.read(), self.block_pool if self.split_blocks else None)
                 end = header_end(raw)
                 if end < 0 or len(raw) < end:
                     raise ValueError("truncated FITS header")
@@ -239,6 +240,7 @@ class FrameLoader:
         if rc:
             raise _native.NativeError(rc, "lfdmi_fits_read_photoobj")
         futs = []
+        self.split_blocks = int((fstat != 0).sum()) < self.threads   # (few files for many cores: their blocks side by side)
         for slot, i in enumerate(order):
             st = int(fstat[slot])
             if st == 0:

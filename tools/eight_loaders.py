@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 
-def worker(rank, ranks, cpus, root, seconds, with_copy, nfields, q, barrier):
+def worker(rank, ranks, cpus, threads, root, seconds, with_copy, nfields, q, barrier):
     os.sched_setaffinity(0, cpus)
     os.environ["PHOTO_REDUX"] = os.path.join(root, "photo", "redux")
     os.environ["BOSS_PHOTOOBJ"] = os.path.join(root, "photoObj")
@@ -34,7 +34,6 @@ def worker(rank, ranks, cpus, root, seconds, with_copy, nfields, q, barrier):
     cnt, st, pst, hl = (np.zeros(slots, np.int32) for _ in range(4))
     hdr = np.zeros((slots, loader.HDR_CAP), np.uint8)
     P = _native._ptr
-    threads = len(cpus)
     fields = [100 + (rank * 997 + i) % nfields for i in range(nfields)]
     copied = [0]
     stop = threading.Event()
@@ -74,17 +73,18 @@ def worker(rank, ranks, cpus, root, seconds, with_copy, nfields, q, barrier):
         k += 1
     dt = time.perf_counter() - t0
     stop.set()
-    q.put((rank, frames / dt, frames * fb / dt / 1e9, copied[0], len(cpus)))
+    q.put((rank, frames / dt, frames * fb / dt / 1e9, copied[0], threads))
 
 
 def main():
     ranks = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
     nd = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-    from lfd_amd import synth
+    from lfd_amd import synth, usable_cores
     cpus = sorted(os.sched_getaffinity(0))
-    print("host: %d CPUs in this process's affinity mask (os.cpu_count() = %d); cgroup cpu.max: %s" % (
-        len(cpus), os.cpu_count(), (open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "n/a")), flush=True)
+    usable = usable_cores()
+    print("host: %d CPUs in this process's affinity mask (os.cpu_count() = %d); cgroup cpu.max: %s -> %d cores' worth of CPU time usable" % (
+        len(cpus), os.cpu_count(), (open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "n/a"), usable), flush=True)
     frames, cats = synth.make_frames(0, nd, synth.SDSS_SHAPE)
     root = tempfile.mkdtemp(prefix="lfd_8load_", dir="/dev/shm")
     nfields = 1024
@@ -94,18 +94,19 @@ def main():
         for r in sorted({1, ranks}):
             for with_copy in (False, True):
                 per = max(1, len(cpus) // r)
+                threads = max(1, usable // r)             # (reader threads per process: the usable cores shared out, never more than the quota)
                 q = mp.Queue()
                 barrier = mp.Barrier(r)
-                procs = [mp.Process(target=worker, args=(i, r, set(cpus[i * per:(i + 1) * per]), root, seconds, with_copy, nfields, q, barrier)) for i in range(r)]
+                procs = [mp.Process(target=worker, args=(i, r, set(cpus[i * per:(i + 1) * per]), threads, root, seconds, with_copy, nfields, q, barrier)) for i in range(r)]
                 for p in procs:
                     p.start()
                 res = sorted(q.get() for _ in procs)
                 for p in procs:
                     p.join()
                 tot_f, tot_g = sum(x[1] for x in res), sum(x[2] for x in res)
-                print("%d loader process%s x %d threads%s: %s frames/s each, %.0f frames/s = %.1f GB/s in total" % (
+                print("%d loader process%s x %d threads%s: %s frames/s each, %.0f frames/s = %.1f GB/s in total (%.0f frames/s per reader thread)" % (
                     r, "es" if r > 1 else "", res[0][4], " + a copy of every filled buffer" if with_copy else "",
-                    "/".join("%.0f" % x[1] for x in res), tot_f, tot_g), flush=True)
+                    "/".join("%.0f" % x[1] for x in res), tot_f, tot_g, tot_f / (r * res[0][4])), flush=True)
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
