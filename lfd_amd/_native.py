@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblfdmi.so")
+LIB_PATH = os.environ.get("LFDMI_LIB") or os.path.join(_HERE, "csrc", "liblfdmi.so")   # ($LFDMI_LIB: a developer's variant build)
 
 HOST, DEVICE, HOST_PINNED = 0, 1, 2
 U8, F32, F64, F32_BE = 0, 1, 2, 3

@@ -70,11 +70,8 @@ __device__ __forceinline__ u64 start_bits(const u64 *row, int wq, int val, int W
 // Per segment k of the wave (words ((seg0 + k) << 6) + lane): run starts of the lane's word, "holds a candidate bit" (fg work
 // list) and "a 0-run can start or join here" (bg work list).  The word to the left comes from the neighbouring lane, the
 // first lane's from the previous segment's last lane.
-// fl[k] (lists only): bit 0 = last pixel of the word to the left, bit 1 = of the word up-left, bit 2 = first pixel of the word
-// up-right (0 outside the row / above row 0): the three neighbour bits the 8-connectivity merge of a candidate word needs
-// besides the word itself and the word above (k_frame_fg's item records)
 __device__ __forceinline__ void scan_words(const u64 *b, int seg0, int nseg, int nw, int wq, int val, int W, bool lists, int lane,
-                                           int *c, bool *tf, bool *tb, int *fl) {
+                                           int *c, bool *tf, bool *tb) {
     u64 cur[SCAN_SEGS], up[SCAN_SEGS];
     int yy[SCAN_SEGS], qq[SCAN_SEGS];
     bool in[SCAN_SEGS];
@@ -112,63 +109,17 @@ __device__ __forceinline__ void scan_words(const u64 *b, int seg0, int nseg, int
         u64 cc = (val ? cur[k] : ~cur[k]) & valid_mask(q, W);
         const u64 pm = q > 0 ? ((val ? prev : ~prev) >> 63) : 0ull;
         c[k] = in[k] ? __popcll(cc & ~((cc << 1) | pm)) : 0;
-        tf[k] = false; tb[k] = false; fl[k] = 0;
-        if (lists) { // (wave-uniform: the shuffles below are executed by every lane)
-            // first pixel of the word up-right: the next lane's `up`, lane 63's from the next segment's lane 0 (the last
-            // segment's lane 63 loads it)
-            u64 unx = __shfl_down(up[k], 1);
-            {
-                const u64 nxt0 = k + 1 < SCAN_SEGS ? (u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)up[k + 1 < SCAN_SEGS ? k + 1 : k], 0) : 0ull;
-                if (lane == 63) {
-                    if (k + 1 < SCAN_SEGS) unx = nxt0;
-                    else { const int i = ((seg0 + k) << 6) + 64; unx = (i < nw && i - wq >= 0) ? b[i - wq] : 0ull; }
-                }
-            }
-            if (in[k]) {
-                u64 m = cur[k];
-                tf[k] = m != 0;
-                if (q > 0) m |= prev >> 63;
-                if (y > 0) { m |= up[k]; if (q > 0) m |= upprev >> 63; }
-                tb[k] = (m != 0) || (q == 0);
-                fl[k] = (q > 0 ? (int)(prev >> 63) : 0) | ((y > 0 && q > 0) ? (int)(upprev >> 63) << 1 : 0) |
-                        ((y > 0 && q + 1 < wq) ? (int)(unx & 1ull) << 2 : 0);
-            }
+        tf[k] = false; tb[k] = false;
+        if (lists && in[k]) {
+            u64 m = cur[k];
+            tf[k] = m != 0;
+            if (q > 0) m |= prev >> 63;
+            if (y > 0) { m |= up[k]; if (q > 0) m |= upprev >> 63; }
+            tb[k] = (m != 0) || (q == 0);
         }
     }
 }
 
-
-// Item records of the candidate-word list (k_frame_fg): the wide scan kernels, which stream the bit plane anyway, leave for
-// every listed word what the per-frame kernel needs of it --
-//   recA[pos] = (word, word above),   recB[pos] = (strong bits of the word, idx | neighbour bits << 24, scan value)
-// -- so that ONE compute unit per frame reads a dense array with coalesced 16-byte loads instead of gathering seven
-// scattered words per item from memory other XCDs wrote (round 4: the gathers, not the union-find, were half of every
-// phase of the per-frame kernels).  rec_cap entries per slot; a frame with more listed words keeps to the gathers.
-#define REC_FLAG_SHIFT 24
-__device__ __forceinline__ void scan_write_records(const u64 *b, const u64 *strong, uint4 *ra, uint4 *rb, int rec_cap, int nw, int wq,
-                                                   int seg0, int nseg, int lane, const bool *tf, const int *fl, const int *pos,
-                                                   const int *id0) {
-#pragma unroll
-    for (int kb = 0; kb < SCAN_SEGS; kb += 4) { // four segments' reloads in flight together (the words are in L2: just read)
-        u64 cw[4], uw[4], mw[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = kb + j, i = ((seg0 + k) << 6) + lane;
-            const bool on = seg0 + k < nseg && tf[k] && pos[k] < rec_cap;
-            cw[j] = on ? b[i] : 0ull;
-            uw[j] = (on && i >= wq) ? b[i - wq] : 0ull;
-            mw[j] = (on && strong) ? strong[i] : 0ull;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = kb + j, i = ((seg0 + k) << 6) + lane;
-            if (seg0 + k < nseg && tf[k] && pos[k] < rec_cap) {
-                ra[pos[k]] = make_uint4((uint32_t)cw[j], (uint32_t)(cw[j] >> 32), (uint32_t)uw[j], (uint32_t)(uw[j] >> 32));
-                rb[pos[k]] = make_uint4((uint32_t)mw[j], (uint32_t)(mw[j] >> 32), (uint32_t)i | ((uint32_t)fl[k] << REC_FLAG_SHIFT), (uint32_t)id0[k]);
-            }
-        }
-    }
-}
 
 __global__ void __launch_bounds__(64 * SCANW_WAVES)
 k_scan_count(const u64 *bits, int val, int4 *segcnt, int h, int w, int lists, const int *active) {
@@ -177,8 +128,8 @@ k_scan_count(const u64 *bits, int val, int4 *segcnt, int h, int w, int lists, co
     const int wq = LFD_WQ(w), nw = h * wq, nseg = (nw + 63) >> 6;
     const int seg0 = (blockIdx.x * SCANW_WAVES + (threadIdx.x >> 6)) * SCAN_SEGS, lane = threadIdx.x & 63;
     if (seg0 >= nseg) return;
-    int c[SCAN_SEGS], fl[SCAN_SEGS]; bool tf[SCAN_SEGS], tb[SCAN_SEGS];
-    scan_words(bits + (size_t)g * nw, seg0, nseg, nw, wq, val, w, lists != 0, lane, c, tf, tb, fl);
+    int c[SCAN_SEGS]; bool tf[SCAN_SEGS], tb[SCAN_SEGS];
+    scan_words(bits + (size_t)g * nw, seg0, nseg, nw, wq, val, w, lists != 0, lane, c, tf, tb);
 #pragma unroll
     for (int k = 0; k < SCAN_SEGS; k++) {
         if (seg0 + k >= nseg) break;
@@ -228,14 +179,14 @@ k_scan_bases(int4 *segcnt, int *counters, int cidx, int h, int w, int run_cap, i
 
 __global__ void __launch_bounds__(64 * SCANW_WAVES)
 k_scan_write(const u64 *bits, int val, const int4 *segcnt, int *scan, int h, int w, int *wl_fg, int *wl_bg, u64 *clear,
-             const int *active, const u64 *strong, uint4 *recA, uint4 *recB, int rec_cap) {
+             const int *active) {
     int g = blockIdx.y;
     if (active && !active[g]) return;
     const int wq = LFD_WQ(w), nw = h * wq, nseg = (nw + 63) >> 6;
     const int seg0 = (blockIdx.x * SCANW_WAVES + (threadIdx.x >> 6)) * SCAN_SEGS, lane = threadIdx.x & 63;
     if (seg0 >= nseg) return;
-    int c[SCAN_SEGS], fl[SCAN_SEGS], rpos[SCAN_SEGS], rid[SCAN_SEGS]; bool tf[SCAN_SEGS], tb[SCAN_SEGS];
-    scan_words(bits + (size_t)g * nw, seg0, nseg, nw, wq, val, w, wl_fg != nullptr, lane, c, tf, tb, fl);
+    int c[SCAN_SEGS]; bool tf[SCAN_SEGS], tb[SCAN_SEGS];
+    scan_words(bits + (size_t)g * nw, seg0, nseg, nw, wq, val, w, wl_fg != nullptr, lane, c, tf, tb);
     int4 base[SCAN_SEGS];
 #pragma unroll
     for (int k = 0; k < SCAN_SEGS; k++) base[k] = seg0 + k < nseg ? segcnt[(size_t)g * SCAN_MAX_SEG + seg0 + k] : make_int4(0, 0, 0, 0);
@@ -248,21 +199,16 @@ k_scan_write(const u64 *bits, int val, const int4 *segcnt, int *scan, int h, int
             int t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
-        rpos[k] = 0; rid[k] = base[k].x + incl - c[k];
         if (wl_fg) {
             u64 bf = __ballot(tf[k]), bb = __ballot(tb[k]), lt = (1ull << lane) - 1ull;
-            rpos[k] = base[k].y + __popcll(bf & lt);
-            if (tf[k]) wl_fg[(size_t)g * nw + rpos[k]] = i;
+            if (tf[k]) wl_fg[(size_t)g * nw + base[k].y + __popcll(bf & lt)] = i;
             if (tb[k]) wl_bg[(size_t)g * nw + base[k].z + __popcll(bb & lt)] = i;
         }
         if (i < nw) {
-            scan[(size_t)g * nw + i] = rid[k];
+            scan[(size_t)g * nw + i] = base[k].x + incl - c[k];
             if (clear) clear[(size_t)g * nw + i] = 0ull;
         }
     }
-    if (recA && wl_fg)
-        scan_write_records(bits + (size_t)g * nw, strong ? strong + (size_t)g * nw : nullptr, recA + (size_t)g * rec_cap, recB + (size_t)g * rec_cap,
-                           rec_cap, nw, wq, seg0, nseg, lane, tf, fl, rpos, rid);
 }
 
 // The three scan kernels in one launch (round 3): a workgroup counts its 32 segments, publishes its totals, adds up the
@@ -281,15 +227,15 @@ k_scan_write(const u64 *bits, int val, const int4 *segcnt, int *scan, int h, int
 #define PASS_FLAG_SCAN_GAVEUP 512 // pass_flags bit (beside k_frame.h's PASS_FLAG_GENERAL): the look-back gave up on this frame
 __global__ void __launch_bounds__(64 * SCANW_WAVES)
 k_scan_fused(const u64 *bits, int val, u64 *partial, int epoch /* 1 .. 2^22 - 1 */, int max_spin, int *pass_flags, int *scan, int h, int w, int *wl_fg, int *wl_bg, u64 *clear,
-             int *counters, int cidx, int run_cap, const int *active, const u64 *strong, uint4 *recA, uint4 *recB, int rec_cap) {
+             int *counters, int cidx, int run_cap, const int *active) {
     const int g = blockIdx.y, bx = blockIdx.x;
     if (active && !active[g]) return;
     const int wq = LFD_WQ(w), nw = h * wq, nseg = (nw + 63) >> 6;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int seg0 = (bx * SCANW_WAVES + wv) * SCAN_SEGS;
     const bool lists = wl_fg != nullptr;
-    int c[SCAN_SEGS], fl[SCAN_SEGS]; bool tf[SCAN_SEGS], tb[SCAN_SEGS];
-    scan_words(bits + (size_t)g * nw, seg0, nseg, nw, wq, val, w, lists, lane, c, tf, tb, fl);
+    int c[SCAN_SEGS]; bool tf[SCAN_SEGS], tb[SCAN_SEGS];
+    scan_words(bits + (size_t)g * nw, seg0, nseg, nw, wq, val, w, lists, lane, c, tf, tb);
     int cs[SCAN_SEGS], nf[SCAN_SEGS], nb[SCAN_SEGS], incl[SCAN_SEGS];
     int wc = 0, wf = 0, wb = 0;
 #pragma unroll
@@ -354,28 +300,21 @@ k_scan_fused(const u64 *bits, int val, u64 *partial, int epoch /* 1 .. 2^22 - 1 
         atomicOr(&pass_flags[g], PASS_FLAG_SCAN_GAVEUP);
     }
     if (seg0 >= nseg) return;
-    int rpos[SCAN_SEGS], rid[SCAN_SEGS];
 #pragma unroll
     for (int k = 0; k < SCAN_SEGS; k++) {
-        rpos[k] = 0; rid[k] = 0;
-        if (seg0 + k >= nseg) continue;
+        if (seg0 + k >= nseg) break;
         const int i = ((seg0 + k) << 6) + lane;
-        rid[k] = rc + incl[k] - c[k];
         if (lists) {
             u64 bfm = __ballot(tf[k]), bbm = __ballot(tb[k]), lt = (1ull << lane) - 1ull;
-            rpos[k] = rf + __popcll(bfm & lt);
-            if (tf[k]) wl_fg[(size_t)g * nw + rpos[k]] = i;
+            if (tf[k]) wl_fg[(size_t)g * nw + rf + __popcll(bfm & lt)] = i;
             if (tb[k]) wl_bg[(size_t)g * nw + rb + __popcll(bbm & lt)] = i;
         }
         if (i < nw) {
-            scan[(size_t)g * nw + i] = rid[k];
+            scan[(size_t)g * nw + i] = rc + incl[k] - c[k];
             if (clear) clear[(size_t)g * nw + i] = 0ull;
         }
         rc += cs[k]; rf += nf[k]; rb += nb[k];
     }
-    if (recA && lists)
-        scan_write_records(bits + (size_t)g * nw, strong ? strong + (size_t)g * nw : nullptr, recA + (size_t)g * rec_cap, recB + (size_t)g * rec_cap,
-                           rec_cap, nw, wq, seg0, nseg, lane, tf, fl, rpos, rid);
 }
 
 // id of the `val`-run holding pixel (y, x) (the pixel must have that value)

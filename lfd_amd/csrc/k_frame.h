@@ -94,6 +94,10 @@ __device__ __forceinline__ void lds_union(int *L, int a, int b) {
     }
 }
 
+// (Round 4, measured and dropped: hooking without the two finds -- one atomicMin per contact, then carrying on with the larger
+// id's former parent -- walks the whole chain of a tall component on every later contact: merge 72 -> 172 us (median, a frame's
+// maximum 1 ms); and flattening by pointer jumping after the merge -- log2(rows) rounds of two LDS reads per run -- costs more
+// rounds than the walks it saves once the finds halve their paths: 4.44 vs 4.43 ms per step.  profiles/README.md.)
 // (Taking the items four at a time -- all of a block's loads issued back to back, the next block's list entries fetched
 // meanwhile -- measured 5-7 % SLOWER for both per-frame kernels: their phases are bound by the LDS label chains and the
 // memory-side atomics of the slot updates, not by the exposed HBM round trips, and the extra live registers cost more.)
@@ -136,25 +140,6 @@ __device__ __forceinline__ void frame_pipeline(const int *wl, int nwork, LoadF l
     frame_pipeline<Item>(wl, m, 0, load, proc);
 }
 
-// The same over list POSITIONS, for phases that read the item records the scan kernels left (k_ccl.h: scan_write_records):
-// dense, coalesced loads.  Two load stages: loadA(pos) reads the record, loadB(item) issues what depends on it (the scan value
-// of the word above, one gather); both run ahead of proc.
-template <class Item, class LoadA, class LoadB, class ProcF>
-__device__ __forceinline__ void frame_pipeline_rec(int nwork, LoadA loadA, LoadB loadB, ProcF proc) {
-    int p0 = threadIdx.x, p1 = p0 + FRAME_THREADS, p2 = p1 + FRAME_THREADS;
-    Item cur, nxt, nn;
-    if (p0 < nwork) cur = loadA(p0);
-    if (p1 < nwork) nxt = loadA(p1);
-    if (p0 < nwork) loadB(cur);
-    while (p0 < nwork) {
-        if (p2 < nwork) nn = loadA(p2);
-        if (p1 < nwork) loadB(nxt);
-        proc(cur);
-        cur = nxt; nxt = nn;
-        p0 = p1; p1 = p2; p2 += FRAME_THREADS;
-    }
-}
-
 // bits 0 .. b
 __device__ __forceinline__ u64 upto_bit(int b) { return (b == 63) ? ~0ull : ((2ull << b) - 1ull); }
 
@@ -176,7 +161,7 @@ struct FgWordItem { int idx, id0; u64 c, cp, m; };
 __global__ void __launch_bounds__(FRAME_THREADS)
 k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_fg, int *counters, int *Lf, int *YMf,
            int *FLf, int *ROWf, u64 *edge, int h, int w, int run_cap, int lds_cap, const int *active, int *fallback,
-           int *pass_flags, int lds_ints, const int *perm, long long *prof, const uint4 *recA, const uint4 *recB, int rec_cap,
+           int *pass_flags, int lds_ints, const int *perm, long long *prof,
            int4 *keys, int *bigkeys, int *medkeys, int2 *rowext, int key_cap, int slot_cap, int *fg_keys, int blocked) {
     // lds_ints: ints of dynamic LDS this launch allocated.  keys != nullptr: the contour stage follows (k_frame_contours): the
     // OUTER-border keys of the edge components, their row slots and the per-row extremes are made here, where the labels of the
@@ -215,25 +200,11 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
     int *YMg = YMf + ro, *ROWg = ROWf + ro;
     const u64 *fb = cand + fo, *mb = strong + fo;
     const int *sf = scanf + fo, *wl = wl_fg + fo;
-    // item records of this frame's list (the scan kernel wrote them when the list fits rec_cap): every phase then reads a
-    // dense array instead of gathering its words
-    const bool use_rec = recA != nullptr && nwork <= rec_cap;
-    const uint4 *ra = recA + (size_t)g * rec_cap, *rb = recB + (size_t)g * rec_cap;
-    auto rec_word_item = [&](int pos) { // (flatten / edge phases: everything is in the record)
-        FgWordItem t;
-        const uint4 a = ra[pos], b = rb[pos];
-        t.idx = (int)(b.z & ((1u << REC_FLAG_SHIFT) - 1u));
-        t.id0 = (int)b.w;
-        t.c = (u64)a.x | ((u64)a.y << 32);
-        t.cp = (u64)((b.z >> REC_FLAG_SHIFT) & 1u) << 63;
-        t.m = (u64)b.x | ((u64)b.y << 32);
-        return t;
-    };
     for (int i = threadIdx.x; i < (nrun + 31) / 32; i += FRAME_THREADS) { FL[i] = 0u; HB[i] = 0u; }
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) L[i] = i; // every run its own root
     __syncthreads();
     constexpr int FG_KC = 8;
-    const ItemMap im = item_map(nwork, blocked);
+    const ItemMap im = item_map(nwork, blocked & 1);
     const bool more = nwork > FG_KC * FRAME_THREADS; // (items beyond the register copies: gathered again in every phase)
     u64 kc_c[FG_KC];
     int kc_i[FG_KC], kc_x[FG_KC]; // id0 | (last pixel of the word to the left) << 31, idx
@@ -298,26 +269,7 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
                 join(own(b), b < 63 ? above(b + 1) : t.idu + __popcll(su));
             }
     };
-    if (use_rec)
-        frame_pipeline_rec<FgMergeItem>(
-            nwork,
-            [&](int pos) {
-                FgMergeItem t;
-                const uint4 a = ra[pos], b = rb[pos];
-                const unsigned fl = b.z >> REC_FLAG_SHIFT;
-                t.idx = (int)(b.z & ((1u << REC_FLAG_SHIFT) - 1u));
-                t.id0 = (int)b.w;
-                t.c = (u64)a.x | ((u64)a.y << 32);
-                t.u = (u64)a.z | ((u64)a.w << 32);
-                t.cp = (u64)(fl & 1u) << 63;         // (only the neighbour pixels the merge looks at)
-                t.up = (u64)((fl >> 1) & 1u) << 63;
-                t.un = (u64)((fl >> 2) & 1u);
-                t.idu = 0;
-                return t;
-            },
-            [&](FgMergeItem &t) { if (t.idx >= wq) t.idu = sf[t.idx - wq]; },
-            merge_proc);
-    else {
+    {
         // the thread's first FG_KC items: processed one behind the loads; word, scan value and left-neighbour bit stay in
         // registers for the two phases below (k_frame_contours does the same, see there)
         FgMergeItem cur, nxt;
@@ -387,8 +339,7 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
         t.idx = kc_x[k]; t.c = kc_c[k]; t.id0 = kc_i[k] & 0x7fffffff; t.cp = (u64)((unsigned)kc_i[k] >> 31) << 63; t.m = m;
         return t;
     };
-    if (use_rec) frame_pipeline_rec<FgWordItem>(nwork, rec_word_item, [](FgWordItem &) {}, flat_proc);
-    else {
+    {
         u64 mk[FG_KC]; // the strong bits of the thread's items: the only loads of this phase, all in flight together
 #pragma unroll
         for (int k = 0; k < FG_KC; k++) mk[k] = kc_x[k] >= 0 ? mb[kc_x[k]] : 0ull;
@@ -499,12 +450,9 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
             edge[fo + t.idx] = res;
     };
     if (keys_path) {
-        if (use_rec) frame_pipeline_rec<FgWordItem>(nwork, rec_word_item, [](FgWordItem &) {}, edge_keys_proc);
-        else {
 #pragma unroll
-            for (int k = 0; k < FG_KC; k++) if (kc_x[k] >= 0) edge_keys_proc(cached_item(k, 0ull));
-            if (more) frame_pipeline<FgWordItem>(wl, im, FG_KC, edge_load, edge_keys_proc);
-        }
+        for (int k = 0; k < FG_KC; k++) if (kc_x[k] >= 0) edge_keys_proc(cached_item(k, 0ull));
+        if (more) frame_pipeline<FgWordItem>(wl, im, FG_KC, edge_load, edge_keys_proc);
         __syncthreads();
         if (lds_slots) for (int i = threadIdx.x; i < n_slots; i += FRAME_THREADS) re[i] = make_int2(SL[2 * i], SL[2 * i + 1]);
         if (threadIdx.x == 0) {
@@ -518,12 +466,9 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
         FG_PROF(); // 11: edge bits + outer extremes
         return;
     }
-    if (use_rec) frame_pipeline_rec<FgWordItem>(nwork, rec_word_item, [](FgWordItem &) {}, edge_proc);
-    else {
 #pragma unroll
-        for (int k = 0; k < FG_KC; k++) if (kc_x[k] >= 0) edge_proc(cached_item(k, 0ull));
-        if (more) frame_pipeline<FgWordItem>(wl, im, FG_KC, edge_load, edge_proc);
-    }
+    for (int k = 0; k < FG_KC; k++) if (kc_x[k] >= 0) edge_proc(cached_item(k, 0ull));
+    if (more) frame_pipeline<FgWordItem>(wl, im, FG_KC, edge_load, edge_proc);
     FG_PROF(); // 10: edge bits
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
         int root = L[i];

@@ -153,15 +153,18 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     constexpr int aw_log2 = AWL;
     int g = blockIdx.z, im = blockIdx.y;
     int slab = blockIdx.x / nsplit, split = blockIdx.x - slab * nsplit;
-    if (slot_off(active, counters, g)) return;
+    // everything this workgroup decides on, requested at once (seven independent loads: one round trip, not a chain of four)
     const int *cnt = counters + g * C_COUNT;
-    if (need_detect && !cnt[C_DETECT]) return;
+    const int on_ = active ? active[g] : 1, ovf_ = cnt[C_OVERFLOW], det_ = cnt[C_DETECT];
+    const int na_e = cnt[C_NPIX_EQU], na_b = cnt[C_NPIX_BOX], nb_e = cnt[C_NPIXB_EQU], nb_b = cnt[C_NPIXB_BOX];
+    if (!on_ || ovf_) return; // (slot_off)
+    if (need_detect && !det_) return;
+    const int cls = (slab < VOTE_MAX_SLABS) ? (int)((rng.cls_b >> slab) & 1u) : 0; // the chunk list this slab's angles may vote with
     if (balance) {
         // gridDim.y == 1 and the nsplit pieces of a slab are shared out between the TWO images in proportion to their list
         // lengths (equ's list is about three times box_img's): every workgroup of a frame then gets about the same number of
         // chunks, whatever XCD it lands on, instead of half the workgroups finishing in a third of the time of the others
-        const int cls_ = (slab < VOTE_MAX_SLABS) ? (int)((rng.cls_b >> slab) & 1u) : 0;
-        const int n0 = cnt[cls_ ? C_NPIXB_EQU : C_NPIX_EQU], n1 = cnt[cls_ ? C_NPIXB_BOX : C_NPIX_BOX];
+        const int n0 = cls ? nb_e : na_e, n1 = cls ? nb_b : na_b;
         int s0 = (n0 + n1) > 0 ? (int)(((long long)nsplit * n0 + (n0 + n1) / 2) / (n0 + n1)) : nsplit / 2;
         s0 = max(1, min(nsplit - 1, s0));
         if (split < s0) { im = 0; nsplit = s0; }
@@ -173,26 +176,31 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     int na = min(AW, numangle - a0);
     const int lo = slab < VOTE_MAX_SLABS ? rng.lo[slab] : -((numrho - 1) / 2);
     const int nb = (slab < VOTE_MAX_SLABS ? rng.hi[slab] : numrho - 1 - (numrho - 1) / 2) - lo + 1;
-    const int cls = (slab < VOTE_MAX_SLABS) ? (int)((rng.cls_b >> slab) & 1u) : 0; // the chunk list this slab's angles may vote with
-    int n = cnt[cls ? (im ? C_NPIXB_BOX : C_NPIXB_EQU) : (im ? C_NPIX_BOX : C_NPIX_EQU)];
+    int n = cls ? (im ? nb_b : nb_e) : (im ? na_b : na_e);
     if ((size_t)n > list_cap) n = (int)list_cap;
     int per = ((n + nsplit - 1) / nsplit + 63) / 64 * 64;
     int begin = min(n, split * per), end = min(n, begin + per);
     const bool merge = balance || nsplit > 1; // pieces of a list are merged with atomic adds into a zeroed accumulator
     if (merge && begin >= end) return; // nothing to add
-    for (int k = threadIdx.x; k < nb * AW + 64; k += VOTE_THREADS) acc[k] = 0;
-    __syncthreads();
     const uint32_t *list = (im ? list1 : list0) + ((size_t)g * 2 + cls) * list_cap;
     int lane = threadIdx.x & 63;
     int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the wave's first 64 list entries and the lane's trig values are on their way while the slab is being zeroed
+    const int NT = (int)blockDim.x; // (the host picks the workgroup size: 1024 threads by default)
+    const int nw_ = NT / 64, share_ = (end - begin + nw_ - 1) / nw_;
+    const int wbeg_ = begin + wv * share_, wend_ = min(end, wbeg_ + share_);
+    const uint32_t pv_first = (wbeg_ + lane < wend_) ? list[wbeg_ + lane] : 0u;
+    float c_pre = 0.f, s_pre = 0.f;
+    if ((lane & (AW - 1)) < na) { c_pre = tab[a0 + (lane & (AW - 1))]; s_pre = tab[numangle + a0 + (lane & (AW - 1))]; }
+    for (int k = threadIdx.x; k < nb * AW + 64; k += NT) acc[k] = 0;
+    __syncthreads();
     // lane = (chunk slot, angle): a slab of AW < 64 angles (large accumulators: the slab's rows x AW must fit in LDS) lets
     // every wave work on 64 / AW chunks side by side instead of idling the lanes beyond AW
     constexpr int SUBS = 64 >> aw_log2;
     const int ang = lane & (AW - 1), sub = lane >> aw_log2;
     bool act = ang < na;
-    float c = 0.f, s = 0.f;
-    if (act) { c = tab[a0 + ang]; s = tab[numangle + a0 + ang]; }
-    const int nw = VOTE_THREADS / 64;
+    const float c = c_pre, s = s_pre;
+    const int nw = NT / 64;
     // |r| <= (numrho-1)/2 by construction (numrho ~ 2(w+h)/rho, |j cos + i sin| < w+h), as in
     // OpenCV, which indexes its accumulator without a range check.
     // Vote address (bytes) = (rint(v) << (aw_log2+2)) + lanebase.  rint (round-half-even,
@@ -223,7 +231,7 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     const int wbeg = begin + wv * share, wend = min(end, wbeg + share);
     for (int base = wbeg; base < wend; base += 64) {
         int m = min(64, wend - base);
-        uint32_t pv = (lane < m) ? list[base + lane] : 0u;
+        uint32_t pv = base == wbeg ? pv_first : ((lane < m) ? list[base + lane] : 0u);
         // every lane converts its own entry once; the wave then walks the entries with v_readlane (one chunk per step,
         // SUBS == 1) or fetches its slot's entry with ds_bpermute (SUBS chunks per step)
         const int lenv = (int)(pv >> 26);                       // len - 1
@@ -297,25 +305,25 @@ k_hough_vote(const uint32_t *list0, const uint32_t *list1, const int *counters, 
     const int ts = numangle + 2; // transposed row length
     const int r0 = (numrho - 1) / 2 + lo; // accumulator row of the slab's first bin
     if (merge) {
-        for (int k = threadIdx.x; k < nb * AW; k += VOTE_THREADS) {
+        for (int k = threadIdx.x; k < nb * AW; k += NT) {
             int rr = r0 + (k >> aw_log2), al = k & (AW - 1);
             int v = acc[k];
             if (v && al < na) atomicAdd(&ag[(size_t)(rr + 1) * ts + a0 + al + 1], v);
         }
         return;
     }
-    for (int k = threadIdx.x; k < numrho * AW; k += VOTE_THREADS) { // rows outside lo .. hi are zero
+    for (int k = threadIdx.x; k < numrho * AW; k += NT) { // rows outside lo .. hi are zero
         int rr = k >> aw_log2, al = k & (AW - 1);
         int rl = rr - r0;
         if (al < na) ag[(size_t)(rr + 1) * ts + a0 + al + 1] = (rl >= 0 && rl < nb) ? acc[rl * AW + al] : 0;
     }
     // guard cells: bins -1 and numrho for this slab's angles; angles -1 and numangle for all bins
-    for (int k = threadIdx.x; k < na; k += VOTE_THREADS) {
+    for (int k = threadIdx.x; k < na; k += NT) {
         ag[a0 + k + 1] = 0;
         ag[(size_t)(numrho + 1) * ts + a0 + k + 1] = 0;
     }
     if (slab == 0)
-        for (int k = threadIdx.x; k < numrho + 2; k += VOTE_THREADS) { ag[(size_t)k * ts] = 0; ag[(size_t)k * ts + ts - 1] = 0; }
+        for (int k = threadIdx.x; k < numrho + 2; k += NT) { ag[(size_t)k * ts] = 0; ag[(size_t)k * ts + ts - 1] = 0; }
 }
 
 // findLocalMaximums on the transposed accumulator: key = votes << 32 | (0x7fffffff - base) with

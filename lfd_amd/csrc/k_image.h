@@ -1895,8 +1895,11 @@ k_dc_tiles(const u64 *cellbm, int bm_bands, const uint8_t *lut, int *tile_list, 
 // 5 Sobel, 6 NMS + stores, and (slot 7) the number of tiles that ran the stages.  The shipped kernel is the PROF = false one.
 // KH, KW > 0: the structuring element's size as compile-time constants (the defaults of the two passes, 4 x 4 and 9 x 9, are
 // instantiated: unrolled running maxima by doubling); 0, 0: any size, run-time loops.
+#ifndef DCT_MIN_WAVES
+#define DCT_MIN_WAVES 5
+#endif
 template <bool PROF, int KH, int KW>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DCT_MIN_WAVES, 8)))
 k_dilate_canny_t(const uint8_t *src, uint8_t *equ, u64 *equb, u64 *cand, u64 *strong, const uint8_t *lut, int h, int w,
                  int kh, int kw, int low, int high, const int *active, int nc, int parts, const int *tile_list, int tile_cap,
                  const int *counters, long long *prof, const int *perm) {

@@ -94,9 +94,6 @@ struct lfdmi_ctx {
     bool delta_dim = true;             // LFDMI_DELTA_DIM=0: the dim pass of lfdmi_detect_batch converts the float frames again
     int delta_state = 0;               // 1: this bright pass also writes dbits / hist2; 2: this dim pass starts from them
     int dual_state = 0;                // 0: none; 1: the next run_front is a bright pass that also feeds the dim pass; 2: dim pass already fed
-    uint4 *recA = nullptr, *recB = nullptr; // item records of the candidate-word list (k_ccl.h: scan_write_records), rec_cap per slot
-    int rec_cap = 0;
-    bool use_rec = false;              // LFDMI_FRAME_REC=1: the scan kernel leaves item records for k_frame_fg (measured: -0.03 ms in k_frame_fg, +0.08 ms in the scans)
     int2 *rsa = nullptr;               // k_frame_contours: (row slot, component) per candidate run, FRAME_RUNCAP per slot
     long long *prof = nullptr;         // LFDMI_FRAME_PROFILE=1: per-frame phase clocks of k_frame_contours (developer tool)
     u64 *cellbm = nullptr;             // cell occupancy of the last prep output, bm_bands x CELLBM_WORDS words per slot
@@ -404,11 +401,6 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_DC_SPECIALIZE")) ctx->dc_specialize = atoi(e) != 0;
     if (getenv("LFDMI_FRAME_PROFILE") || ctx->dc_profile) RET(dmalloc(ctx, &ctx->prof, G * 16));
     RET(dmalloc(ctx, &ctx->rsa, G * FRAME_RUNCAP));
-    if (const char *e = getenv("LFDMI_FRAME_REC")) ctx->use_rec = atoi(e) != 0;
-    ctx->rec_cap = (int)std::min<size_t>(BW, std::max<size_t>(4096, BW / 4)); // (sky frames list ~1/6 of their words; busier frames gather)
-    if (const char *e = getenv("LFDMI_REC_CAP")) ctx->rec_cap = std::max(1, std::min((int)BW, atoi(e))); // (tests of the gather path)
-    RET(dmalloc(ctx, &ctx->recA, G * ctx->rec_cap));
-    RET(dmalloc(ctx, &ctx->recB, G * ctx->rec_cap));
     ctx->bm_bands = (max_h + CELLBM_ROWS - 1) / CELLBM_ROWS;
     if (const char *e = getenv("LFDMI_CELLBM")) ctx->use_cellbm = atoi(e) != 0;
     ctx->tile_cap = ((max_h + DCW_TH - 1) / DCW_TH) * ((max_w + CANNY_TW - 1) / CANNY_TW);
@@ -489,7 +481,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     HIPCHK(hipFuncSetAttribute((const void *)k_hough_vote<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_rects_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     HIPCHK(hipFuncSetAttribute((const void *)k_dilate_canny_v, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_frame_fg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute((const void *)k_frame_fg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); // (the kernel has a few hundred bytes of static LDS)
     HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_prep_erode<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
@@ -915,9 +907,7 @@ static int run_morph(lfdmi_ctx *ctx, const uint8_t *src, uint8_t *dst, u64 *bits
 // Canny = NMS bit rows + hysteresis by run labelling; leaves edge bits in ctx->edgeb and the
 // per-word run-count scan (compact run ids) + work lists + clearing of a sparse bit image: three wide kernels
 static int run_scan(lfdmi_ctx *ctx, const u64 *bits, int val, int *scan, int cidx, int nc, int h, int w, int *wl_fg, int *wl_bg,
-                    u64 *clear, const int *active, const u64 *strong = nullptr) {
-    // (with the work lists: item records for k_frame_fg, see k_ccl.h)
-    uint4 *recA = (wl_fg && ctx->use_rec && ctx->frame_ccl) ? ctx->recA : nullptr, *recB = recA ? ctx->recB : nullptr;
+                    u64 *clear, const int *active) {
     int nseg = (h * LFD_WQ(w) + 63) / 64;
     dim3 grid((nseg + SCANW_WAVES * SCAN_SEGS - 1) / (SCANW_WAVES * SCAN_SEGS), nc);
     if (ctx->scan_fused && (int)grid.x <= SCAN_MAX_BLK) { // count + bases + write in one launch (k_scan_fused)
@@ -926,7 +916,7 @@ static int run_scan(lfdmi_ctx *ctx, const u64 *bits, int val, int *scan, int cid
             ctx->scan_epoch = 1;
         }
         k_scan_fused<<<grid, 64 * SCANW_WAVES, 0, ctx->stream>>>(bits, val, ctx->scan_partial, ctx->scan_epoch, ctx->scan_spin, ctx->pass_flags, scan, h, w, wl_fg, wl_bg, clear,
-                                                                  ctx->counters, cidx, ctx->run_cap, active, strong, recA, recB, ctx->rec_cap);
+                                                                  ctx->counters, cidx, ctx->run_cap, active);
         KCHK("k_scan_fused");
         return 0;
     }
@@ -934,7 +924,7 @@ static int run_scan(lfdmi_ctx *ctx, const u64 *bits, int val, int *scan, int cid
     KCHK("k_scan_count");
     k_scan_bases<<<nc, SCAN_THREADS, 0, ctx->stream>>>(ctx->segcnt, ctx->counters, cidx, h, w, ctx->run_cap, wl_fg != nullptr, active);
     KCHK("k_scan_bases");
-    k_scan_write<<<grid, 64 * SCANW_WAVES, 0, ctx->stream>>>(bits, val, ctx->segcnt, scan, h, w, wl_fg, wl_bg, clear, active, strong, recA, recB, ctx->rec_cap);
+    k_scan_write<<<grid, 64 * SCANW_WAVES, 0, ctx->stream>>>(bits, val, ctx->segcnt, scan, h, w, wl_fg, wl_bg, clear, active);
     KCHK("k_scan_write");
     return 0;
 }
@@ -955,7 +945,7 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
     dim3 lg(WORDLIST_BLOCKS, nc);
     int rc = ctx->run_cap;
     { Span sp(ctx, KID_RUNS_INIT_FG);
-      RET(run_scan(ctx, ctx->candb, 1, ctx->scanf_, C_NRUNF, nc, h, w, ctx->wl_fg, ctx->wl_bg, ctx->edgeb, active, ctx->strongb));
+      RET(run_scan(ctx, ctx->candb, 1, ctx->scanf_, C_NRUNF, nc, h, w, ctx->wl_fg, ctx->wl_bg, ctx->edgeb, active));
     }
     RET(rs_fill_point(ctx, 3 + 10 * ctx->cur_pass));
     if (ctx->frame_ccl) { // frames that fit the LDS tables; the rest (fallback flag) take the kernels below
@@ -964,12 +954,11 @@ static int run_canny(lfdmi_ctx *ctx, const uint8_t *img, int nc, int h, int w, d
         // everything the CU has when the label table is at its full size
         const bool keys = want_keys && ctx->fg_keys_on;
         size_t lds = (size_t)(ctx->frame_lds + 2 * (ctx->frame_lds / 32)) * sizeof(int);
-        if (keys) lds = std::min<size_t>(2 * lds, 160 * 1024 - 512);
+        if (keys) lds = std::min<size_t>(2 * lds, 160 * 1024 - 1024);
         if (!keys) HIPCHK(hipMemsetAsync(ctx->fg_keys, 0, (size_t)nc * sizeof(int), ctx->stream));
         k_frame_fg<<<nc, FRAME_THREADS, lds, ctx->stream>>>(ctx->candb, ctx->strongb, ctx->scanf_, ctx->wl_fg, ctx->counters, ctx->Lf,
                                                             ctx->YMf, ctx->FLf, ctx->ROWf, ctx->edgeb, h, w, rc, ctx->frame_runcap, active, ctx->fb_fg,
                                                             ctx->pass_flags, (int)(lds / sizeof(int)), active ? ctx->perm_cur : nullptr, ctx->dc_profile ? nullptr : ctx->prof,
-                                                            ctx->use_rec ? ctx->recA : nullptr, ctx->recB, ctx->rec_cap,
                                                             keys ? ctx->keys : nullptr, ctx->bigkeys, ctx->medkeys, ctx->rowext, ctx->key_cap, ctx->slot_cap,
                                                             keys ? ctx->fg_keys : nullptr, (ctx->frame_dbg & 16) ? 1 : 0);
         KCHK("k_frame_fg");
@@ -1343,9 +1332,10 @@ static int run_hough(lfdmi_ctx *ctx, int nc, int h, int w, double rho, double th
         const int vsplit = balance ? 2 * nsplit : nsplit;
         dim3 vgrid(nslabs * vsplit, balance ? 1 : n_img, nc);
         size_t vlds = ((size_t)nbmax << aw_log2) * 4 + 256;
+        static const int vote_threads = getenv("LFDMI_VOTE_THREADS") ? std::max(64, std::min(1024, atoi(getenv("LFDMI_VOTE_THREADS")) & ~63)) : VOTE_THREADS; // developer knob
 #define LFD_LAUNCH_VOTE(L)                                                                                          \
     case L:                                                                                                         \
-        k_hough_vote<L><<<vgrid, VOTE_THREADS, vlds, ctx->stream>>>(ctx->pix_equ, ctx->pix_box, ctx->counters,           \
+        k_hough_vote<L><<<vgrid, vote_threads, vlds, ctx->stream>>>(ctx->pix_equ, ctx->pix_box, ctx->counters,           \
                                                                    ctx->tab + (size_t)ctx->tab_cur * 2 * MAX_ANGLES, \
                                                                    ctx->accum, na, nr, vsplit, ctx->list_cap,       \
                                                                    ctx->acc_cap, active, need_detect, rng, balance); \
