@@ -524,6 +524,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
     const int nwf = counters[g * C_COUNT + C_NFGW], nrunf = counters[g * C_COUNT + C_NRUNF];
     const bool fits = nrun <= lds_cap && nrunf <= lds_cap; // (then k_frame_fg took the frame too: FLf is set)
     const bool fgk = fg_keys != nullptr && fg_keys[g] != 0;
+    const int nkeys_fg = fgk ? min(counters[g * C_COUNT + C_NKEYS], key_cap) : 0; // (read before this kernel adds the holes' keys)
     if (threadIdx.x == 0) {
         fallback[g] = fits ? 0 : 1;
         if (!fits) {
@@ -791,6 +792,26 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
         }
     }
     __syncthreads(); // rsa, the hole table, SBb / PAb of this frame are written
+    // fgk: which holes have a component INSIDE them.  The edge pixels next to a hole B belong to the component around it (A) or
+    // to components whose own outside is B -- "islands": exactly the components whose raster-first pixel has a run of B to its
+    // left (a component next to B that is not A cannot be around B, so B is its exterior).  Only a hole with an island needs
+    // the "is this stretch part of A" test in the extremes below -- and with it the stretch's component label, a gather, and
+    // the candidate word and scan value that lead to it.  Sky frames: rings without islands almost everywhere.
+    unsigned *HI = HB; // (HB is not needed after the hole-extent phase)
+    if (fgk) {
+        for (int i = threadIdx.x; i < (nrun + 31) / 32; i += FRAME_THREADS) HI[i] = 0u;
+        __syncthreads();
+        for (int ki = threadIdx.x; ki < nkeys_fg; ki += FRAME_THREADS) {
+            const int4 key = kg[ki];                       // an outer-border key made by k_frame_fg: (root run, rows, first row, slot base)
+            const int y0 = key.z, x0 = re[key.w].x;        // the first row's left-most pixel: the component's raster-first pixel
+            if (x0 <= 0 || x0 >= w) continue;              // column 0: the exterior is the frame
+            const int bid = run_id(sb, fb, y0, x0 - 1, 0, wq, w);
+            if (bid < 0 || bid >= nrun || !((HL[bid >> 5] >> (bid & 31)) & 1u)) continue;
+            const int B = L[bid];
+            atomicOr(&HI[B >> 5], 1u << (B & 31));
+        }
+        __syncthreads();
+    }
     // Row extremes are min / max updates of (slot.x, slot.y), two per edge stretch and hole contact: as memory-side atomics they
     // were 40 % of this kernel.  The label table only uses its first nrun entries, so when the frame's slots fit into the rest
     // of it (they do on sky frames: a few thousand slots, 8 bytes each) the updates go to LDS and are copied out once at the end.
@@ -830,23 +851,24 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
         acc_flush(a);
         a.slot = slot; a.lo = xa; a.hi = xb;
     };
-    // A: the edge stretch's component, or -2 = not looked up yet (fgk: Lf[fid], fetched only when a hole is in reach)
-    auto hole_update = [&](SlotAcc &acc, int bid, int &A, int fid, int y, int xa, int xb) {
+    // A: the edge stretch's component, or -2 = not looked up yet (fgk: fetched by get_A only for a hole with an island inside)
+    auto hole_update = [&](SlotAcc &acc, int bid, int &A, auto get_A, int y, int xa, int xb) {
         if (dbg & 2) return;
         if (!((HL[bid >> 5] >> (bid & 31)) & 1u)) return; // a run of the outside
-        if (A == -2) A = Lfg[fid];
         int B = L[bid];
+        const bool check = !fgk || ((HI[B >> 5] >> (B & 31)) & 1u); // no island in B: every edge pixel next to it is the surrounding component's
+        if (check && A == -2) A = get_A();
         unsigned hs = ((unsigned)B * 2654435761u) >> 22;
         for (int probe = 0; probe < 16; probe++, hs = (hs + 1) & (FRAME_HOLECAP - 1)) {
             int kk = hkey[hs];
             if (kk == B) {
                 int2 v = hval[hs];
-                if (v.y == A && v.x != INT_MIN) acc_add(acc, v.x + y, xa, xb);
+                if ((!check || v.y == A) && v.x != INT_MIN) acc_add(acc, v.x + y, xa, xb);
                 return;
             }
             if (kk == -1) break;
         }
-        if (hovf && PAbg[B] == A && SBbg[B] >= 0) acc_add(acc, SBbg[B] + (y - (ROWbg[B] - 1)), xa, xb); // table was full
+        if (hovf && (!check || PAbg[B] == A) && SBbg[B] >= 0) acc_add(acc, SBbg[B] + (y - (ROWbg[B] - 1)), xa, xb); // table was full
     };
     frame_pipeline<ExtItem>(
         wlf, nwf,
@@ -856,8 +878,11 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
             k.idx = idx;
             word_pair(fb, idx, q > 0, ~0ull, k.ep, k.e); // "edge" left of column 0: no background run continues from there
             k.en = q + 1 < wq ? fb[idx + 1] : 0ull;
-            word_pair(cb, idx, q > 0, 0ull, k.cp, k.c);
-            k.id0 = sf[idx];
+            k.c = 0; k.cp = 0; k.id0 = 0;
+            if (!fgk) { // (fgk: the stretch's candidate run is only needed next to a hole with an island: fetched there)
+                word_pair(cb, idx, q > 0, 0ull, k.cp, k.c);
+                k.id0 = sf[idx];
+            }
             k.sbc = sb[idx];
             k.u = ~0ull; k.up = ~0ull; k.sbu = 0; k.d = ~0ull; k.dp = ~0ull; k.sbd = 0;
             if (y > 0) {
@@ -890,10 +915,18 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
                 u64 seg = (len >= 64 ? ~0ull : ((1ull << len) - 1)) << b;
                 rem &= ~seg;
                 int xs = (q << 6) + b, xe = xs + len - 1;
-                int fid = k.id0 + __popcll(sc & upto_bit(b)) - 1; // a stretch continuing from the previous word: id0 - 1
-                if (fid < 0 || fid >= nrunf) continue;
                 int A = -2;
+                auto get_A = [&]() -> int { // fgk: the component of this stretch's candidate run (label table of k_frame_fg, in memory)
+                    u64 cc, ccp;
+                    word_pair(cb, k.idx, q > 0, 0ull, ccp, cc);
+                    cc &= vmask;
+                    const u64 scc = cc & ~((cc << 1) | (ccp >> 63));
+                    const int f = sf[k.idx] + __popcll(scc & upto_bit(b)) - 1; // a stretch continuing from the previous word: id0 - 1
+                    return (f >= 0 && f < nrunf) ? Lfg[f] : -1;
+                };
                 if (!fgk) {
+                    int fid = k.id0 + __popcll(sc & upto_bit(b)) - 1; // a stretch continuing from the previous word: id0 - 1
+                    if (fid < 0 || fid >= nrunf) continue;
                     int2 ra = (dbg & 1) ? make_int2(fid & 1023, 0) : RSA[fid];
                     A = ra.y;
                     if (ra.x >= 0) acc_add(outer, ra.x, xs, xe);
@@ -901,9 +934,9 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
                 // same-row neighbours: the 0-pixel before the run and the one after it
                 bool starts = (se >> b) & 1ull;
                 bool ends = (b + len < 64) || q + 1 >= wq || !(k.en & 1ull);
-                if (starts && xs > 0) hole_update(hole, b ? k.sbc + __popcll(s0 & upto_bit(b - 1)) - 1 : k.sbc - 1, A, fid, y, xs, xs);
+                if (starts && xs > 0) hole_update(hole, b ? k.sbc + __popcll(s0 & upto_bit(b - 1)) - 1 : k.sbc - 1, A, get_A, y, xs, xs);
                 if (ends && xe < w - 1)
-                    hole_update(hole, (b + len < 64) ? k.sbc + __popcll(s0 & upto_bit(b + len)) - 1 : k.sbc + __popcll(s0), A, fid, y, xe, xe);
+                    hole_update(hole, (b + len < 64) ? k.sbc + __popcll(s0 & upto_bit(b + len)) - 1 : k.sbc + __popcll(s0), A, get_A, y, xe, xe);
                 // rows above and below: 0-runs overlapping [xs, xe]
                 for (int dy = -1; dy <= 1; dy += 2) {
                     int yy = y + dy;
@@ -917,7 +950,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
                         int bx = __ffsll((long long)ov) - 1;
                         u64 inv2 = ~(ov >> bx);
                         int l2 = inv2 ? (__ffsll((long long)inv2) - 1) : (64 - bx);
-                        hole_update(hole, sbo + __popcll(s0o & upto_bit(bx)) - 1, A, fid, y, (q << 6) + bx, (q << 6) + bx + l2 - 1);
+                        hole_update(hole, sbo + __popcll(s0o & upto_bit(bx)) - 1, A, get_A, y, (q << 6) + bx, (q << 6) + bx + l2 - 1);
                         ov &= ~((l2 >= 64 ? ~0ull : ((1ull << l2) - 1)) << bx);
                     }
                 }

@@ -192,6 +192,20 @@ struct HullView {
     __device__ __forceinline__ float py(int i) const { return (float)at(i).y; }
 };
 
+// the same over lane-interleaved chains (k_rects: a lane per key, element k of a lane's chain at k * 64)
+struct LaneHullView {
+    const int2 *c1, *c2;
+    int n1, n, s0;
+    __device__ __forceinline__ int2 raw(int i) const { return i < n1 ? c1[i * 64] : c2[(i - n1) * 64]; }
+    __device__ __forceinline__ int2 at(int i) const {
+        int k = i + s0;
+        if (k >= n) k -= n;
+        return raw(k);
+    }
+    __device__ __forceinline__ float px(int i) const { return (float)at(i).x; }
+    __device__ __forceinline__ float py(int i) const { return (float)at(i).y; }
+};
+
 template <class HV>
 __device__ __forceinline__ void hv_vect(const HV &hv, int i, float *vx, float *vy, float *inv) {
     int j = (i + 1 < hv.n) ? i + 1 : 0;
@@ -405,36 +419,40 @@ k_rects(const int4 *keys, const int2 *rowext, int2 *hullbuf, int *quads, int *co
     // per thread in LDS: the key's row extremes (fetched with independent loads first) and the
     // two chain stacks -- the hull walk is a chain of dependent accesses, which in global memory
     // made this kernel pure latency
+    // (lane-interleaved: element k of lane t sits at k * 64 + t.  With a block of 3 x 16 int2 per lane -- 96 dwords, a multiple of
+    // the 32 banks -- every lane's element k fell into the same bank: the counters showed five times as many LDS clocks lost to
+    // bank conflicts as spent on the accesses themselves: profiles/r04_util_sdss.json, k_rects)
     __shared__ int2 stk[64 * 3 * SMALL_KEY_ROWS];
-    int2 *ext = stk + (size_t)threadIdx.x * 3 * SMALL_KEY_ROWS, *c1 = ext + SMALL_KEY_ROWS, *c2 = c1 + SMALL_KEY_ROWS;
+    int2 *ext = stk + threadIdx.x, *c1 = ext + 64 * SMALL_KEY_ROWS, *c2 = c1 + 64 * SMALL_KEY_ROWS;
+#define LANE_AT(p_, k_) (p_)[(k_) * 64]
     (void)hullbuf;
     for (int ki = blockIdx.x * blockDim.x + threadIdx.x; ki < nkeys; ki += gridDim.x * blockDim.x) {
         int4 key = kg[ki];
         int extent = key.y & ~KEY_HOLE_BIT, ymin = key.z, base = key.w;
         if (extent > SMALL_KEY_ROWS) continue; // k_rects_big
-        for (int r = 0; r < extent; r++) ext[r] = re[base + r];
+        for (int r = 0; r < extent; r++) LANE_AT(ext, r) = re[base + r];
         int n1 = 0, n2 = 0;
         for (int r = 0; r < extent; r++) {
-            int2 e = ext[r];
+            int2 e = LANE_AT(ext, r);
             if (e.x > e.y) continue;
             int2 p = make_int2(e.x, ymin + r);
-            while (n1 >= 2 && cross_i(c1[n1 - 2], c1[n1 - 1], p) >= 0) n1--;
-            c1[n1++] = p;
+            while (n1 >= 2 && cross_i(LANE_AT(c1, n1 - 2), LANE_AT(c1, n1 - 1), p) >= 0) n1--;
+            LANE_AT(c1, n1++) = p;
         }
         for (int r = extent - 1; r >= 0; r--) {
-            int2 e = ext[r];
+            int2 e = LANE_AT(ext, r);
             if (e.x > e.y) continue;
             int2 p = make_int2(e.y, ymin + r);
-            while (n2 >= 2 && cross_i(c2[n2 - 2], c2[n2 - 1], p) >= 0) n2--;
-            c2[n2++] = p;
+            while (n2 >= 2 && cross_i(LANE_AT(c2, n2 - 2), LANE_AT(c2, n2 - 1), p) >= 0) n2--;
+            LANE_AT(c2, n2++) = p;
         }
         if (n1 == 0) continue;
         // drop the vertices the two chains share at the bottom and at the top
         int a = 0, bnd = n2;
-        if (c2[0].x == c1[n1 - 1].x && c2[0].y == c1[n1 - 1].y) a = 1;
-        if (bnd > a && c2[bnd - 1].x == c1[0].x && c2[bnd - 1].y == c1[0].y) bnd--;
-        HullView hv;
-        hv.c1 = c1; hv.c2 = c2 + a; hv.n1 = n1; hv.n = n1 + (bnd - a); hv.s0 = 0;
+        if (LANE_AT(c2, 0).x == LANE_AT(c1, n1 - 1).x && LANE_AT(c2, 0).y == LANE_AT(c1, n1 - 1).y) a = 1;
+        if (bnd > a && LANE_AT(c2, bnd - 1).x == LANE_AT(c1, 0).x && LANE_AT(c2, bnd - 1).y == LANE_AT(c1, 0).y) bnd--;
+        LaneHullView hv;
+        hv.c1 = c1; hv.c2 = c2 + a * 64; hv.n1 = n1; hv.n = n1 + (bnd - a); hv.s0 = 0;
         if (hv.n < 1) continue;
         int s0 = 0;
         int2 best = hv.raw(0);
@@ -445,6 +463,7 @@ k_rects(const int4 *keys, const int2 *rowext, int2 *hullbuf, int *quads, int *co
         hv.s0 = s0;
         rect_from_hull(hv, minLen, lwTresh, cnt, quads, (size_t)g * key_cap, true);
     }
+#undef LANE_AT
 }
 
 

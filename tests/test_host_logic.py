@@ -199,6 +199,27 @@ def test_bench_finds_the_committed_traffic_counters():
                       ("k_prep_hist", lsst), ("k_morph(erode)", lsst), ("k_dilate_canny", lsst), ("k_hough_vote", lsst)):
         nbytes, src = bench.load_traffic(name, cfg)
         assert nbytes and nbytes > 1e6 and src.endswith(".json"), (name, cfg[0])
+    # ... and the utilisation figures of `kernels{}` (tools/make_util.py): the newest file per workload was collected from the
+    # kernels as they are now (it records the SHA-256 of lfd_amd/csrc's sources; VERDICT r03 item 3: no profile older than the
+    # last kernel change is quoted by the bench line)
+    import glob
+    import hashlib
+    import json
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "lfd_amd", "csrc", "*.h")) + glob.glob(os.path.join(root, "lfd_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(root, "lfd_amd", "csrc", "*.inc"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    for workload, slots in (("sdss", ("k_dilate_canny", "k_prep_hist", "k_frame_bg", "k_frame_fg", "k_hough_vote", "k_bits_erode", "k_scan_fused")),
+                            ("lsst", ("k_dilate_canny", "k_prep_hist", "k_hough_vote", "k_morph(erode)"))):
+        util, src, top = bench.load_util(workload)
+        assert src and top and top["name"], workload
+        doc = json.load(open(os.path.join(root, "profiles", src)))
+        assert doc["csrc_sha256"] == h.hexdigest(), ("%s was collected before the last change under lfd_amd/csrc: run tools/collect_profiles.sh "
+                                                     "on the GPU box and commit the new profiles" % src)
+        for s_ in slots:
+            u = util.get(s_)
+            assert u and 0 < u["valu_pipe"] < 1 and 0 < u["waves_per_simd"] <= 8 and "hbm" in u, (workload, s_, u)
 
 
 

@@ -15,8 +15,9 @@ names = ["input wait+stage", "masks", "hmax", "vmax+lut", "borders+equ bits", "s
 for label, fn in (("bright", lambda: ctx.process_bright(frames, pb, flip=True)),
                   ("dim", lambda: ctx.process_dim(frames, pd, flip=True, after_bright=True))):
     fn(); fn()
-    out = np.zeros((n, 8), np.int64)
-    assert ctx._lib.lfdmi_debug_frame_profile(ctx._h, n, out.ctypes.data) == 0
+    raw = np.zeros(n * 16, np.int64)                     # (the getter copies 16 values per slot; the tile kernel's clocks are the first 8 n)
+    assert ctx._lib.lfdmi_debug_frame_profile(ctx._h, n, raw.ctypes.data) == 0
+    out = raw[:n * 8].reshape(n, 8)
     tiles = out[:, 7].sum()
     cyc = out[:, :7].sum(axis=0)
     ntl = ctx.get_counters(0, n)[:, 17]
