@@ -229,8 +229,8 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
             u64 c = t.c & vmask;
             u64 s = c & ~((c << 1) | (t.cp >> 63)); // run starts of this word
             for (int k = 0, n = __popcll(s); k < n; k++) {
-                ROWg[t.id0 + k] = y;
-                if (keys_path) YM[t.id0 + k] = y; else YMg[t.id0 + k] = y;
+                if (keys_path) YM[t.id0 + k] = y; // (row and last row of the roots go to memory when their keys are made)
+                else { ROWg[t.id0 + k] = y; YMg[t.id0 + k] = y; }
             }
             if (y == 0 || !c) return;
             u64 u = t.u & vmask;
@@ -351,6 +351,15 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
     FG_PROF(); // 9: flatten + strong
     // ---- contour keys of the edge components (their outer borders), keys_path only
     const int NOEDGE = INT_MIN, EDGE_NOSLOT = INT_MIN + 1;
+    auto edge_load_early = [&](int idx) { // (items beyond the register copies)
+            FgWordItem t;
+            int y = idx / wq, q = idx - y * wq;
+            t.idx = idx;
+            word_pair(fb, idx, q > 0, 0ull, t.cp, t.c);
+            t.m = 0;
+            t.id0 = sf[idx];
+            return t;
+    };
     int4 *kg = keys + (size_t)g * key_cap;
     int2 *re = rowext + (size_t)g * slot_cap;
     bool lds_slots = false;
@@ -362,22 +371,33 @@ k_frame_fg(const u64 *cand, const u64 *strong, const int *scanf, const int *wl_f
             const int root = L[i];
             Lf[ro + i] = root;
             FLf[ro + i] = (root == i) ? (int)((FL[i >> 5] >> (i & 31)) & 1u) : 0; // root of an edge component
-            YMg[i] = YM[i];
         }
-        for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
-            if (L[i] != i || !((FL[i >> 5] >> (i & 31)) & 1u)) continue;
-            const int y0 = ROWg[i], extent = YM[i] - y0 + 1; // (ROWg: written by this workgroup before the barriers above)
-            const int base = atomicAdd(&c_slots, extent), ki = atomicAdd(&c_keys, 1);
-            if (base + extent > slot_cap || ki >= key_cap) {
-                c_ovf = 1;
-                YM[i] = EDGE_NOSLOT;
-                continue;
+        // a key per root of an edge component.  The thread that holds a root's word knows its row: no per-run row table is written
+        // or read (round 4; 14 000 scattered stores per frame in the merge phase, for the ~300 rows this loop wants)
+        auto keys_proc = [&](const FgWordItem &t) {
+            const int y0 = t.idx / wq, q = t.idx - y0 * wq;
+            const u64 c = t.c & valid_mask(q, w);
+            const u64 s = c & ~((c << 1) | (t.cp >> 63));
+            for (int k = 0, n = __popcll(s); k < n; k++) {
+                const int i = t.id0 + k;
+                if (L[i] != i || !((FL[i >> 5] >> (i & 31)) & 1u)) continue;
+                const int ymax = YM[i], extent = ymax - y0 + 1;
+                ROWg[i] = y0; YMg[i] = ymax;               // (what the general contour kernels read, should they take this frame)
+                const int base = atomicAdd(&c_slots, extent), ki = atomicAdd(&c_keys, 1);
+                if (base + extent > slot_cap || ki >= key_cap) {
+                    c_ovf = 1;
+                    YM[i] = EDGE_NOSLOT;
+                    continue;
+                }
+                kg[ki] = make_int4(i, extent, y0, base);
+                if (extent > BIG_KEY_ROWS) bigkeys[(size_t)g * key_cap + atomicAdd(&c_big, 1)] = ki;
+                else if (extent > SMALL_KEY_ROWS) medkeys[(size_t)g * key_cap + atomicAdd(&c_med, 1)] = ki;
+                YM[i] = base - y0; // row y of this component lives in slot YM[root] + y
             }
-            kg[ki] = make_int4(i, extent, y0, base);
-            if (extent > BIG_KEY_ROWS) bigkeys[(size_t)g * key_cap + atomicAdd(&c_big, 1)] = ki;
-            else if (extent > SMALL_KEY_ROWS) medkeys[(size_t)g * key_cap + atomicAdd(&c_med, 1)] = ki;
-            YM[i] = base - y0; // row y of this component lives in slot YM[root] + y
-        }
+        };
+#pragma unroll
+        for (int k = 0; k < FG_KC; k++) if (kc_x[k] >= 0) keys_proc(cached_item(k, 0ull));
+        if (more) frame_pipeline<FgWordItem>(wl, im, FG_KC, edge_load_early, keys_proc);
         __syncthreads();
         // L[run] := slot offset of its component (or "not an edge run"): one LDS read per stretch below
         for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
@@ -592,10 +612,7 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
         u64 vmask = valid_mask(q, w);
         u64 z = ~t.c & vmask;                              // 0-pixels of this word
         u64 s = z & ~((z << 1) | ((~t.cp) >> 63));         // 0-run starts (cp = all ones left of column 0)
-        for (int k = 0, n = __popcll(s); k < n; k++) {
-            ROWg[t.id0 + k] = y;
-            YMg[t.id0 + k] = y;
-        }
+        // (no per-run row / last-row tables: only the roots of holes need them, and those are written in the hole phase)
         if (y == 0) return;
         // the run before this row's first one is the last run of the row above: it touches the frame if that row ends in a 0
         if (q == 0 && t.id0 > 0 && !((t.pl >> last_bit) & 1ull)) atomicOr(&CL[(t.id0 - 1) >> 5], 1u << ((t.id0 - 1) & 31));
@@ -688,12 +705,30 @@ k_frame_contours(RunTabs t, const int *wl_fg, const int *wl_bg, int *counters, i
             if (root == id) {
                 atomicOr(&HR[id >> 5], 1u << (id & 31));
                 XSg[id] = (q << 6) + hole_bit(s, k); // column of the hole's raster-first pixel
-            } else if (!((HB[id >> 5] >> (id & 31)) & 1u)) atomicMax(&YMg[root], y);
+                ROWg[id] = y;                        // row / last row: of a hole's root only (a few hundred per frame, not every run)
+                YMg[id] = y;
+            }
+        }
+    };
+    auto hole_extent_proc = [&](const BgWordItem &t) { // (after the roots' entries are in place)
+        int y = t.idx / wq, q = t.idx - y * wq;
+        u64 z = ~t.c & valid_mask(q, w);
+        u64 s = z & ~((z << 1) | ((~t.cp) >> 63));
+        int n = __popcll(s);
+        for (int k = 0; k < n; k++) {
+            int id = t.id0 + k;
+            if (!((HL[id >> 5] >> (id & 31)) & 1u) || ((HB[id >> 5] >> (id & 31)) & 1u)) continue; // not a hole's run, or one with a run below
+            int root = L[id];
+            if (root != id) atomicMax(&YMg[root], y);
         }
     };
 #pragma unroll
     for (int k = 0; k < BG_KC; k++) if (kc_x[k] >= 0) hole_proc(cached_item(k));
     if (more) frame_pipeline<BgWordItem>(wl, im, BG_KC, word_load, hole_proc);
+    __syncthreads(); // (device-scope ordering of the plain stores above and the atomics below is by the memory-side atomic unit: see the note at the read)
+#pragma unroll
+    for (int k = 0; k < BG_KC; k++) if (kc_x[k] >= 0) hole_extent_proc(cached_item(k));
+    if (more) frame_pipeline<BgWordItem>(wl, im, BG_KC, word_load, hole_extent_proc);
     if (prof) { __syncthreads(); FRAME_PROF(); } // 2: hole extents
     for (int i = threadIdx.x; i < nrun; i += FRAME_THREADS) {
         int root = L[i];
