@@ -78,7 +78,32 @@ def dc_split():
     return 0.5, 0.5, None
 
 
+def fg_split():
+    """(hysteresis share, contour-key share, source) of k_frame_fg's time from the newest profiles/r*_frame_profile.txt
+    (tools/frame_profile.py: wall-clock stamps per phase).  Since round 4 the kernel that does Canny's hysteresis also makes the
+    outer-border keys of the contour stage from its label table (k_frame.h): its merge / flatten / edge-bit phases are Canny,
+    its "outer keys" phase belongs to contours+rect+fill (the extremes themselves ride on the edge-bit pass and stay with Canny:
+    a lower bound for the contour share)."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_frame_profile.txt")), reverse=True):
+        try:
+            keys = tot = 0.0
+            for line in open(path):
+                m = re.search(r"k_frame_fg: merge (\d+)/\d+ flatten\+strong (\d+)/\d+ outer keys \| edge bits (\d+)/\d+ edge\+extremes \| write-out (\d+)/\d+", line)
+                if m:
+                    a, b, c, d = (float(x) for x in m.groups())
+                    keys += c
+                    tot += a + b + c + d
+            if tot > 0 and keys > 0:
+                return 1.0 - keys / tot, keys / tot, os.path.basename(path)
+        except (OSError, ValueError):
+            continue
+    return 1.0, 0.0, None
+
+
 DC_DILATE, DC_CANNY, DC_SRC = dc_split()
+FG_CANNY, FG_KEYS, FG_SRC = fg_split()
 STAGES = {
     "prep": (5.0, {"k_prep_hist": 1.0, "k_lut": 1.0, "k_removestars": 1.0}),
     "prep+erode": (7.0, {"k_prep_erode": 1.0}),
@@ -91,9 +116,9 @@ STAGES = {
     "dilate": (2.0, {"k_morph(dilate)": 1.0, "k_dilate_canny": DC_DILATE}),
     # Canny = NMS (the Sobel / NMS stages of the fused tile kernel) + hysteresis (candidate-run scan, per-frame union-find,
     # general fallback kernels)
-    "canny": (2.0, {"k_dilate_canny": DC_CANNY, "k_canny_nms": 1.0, "k_runs_init(fg)": 1.0, "k_frame_fg": 1.0, "k_runs_merge8": 1.0,
+    "canny": (2.0, {"k_dilate_canny": DC_CANNY, "k_canny_nms": 1.0, "k_runs_init(fg)": 1.0, "k_frame_fg": FG_CANNY, "k_runs_merge8": 1.0,
                     "k_runs_flatten(fg)": 1.0, "k_edge_from_cand": 1.0}),
-    "contours+rect+fill": (2.0, {"k_runs_init(bg)": 1.0, "k_frame_bg": 1.0, "k_frame_keys": 1.0, "k_runs_merge4_bg": 1.0,
+    "contours+rect+fill": (2.0, {"k_runs_init(bg)": 1.0, "k_frame_bg": 1.0, "k_frame_fg": FG_KEYS, "k_frame_keys": 1.0, "k_runs_merge4_bg": 1.0,
                                  "k_runs_flatten(bg)": 1.0, "k_keys": 1.0, "k_extremes": 1.0, "k_rects": 1.0, "k_fill_quads": 1.0}),
     # two images per frame with a detected rectangle, 1N each
     "hough": (2.0, {"k_pixlist": 1.0, "k_hough_vote": 1.0, "k_hough_peaks": 1.0, "k_hough_topk": 1.0, "k_hough_sort": 1.0}),
@@ -467,6 +492,7 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
                   "frac": round(gb / (t_ms * 1e-3) / HBM_PEAK_GBPS, 4),
                   "frac_if_fused_tile_kernel_is_all_canny": round(gb / (t_lo * 1e-3) / HBM_PEAK_GBPS, 4),
                   "fused_tile_kernel_split": {"dilate": round(DC_DILATE, 3), "canny": round(DC_CANNY, 3), "source": DC_SRC},
+                  "k_frame_fg_split": {"hysteresis": round(FG_CANNY, 3), "contour_keys": round(FG_KEYS, 3), "source": FG_SRC},
                   "target": 0.5}
         hv = None
         if "k_hough_vote" in table and table["k_hough_vote"][1]:
