@@ -274,6 +274,34 @@ int lfdmi_fits_read_photoobj(const char *const *paths, int n, int max_obj, float
  * (out[i] = bit offset * 2 + 1 for the end-of-stream magic; returns their number, the first `cap` stored) -- the blocks of a
  * .fits.bz2 frame are then decoded side by side (the reference pipes the file through bunzip2: detecttrails.py:81-109). */
 int64_t lfdmi_bz2_find_blocks(const uint8_t *data, uint64_t n, uint64_t *out, int64_t cap);
+/* ---- bzip2 on the device --------------------------------------------------------------------------------------------------
+ * SDSS serves frames as frame-*.fits.bz2; the reference decompresses every one before it reads it (detecttrails.py:81-109:
+ * `bunzip2` into $FITS_DUMP, then fitsio.read) at ~0.4 s per frame and core.  lfdmi_bz2_decode_batch decompresses n whole files
+ * at once on the GPU (a frame is ~14 independent 900 kB blocks: Huffman / move-to-front a wave per block, inverse
+ * Burrows-Wheeler transform as a list ranking, run-length layer as a scan; every block's CRC and the stream's CRC are
+ * checked).  A handle owns its own stream and buffers and is independent of any lfdmi_ctx (one thread per handle).
+ *   src + src_off[i], src_len[i]  file i's bytes in host memory (ordinary or page-locked);
+ *   out_cap                        room per decompressed file;
+ *   head, head_bytes               if head_bytes > 0: the first head_bytes of every decompressed file, side by side, in host
+ *                                  memory (for parsing FITS headers; zero-filled beyond a file's end);
+ *   out_len[i], status[i]          decompressed size, and 0 = decoded and checked, or why not (LFDMI_BZ2_*: the caller then
+ *                                  decompresses that file on the host, which also produces the reference's error for broken
+ *                                  files).  Files that are not one plain stream (several streams joined, trailing bytes,
+ *                                  randomised blocks of bzip2 < 0.9.5) are declined, not decoded.
+ * The decompressed files stay on the device until the handle's next lfdmi_bz2_decode_batch; lfdmi_bz2_fetch /
+ * lfdmi_bz2_fetch_many copy ranges of them to host (loc LFDMI_HOST / LFDMI_HOST_PINNED) or device (LFDMI_DEVICE) memory. */
+typedef struct lfdmi_bz2 lfdmi_bz2;
+enum { LFDMI_BZ2_OK = 0, LFDMI_BZ2_MAGIC = 1, LFDMI_BZ2_RANDOMISED = 2, LFDMI_BZ2_HEADER = 3, LFDMI_BZ2_DATA = 4, LFDMI_BZ2_LENGTH = 5,
+       LFDMI_BZ2_ORIGPTR = 6, LFDMI_BZ2_CRC = 7, LFDMI_BZ2_CYCLE = 8, LFDMI_BZ2_SIZE = 9, LFDMI_BZ2_STREAM = 10 };
+int lfdmi_bz2_create(int device, lfdmi_bz2 **out);
+void lfdmi_bz2_destroy(lfdmi_bz2 *z);
+const char *lfdmi_bz2_last_error(lfdmi_bz2 *z);
+int lfdmi_bz2_decode_batch(lfdmi_bz2 *z, const void *src, const uint64_t *src_off, const uint64_t *src_len, int n, uint64_t out_cap,
+                           void *head, uint64_t head_bytes, uint64_t *out_len, int32_t *status);
+int lfdmi_bz2_fetch(lfdmi_bz2 *z, int i, uint64_t off, uint64_t nbytes, void *dst, int loc);
+int lfdmi_bz2_fetch_many(lfdmi_bz2 *z, int n, const int32_t *file, const uint64_t *off, const uint64_t *nbytes, void *const *dst, int loc);
+/* milliseconds of the last batch: upload + magic search, Huffman / move-to-front, sort, inverse BWT walks, run-length + CRC + output */
+int lfdmi_bz2_timings(lfdmi_bz2 *z, float *ms5);
 /* Which calls keep the 8-bit stage images (gray, eroded, equalised+dilated: what the reference's debug PNGs show) for
  * lfdmi_get_stage.  mode -1 (default): the per-pass entry points (lfdmi_process_bright / _dim / _multiscale) do,
  * lfdmi_detect_batch does not; 0: no call does (batches through the per-pass entry points: an image per frame less to

@@ -31,7 +31,7 @@ SYMBOLS = (
     "lfdmi_max_inflight", "lfdmi_prep_u8", "lfdmi_equalize_hist", "lfdmi_dilate", "lfdmi_erode",
     "lfdmi_canny", "lfdmi_gaussian_blur", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
     "lfdmi_hough_dims", "lfdmi_remove_stars", "lfdmi_process_bright", "lfdmi_process_dim",
-    "lfdmi_detect_batch", "lfdmi_detect_batch_raw", "lfdmi_host_alloc", "lfdmi_host_free", "lfdmi_fits_read_frames", "lfdmi_fits_read_photoobj", "lfdmi_bz2_find_blocks", "lfdmi_set_stage_images", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_timing_select", "lfdmi_get_timing",
+    "lfdmi_detect_batch", "lfdmi_detect_batch_raw", "lfdmi_host_alloc", "lfdmi_host_free", "lfdmi_fits_read_frames", "lfdmi_fits_read_photoobj", "lfdmi_bz2_find_blocks", "lfdmi_bz2_create", "lfdmi_bz2_destroy", "lfdmi_bz2_last_error", "lfdmi_bz2_decode_batch", "lfdmi_bz2_fetch", "lfdmi_bz2_fetch_many", "lfdmi_bz2_timings", "lfdmi_set_stage_images", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_timing_select", "lfdmi_get_timing",
     "lfdmi_timing_slots", "lfdmi_timing_name",
 )
 
@@ -109,6 +109,16 @@ def lib():
         _lib.lfdmi_timing_name.restype = C.c_char_p
         _lib.lfdmi_bz2_find_blocks.restype = C.c_int64
         _lib.lfdmi_bz2_find_blocks.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64]
+        _lib.lfdmi_bz2_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        _lib.lfdmi_bz2_destroy.restype = None
+        _lib.lfdmi_bz2_destroy.argtypes = [C.c_void_p]
+        _lib.lfdmi_bz2_last_error.restype = C.c_char_p
+        _lib.lfdmi_bz2_last_error.argtypes = [C.c_void_p]
+        _lib.lfdmi_bz2_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                C.c_void_p, C.c_void_p]
+        _lib.lfdmi_bz2_fetch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
+        _lib.lfdmi_bz2_fetch_many.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.lfdmi_bz2_timings.argtypes = [C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -189,6 +199,81 @@ class PinnedBuffer:
             self._lib.lfdmi_host_free(None, p)
 
     __del__ = close
+
+
+BZ2_STATUS = {0: "ok", 1: "no block magic", 2: "randomised block", 3: "bad block header", 4: "bad compressed data",
+              5: "block length mismatch", 6: "bad origin pointer", 7: "CRC mismatch", 8: "BWT cycle shorter than the block",
+              9: "larger than out_cap", 10: "not one plain bzip2 stream"}
+
+
+class Bz2Decoder:
+    """lfdmi_bz2_*: whole ``.bz2`` files decompressed on the GPU, many at once (include/lfdmi.h).  ``decode`` takes the
+    compressed files as one uint8 array + offsets / lengths and returns (out_len, status, heads); the decompressed bytes stay on
+    the device until the next ``decode`` and are copied out in ranges by ``fetch`` / ``fetch_many``.  A file whose status is not
+    0 was NOT decoded (several streams joined, a broken block, ...): decompress it on the host, as the reference does."""
+
+    def __init__(self, device=0):
+        self._lib = lib()
+        self._h = C.c_void_p()
+        rc = self._lib.lfdmi_bz2_create(int(device), C.byref(self._h))
+        if rc:
+            raise NativeError(rc, "lfdmi_bz2_create")
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.lfdmi_bz2_destroy(h)
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc:
+            raise NativeError(rc, (self._lib.lfdmi_bz2_last_error(self._h) or b"").decode())
+
+    def decode(self, src, offsets, lengths, out_cap, head_bytes=0):
+        src = np.ascontiguousarray(src).view(np.uint8).reshape(-1)
+        off = np.ascontiguousarray(offsets, np.uint64)
+        ln = np.ascontiguousarray(lengths, np.uint64)
+        n = len(off)
+        if n == 0 or len(ln) != n or (n and int((off + ln).max()) > src.size):
+            raise ValueError("Bz2Decoder.decode: offsets / lengths do not fit the source array")
+        out_len = np.zeros(n, np.uint64)
+        status = np.zeros(n, np.int32)
+        heads = np.zeros((n, int(head_bytes)), np.uint8) if head_bytes else None
+        self._chk(self._lib.lfdmi_bz2_decode_batch(self._h, _ptr(src), _ptr(off), _ptr(ln), n, C.c_uint64(int(out_cap)),
+                                                   _ptr(heads), C.c_uint64(int(head_bytes)), _ptr(out_len), _ptr(status)))
+        return out_len, status, heads
+
+    def fetch(self, i, offset, nbytes, dst=None):
+        """Bytes [offset, offset + nbytes) of decompressed file i into ``dst`` (a uint8 numpy array / torch CUDA tensor; a new
+        numpy array if None)."""
+        if dst is None:
+            dst = np.empty(int(nbytes), np.uint8)
+        self._chk(self._lib.lfdmi_bz2_fetch(self._h, int(i), C.c_uint64(int(offset)), C.c_uint64(int(nbytes)), _ptr(dst),
+                                            DEVICE if _is_dev(dst) else HOST))
+        return dst
+
+    def fetch_many(self, files, offsets, nbytes, dsts):
+        """One range per entry, all copies queued before one wait.  dsts: numpy arrays (or torch CUDA tensors, all of one kind)."""
+        n = len(files)
+        if n == 0:
+            return
+        f = np.ascontiguousarray(files, np.int32)
+        o = np.ascontiguousarray(offsets, np.uint64)
+        b = np.ascontiguousarray(nbytes, np.uint64)
+        ptrs = (C.c_void_p * n)(*[_ptr(d) for d in dsts])
+        self._chk(self._lib.lfdmi_bz2_fetch_many(self._h, n, _ptr(f), _ptr(o), _ptr(b), ptrs, DEVICE if _is_dev(dsts[0]) else HOST))
+
+    def timings(self):
+        ms = np.zeros(5, np.float32)
+        self._chk(self._lib.lfdmi_bz2_timings(self._h, _ptr(ms)))
+        return dict(zip(("upload+magics", "huffman+mtf", "sort", "walk", "rle+crc+out"), (float(x) for x in ms)))
 
 
 class Context:

@@ -1,0 +1,600 @@
+// k_bz2.h -- bzip2 decompression on the device: the step in front of the hot path on real archives (SDSS serves frames as
+// frame-*.fits.bz2; the reference decompresses every one with `bunzip2` before it reads it, detecttrails.py:81-109, at ~0.4 s
+// per frame and core).  A frame is ~14 independent blocks of 900 kB; a chunk of 256 frames is ~3 600 blocks.
+//
+//   k_bz2_magics   every 48-bit block / end-of-stream magic of every file, at any bit offset        (bandwidth, trivial)
+//   k_bz2_huff     a WAVE per block: header, coding tables, Huffman + RUNA/RUNB + move-to-front     (sequential per block: a
+//                  -> the block's BWT column L                                                        chain of LDS look-ups)
+//   k_bz2_sort     a workgroup per block: stable counting sort of L -> tt[q] = (T[q] << 8) | byte    (LDS histograms)
+//   k_bz2_walk     inverse BWT as list ranking: ~3 500 splitters per block walk to the next          (random 4-byte loads:
+//                  splitter, one thread ranks the splitters, the walks are repeated writing bytes     HBM / L2 latency)
+//   k_bz2_rle_scan the run-length layer (4 equal bytes + count): per-thread parse under both          (LDS scan)
+//                  possible entry states, composed by a scan -> output offset of every thread
+//   k_bz2_offsets  output offset of every block inside its file
+//   k_bz2_expand   writes the file's bytes, CRC of every block (per-thread CRCs combined with x^(8 len) mod P)
+// All integer / byte work: bit-exact by construction, and every block's stored CRC is checked on the device.
+#pragma once
+#include "common.h"
+#include "bz2_core.h"
+
+#define BZ_LSTRIDE 900608     // bytes per block of the L / pre-RLE buffers (>= 900 000 + a staging buffer of 256, a multiple of 256)
+#define BZ_TSTRIDE 900096     // words per block of tt
+#define BZ_SEL_STRIDE 18048
+#define BZ_SPLIT_LOG 8        // a splitter every 256 positions of tt
+#define BZ_MAX_SPLIT 3520     // 900 000 / 256 + head, rounded up
+#define BZ_MARK_CAP 256       // magics kept per file (a level-1 file of 12.6 MB has 127 blocks)
+
+struct BzBlockDesc {
+    uint64_t start_bit, end_bit; // of the block's magic / of the next magic, relative to the file's first word
+    uint64_t word_off, nwords;   // the file inside the device's copy of the compressed bytes
+    int file, max_block;
+};
+
+// ---- magics -----------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_bz2_magics(const uint32_t *comp, const uint64_t *word_off, const uint64_t *nbytes, int *nfound, u64 *marks) {
+    const int f = blockIdx.y;
+    const uint64_t nb = nbytes[f];
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; // this thread: magics that START in bytes 8 i .. 8 i + 7
+    if (i * 8 >= nb) return;
+    const uint32_t *w = comp + word_off[f] + i * 2; // (the copy is padded with zero words: reading 16 bytes is safe)
+    const u64 hi = ((u64)bz_bswap32(w[0]) << 32) | bz_bswap32(w[1]), lo = ((u64)bz_bswap32(w[2]) << 32) | bz_bswap32(w[3]);
+    for (int o = 0; o < 64; o++) {
+        const u64 v = (o ? ((hi << o) | (lo >> (64 - o))) : hi) >> 16;
+        const bool blk = v == 0x314159265359ull, eos = v == 0x177245385090ull;
+        if (blk || eos) {
+            const u64 bit = i * 64 + (u64)o;
+            if (bit + 48 > nb * 8) continue;
+            const int k = atomicAdd(&nfound[f], 1);
+            if (k < BZ_MARK_CAP) marks[(size_t)f * BZ_MARK_CAP + k] = (bit << 1) | (eos ? 1ull : 0ull);
+        }
+    }
+}
+
+// ---- Huffman + MTF: a wave per block ----------------------------------------------------------------------------------------
+struct BzDevIO {
+    uint8_t *len;
+    int *limit, *base, *min_len;
+    uint16_t *perm, *fast;
+    uint8_t *sel;
+    uint8_t *L;
+    int flushed, cnt, lane;
+    uint32_t stage; // 256 output bytes in flight: lane l holds bytes 4 l .. 4 l + 3
+    uint32_t list;  // the move-to-front list (byte values), lane l holds entries 4 l .. 4 l + 3, entry j in bits 8 j ..
+    __device__ __forceinline__ void mtf_begin() { list = 0; }
+    __device__ __forceinline__ void mtf_add(int k, uint32_t b) {
+        list |= lane == (k >> 2) ? b << (8 * (k & 3)) : 0u;
+    }
+    __device__ __forceinline__ uint32_t mtf_head() { return __builtin_amdgcn_readfirstlane(list) & 0xffu; }
+    __device__ __forceinline__ uint32_t mtf_front(int nn) { // nn >= 1 (position 0 is coded as a run)
+        const int q = nn >> 2, r8 = (nn & 3) << 3;
+        const uint32_t v = ((uint32_t)__builtin_amdgcn_readlane((int)list, q) >> r8) & 0xffu;
+        // every entry below nn moves up by one: a byte shift inside each lane, the top byte of lane l - 1 comes in at the bottom
+        // (lane 0 has no lane below it: it receives v, the new front)
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)(v << 24), (int)list, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        const uint32_t sh = (list << 8) | (prev >> 24);
+        const uint32_t mr = (2u << (r8 + 7)) - 1u; // bytes 0 .. r of lane q (r = 3: the shift count wraps to give all ones)
+        const uint32_t m = lane < q ? 0xffffffffu : (lane == q ? mr : 0u);
+        list = (sh & m) | (list & ~m);
+        return v;
+    }
+    __device__ __forceinline__ void flush_full() {
+        ((uint32_t *)(L + flushed))[lane] = stage;
+        flushed += 256;
+        cnt = 0;
+        stage = 0;
+    }
+    // 256 bytes per store: byte cnt goes to byte cnt & 3 of lane cnt >> 2 (no branch but the one for a full buffer)
+    __device__ __forceinline__ void emit(uint32_t b) {
+        const uint32_t x = b << ((cnt & 3) << 3);
+        stage |= lane == (cnt >> 2) ? x : 0u;
+        cnt++;
+        if (cnt == 256) flush_full();
+    }
+    __device__ __forceinline__ void emit_run(uint32_t b, int n) {
+        while (n > 0 && ((cnt & 3) || n < 4)) { emit(b); n--; }
+        const uint32_t bb = b * 0x01010101u;
+        while (n >= 4) { // whole words: lanes cnt / 4 .. cnt / 4 + k - 1
+            const int w0 = cnt >> 2, k = min(n >> 2, 64 - w0);
+            stage = (lane >= w0 && lane < w0 + k) ? bb : stage; // (a select, not a branch: the loop's control flow stays scalar)
+            cnt += 4 * k;
+            n -= 4 * k;
+            if (cnt == 256) flush_full();
+        }
+        while (n > 0) { emit(b); n--; }
+    }
+    __device__ __forceinline__ void flush_tail() {
+        for (int j = 0; j < 4; j++)
+            if (4 * lane + j < cnt) L[flushed + 4 * lane + j] = (uint8_t)(stage >> (8 * j));
+        flushed += cnt;
+        cnt = 0;
+        stage = 0;
+    }
+    __device__ __forceinline__ int emitted() const { return flushed + cnt; }
+    __device__ __forceinline__ void build_fast(int t, int mn) {
+        __syncthreads(); // (one wave: orders the LDS traffic of the table building before the fast table overwrites `len`)
+        for (int k = 0; k < BZ_FAST_SIZE / 64; k++) {
+            const uint32_t x = (uint32_t)(lane + 64 * k);
+            fast[t * BZ_FAST_SIZE + x] = bz_fast_entry(*this, t, mn, x);
+        }
+        __syncthreads();
+    }
+};
+
+// The coded symbols of a block, decoded by one wave.  Every lane looks up the code that would start at ITS bit offset of a 64-bit
+// window (one LDS read for 64 candidates); the wave then follows the chain of code lengths through the window with v_readlane:
+// ~8 symbols per window on incompressible data, more on sky.  The move-to-front list and the output staging live in registers
+// (BzDevIO).  A table switch (every 50 symbols) or a code longer than BZ_FAST_BITS ends a window early.
+__device__ __forceinline__ int bz_dev_symbols(BzDevIO &io, const uint32_t *w, uint64_t nwords, uint64_t bit0, const BzHeader &hd,
+                                              int max_block, uint64_t &bit_end) {
+    const int lane = io.lane;
+    const int eob = hd.n_in_use + 1, n_sel = hd.n_sel;
+    uint64_t base = bit0 >> 5; // first word held in wv
+    int bp = (int)(bit0 & 31); // the cursor, in bits from word `base`
+    auto loadw = [&](uint64_t b) {
+        const uint64_t i = b + (uint64_t)lane;
+        return i < nwords ? bz_bswap32(w[i]) : 0u;
+    };
+    uint32_t wv = loadw(base);
+    int group_no = -1, group_pos = 0, t = 0;
+    int run_n = 0, run_len = 0;
+    const int lsh = lane & 31;
+    const bool upper = lane >= 32;
+    int st = -1, bad = 0;
+    while (st < 0) {
+        if (group_pos == 0) {
+            group_no++;
+            if (group_no >= n_sel) { st = BZ_E_DATA; break; }
+            group_pos = BZ_GROUP_SYMS;
+            t = __builtin_amdgcn_readfirstlane((int)io.sel[group_no]);
+        }
+        int k0 = bp >> 5;
+        if (k0 > 59) { // keep four whole words ahead of the cursor inside wv
+            base += (uint64_t)k0;
+            bp &= 31;
+            wv = loadw(base);
+            k0 = 0;
+        }
+        const int c = bp & 31;
+        const uint32_t a0 = __builtin_amdgcn_readlane(wv, k0), a1 = __builtin_amdgcn_readlane(wv, k0 + 1);
+        const uint32_t a2 = __builtin_amdgcn_readlane(wv, k0 + 2), a3 = __builtin_amdgcn_readlane(wv, k0 + 3);
+        const u64 A = ((u64)a0 << 32) | a1, B = ((u64)a2 << 32) | a3;
+        const u64 hi = c ? ((A << c) | (B >> (64 - c))) : A; // the 64 bits at the cursor
+        const uint32_t nx = (uint32_t)((B << c) >> 32);       // and the 32 after them
+        const uint32_t h0 = (uint32_t)(hi >> 32), h1 = (uint32_t)hi;
+        // lane l: the BZ_FAST_BITS bits starting l bits after the cursor
+        const u64 pair = upper ? (((u64)h1 << 32) | nx) : (((u64)h0 << 32) | h1);
+        const uint32_t prefix = (uint32_t)((pair << lsh) >> (64 - BZ_FAST_BITS));
+        const uint32_t ev = io.fast[t * BZ_FAST_SIZE + prefix];
+        int pos = 0;
+        bool done = false;
+        do { // (errors are collected in `bad` and looked at once per window: the loop has one exit besides its end)
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ev, pos);
+            int sym = (int)(e >> 4), len = (int)(e & 15u);
+            if (__builtin_expect(e == 0u, 0)) { // a longer code (or none): bit by bit from this position
+                BzBits br;
+                const uint64_t at = base * 32 + (uint64_t)(bp + pos);
+                br.init(w, nwords, at);
+                sym = bz_slow_symbol(io, br, t);
+                len = (int)(br.pos - at);
+                if (sym < 0) { bad = 1; sym = 2; }
+            }
+            pos += len;
+            if (__builtin_expect(sym <= 1, 0)) {
+                if (run_n == 0) { run_n = 1; run_len = 0; }
+                if (run_n >= 2 * 1024 * 1024) { bad = 1; run_n = 1; }
+                run_len += run_n << sym;
+                run_n <<= 1;
+            } else {
+                if (__builtin_expect(run_n != 0, 0)) {
+                    if (run_len > max_block - io.emitted()) { bad = 1; run_len = 0; }
+                    io.emit_run(io.mtf_head(), run_len);
+                    run_n = 0;
+                }
+                if (__builtin_expect(sym == eob, 0)) { done = true; break; }
+                io.emit(io.mtf_front(sym - 1)); // (a block that grows beyond its level's size is caught when a buffer is flushed)
+            }
+        } while (--group_pos != 0 && pos < 64);
+        if (done) {
+            bit_end = base * 32 + (uint64_t)(bp + pos);
+            st = BZ_OK;
+        }
+        if (bad) st = BZ_E_DATA;
+        bp += pos;
+        if (io.flushed > max_block) st = BZ_E_DATA;
+    }
+    return st;
+}
+
+__global__ void __launch_bounds__(64)
+k_bz2_huff(const uint32_t *comp, const BzBlockDesc *desc, BzBlockInfo *info, uint8_t *Lbuf, uint8_t *selbuf, int nblocks) {
+    const int b = blockIdx.x;
+    if (b >= nblocks) return;
+    __shared__ __attribute__((aligned(16))) uint16_t s_fast[BZ_MAX_GROUPS * BZ_FAST_SIZE];
+    __shared__ uint16_t s_perm[BZ_MAX_GROUPS * BZ_MAX_ALPHA + 4];
+    __shared__ int s_limit[BZ_MAX_GROUPS * BZ_NLEN], s_base[BZ_MAX_GROUPS * BZ_NLEN], s_min[8];
+    const BzBlockDesc d = desc[b];
+    BzDevIO io;
+    io.len = (uint8_t *)s_fast; // code lengths: needed only until the tables exist
+    io.fast = s_fast;
+    io.perm = s_perm;
+    io.limit = s_limit;
+    io.base = s_base;
+    io.min_len = s_min;
+    io.sel = selbuf + (size_t)b * BZ_SEL_STRIDE;
+    io.L = Lbuf + (size_t)b * BZ_LSTRIDE;
+    io.flushed = 0;
+    io.cnt = 0;
+    io.stage = 0;
+    io.list = 0;
+    io.lane = threadIdx.x;
+    BzBlockInfo bi;
+    BzBits br;
+    const uint32_t *w = comp + d.word_off;
+    br.init(w, d.nwords, d.start_bit);
+    BzHeader hd;
+    if (bz_read_header(io, br, bi, hd) == BZ_OK) {
+        __syncthreads(); // (selectors written to memory by this wave are read back below)
+        uint64_t bit_end = 0;
+        int st = bz_dev_symbols(io, w, d.nwords, br.pos, hd, d.max_block, bit_end);
+        io.flush_tail();
+        bi.nblock = io.emitted();
+        if (st == BZ_OK && bi.nblock > d.max_block) st = BZ_E_DATA;
+        if (st == BZ_OK && (bi.orig_ptr < 0 || bi.orig_ptr >= bi.nblock)) st = BZ_E_ORIGPTR;
+        if (st == BZ_OK && d.end_bit && bit_end != d.end_bit) st = BZ_E_LENGTH;
+        bi.status = st;
+    }
+    if (threadIdx.x == 0) info[b] = bi;
+}
+
+// ---- tt: stable counting sort of the BWT column ------------------------------------------------------------------------------
+// tt[q] = (i << 8) | L[i] for the i-th byte of L, placed at q = (bytes smaller than L[i]) + (equal bytes before i): following
+// q -> tt[q] >> 8 from orig_ptr yields the block's bytes in order, each step's byte in the low 8 bits of the entry just read.
+__global__ void __launch_bounds__(1024)
+k_bz2_sort(const BzBlockInfo *info, const uint8_t *Lbuf, uint32_t *ttbuf) {
+    const int b = blockIdx.x;
+    if (info[b].status != BZ_OK) return;
+    const int n = info[b].nblock;
+    const uint8_t *L = Lbuf + (size_t)b * BZ_LSTRIDE;
+    uint32_t *tt = ttbuf + (size_t)b * BZ_TSTRIDE;
+    __shared__ int hist[16][256];
+    __shared__ int tot[256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int seg = (((n + 15) / 16) + 63) & ~63, s0 = min(n, wv * seg), s1 = min(n, s0 + seg);
+    for (int k = tid; k < 16 * 256; k += 1024) (&hist[0][0])[k] = 0;
+    __syncthreads();
+    for (int i = s0 + lane; i < s1; i += 64) atomicAdd(&hist[wv][L[i]], 1);
+    __syncthreads();
+    if (tid < 256) {
+        int s = 0;
+        for (int w = 0; w < 16; w++) s += hist[w][tid];
+        tot[tid] = s;
+    }
+    __syncthreads();
+    if (wv == 0) { // exclusive scan of the 256 totals: four per lane, then across the wave
+        int a0 = tot[4 * lane], a1 = tot[4 * lane + 1], a2 = tot[4 * lane + 2], a3 = tot[4 * lane + 3];
+        int inc = a0 + a1 + a2 + a3;
+        const int loc = inc;
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        int run = inc - loc;
+        tot[4 * lane] = run; run += a0;
+        tot[4 * lane + 1] = run; run += a1;
+        tot[4 * lane + 2] = run; run += a2;
+        tot[4 * lane + 3] = run;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        int run = tot[tid];
+        for (int w = 0; w < 16; w++) {
+            const int t = hist[w][tid];
+            hist[w][tid] = run;
+            run += t;
+        }
+    }
+    __syncthreads();
+    for (int i0 = s0; i0 < s1; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < s1;
+        const uint32_t v = valid ? L[i] : 0u;
+        u64 m = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+            const bool one = (v >> bit) & 1u;
+            const u64 bal = __ballot(one);
+            m &= one ? bal : ~bal;
+        }
+        const int rank = __popcll(m & ((1ull << lane) - 1ull)), peers = __popcll(m);
+        int base = 0;
+        if (valid) {
+            base = hist[wv][v];
+            tt[base + rank] = ((uint32_t)i << 8) | v;
+        }
+        if (valid && rank == peers - 1) hist[wv][v] = base + peers;
+    }
+}
+
+// ---- inverse BWT by list ranking --------------------------------------------------------------------------------------------
+struct BzPacker { // consecutive bytes to memory, as word stores wherever a whole aligned word belongs to this writer
+    uint8_t *cur;
+    uint32_t acc;
+    int have, count;
+    __device__ __forceinline__ void init(uint8_t *at) { cur = at; acc = 0; have = 0; count = 0; }
+    __device__ __forceinline__ void put(uint32_t b) {
+        const int sh = (int)((uintptr_t)cur & 3);
+        acc |= b << (8 * sh);
+        have++;
+        if (sh == 3) {
+            if (have == 4) *(uint32_t *)(cur - 3) = acc;
+            else for (int j = 4 - have; j < 4; j++) cur[j - 3] = (uint8_t)(acc >> (8 * j));
+            acc = 0;
+            have = 0;
+        }
+        cur++;
+        count++;
+    }
+    __device__ __forceinline__ void finish() { // (the bytes still in acc end right before cur)
+        for (int j = 0; j < have; j++) {
+            uint8_t *a = cur - have + j;
+            *a = (uint8_t)(acc >> (8 * (int)((uintptr_t)a & 3)));
+        }
+        have = 0;
+        acc = 0;
+    }
+};
+
+#define BZ_CHAINS 4 // splitters per thread, walked side by side (independent loads in flight)
+__global__ void __launch_bounds__(1024)
+k_bz2_walk(BzBlockInfo *info, const uint32_t *ttbuf, uint8_t *prebuf) {
+    const int b = blockIdx.x;
+    if (info[b].status != BZ_OK) return;
+    const int n = info[b].nblock;
+    const uint32_t orig = (uint32_t)info[b].orig_ptr;
+    const uint32_t *tt = ttbuf + (size_t)b * BZ_TSTRIDE;
+    uint8_t *pre = prebuf + (size_t)b * BZ_LSTRIDE;
+    __shared__ int nxt[BZ_MAX_SPLIT], slen[BZ_MAX_SPLIT], spos[BZ_MAX_SPLIT];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x;
+    const int G = 1 << BZ_SPLIT_LOG;
+    const int Ks = (n + G - 1) >> BZ_SPLIT_LOG; // regular splitters 0 .. Ks - 1 at q = s G; splitter Ks is orig_ptr, the head of the chain
+    for (int k = tid; k <= Ks; k += 1024) spos[k] = -1;
+    uint32_t q[BZ_CHAINS];
+    int len[BZ_CHAINS];
+    bool on[BZ_CHAINS];
+#pragma unroll
+    for (int k = 0; k < BZ_CHAINS; k++) {
+        const int s = tid + 1024 * k;
+        on[k] = s <= Ks;
+        q[k] = s == Ks ? orig : ((uint32_t)s << BZ_SPLIT_LOG);
+        len[k] = 0;
+    }
+    for (int step = 0; step < n; step++) { // (a chain ends at the next splitter: ~256 steps on average)
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < BZ_CHAINS; k++)
+            if (on[k]) {
+                q[k] = tt[q[k]] >> 8;
+                len[k]++;
+                if ((q[k] & (uint32_t)(G - 1)) == 0u || q[k] == orig) {
+                    const int s = tid + 1024 * k;
+                    nxt[s] = q[k] == orig ? Ks : (int)(q[k] >> BZ_SPLIT_LOG);
+                    slen[s] = len[k];
+                    on[k] = false;
+                } else any = true;
+            }
+        if (!any) break;
+    }
+    __syncthreads();
+    if (tid == 0) { // the splitters in chain order: where in the output each one's stretch begins
+        int pos = 0, j = Ks, ok = 1;
+        while (pos < n) {
+            if (spos[j] != -1) { ok = 0; break; } // back at a splitter before n steps: the permutation has a shorter cycle
+            spos[j] = pos;
+            pos += slen[j];
+            j = nxt[j];
+        }
+        if (pos != n) ok = 0;
+        s_ok = ok;
+        if (!ok) info[b].status = BZ_E_CYCLE;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    BzPacker pk[BZ_CHAINS];
+    int left[BZ_CHAINS];
+#pragma unroll
+    for (int k = 0; k < BZ_CHAINS; k++) {
+        const int s = tid + 1024 * k;
+        const int p0 = s <= Ks ? spos[s] : -1;
+        left[k] = p0 >= 0 ? slen[s] : 0;
+        q[k] = s == Ks ? orig : ((uint32_t)s << BZ_SPLIT_LOG);
+        pk[k].init(pre + (p0 >= 0 ? p0 : 0));
+    }
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < BZ_CHAINS; k++)
+            if (left[k] > 0) {
+                const uint32_t e = tt[q[k]];
+                pk[k].put(e & 0xffu);
+                q[k] = e >> 8;
+                left[k]--;
+                any = true;
+            }
+        if (!any) break;
+    }
+#pragma unroll
+    for (int k = 0; k < BZ_CHAINS; k++) pk[k].finish();
+}
+
+// ---- run-length layer ----------------------------------------------------------------------------------------------------------
+// A thread's stretch starts at a position whose byte differs from the one before it, so the only thing it inherits is whether its
+// first byte is the COUNT of a run of four that ended exactly at the stretch's start (c = 1) or not (c = 0).
+struct BzRle { int c_out, size; };
+__device__ __forceinline__ BzRle bz_rle_parse(const uint8_t *pre, int s, int e, int c) {
+    BzRle r;
+    r.size = 0;
+    int p = s;
+    if (c) {
+        if (p >= e) { r.c_out = 1; return r; } // nothing here: the count is further on
+        r.size += pre[p++];
+    }
+    int k = 0, v = -1;
+    while (p < e) {
+        const int x = pre[p++];
+        if (k > 0 && x == v) {
+            k++;
+            r.size++;
+            if (k == 4) {
+                if (p >= e) { r.c_out = 1; return r; }
+                r.size += pre[p++];
+                k = 0;
+            }
+        } else { v = x; k = 1; r.size++; }
+    }
+    r.c_out = 0;
+    return r;
+}
+
+__global__ void __launch_bounds__(1024)
+k_bz2_rle_scan(const BzBlockInfo *info, const uint8_t *prebuf, int4 *meta, int *blk_size) {
+    const int b = blockIdx.x;
+    if (info[b].status != BZ_OK) { if (threadIdx.x == 0) blk_size[b] = 0; return; }
+    const int n = info[b].nblock;
+    const uint8_t *pre = prebuf + (size_t)b * BZ_LSTRIDE;
+    __shared__ int bnd[1025];
+    __shared__ int f_c0[2][1024], f_c1[2][1024], f_s0[2][1024], f_s1[2][1024];
+    const int t = threadIdx.x;
+    const int C = (n + 1023) / 1024;
+    int p = min(n, t * C);
+    while (p > 0 && p < n && pre[p] == pre[p - 1]) p++;
+    bnd[t] = p;
+    if (t == 0) bnd[1024] = n;
+    __syncthreads();
+    const int s = bnd[t], e = bnd[t + 1];
+    const BzRle r0 = bz_rle_parse(pre, s, e, 0), r1 = bz_rle_parse(pre, s, e, 1);
+    // inclusive scan of the stretches' transfer functions c -> (c', bytes), composed left to right
+    int c0 = r0.c_out, c1 = r1.c_out, z0 = r0.size, z1 = r1.size, cur = 0;
+    f_c0[0][t] = c0; f_c1[0][t] = c1; f_s0[0][t] = z0; f_s1[0][t] = z1;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        if (t >= off) {
+            // (left part, then this one): the left part's outcome selects which of this part's two rows applies
+            const int lc0 = f_c0[cur][t - off], lc1 = f_c1[cur][t - off], ls0 = f_s0[cur][t - off], ls1 = f_s1[cur][t - off];
+            const int n_c0 = lc0 ? c1 : c0, n_s0 = ls0 + (lc0 ? z1 : z0);
+            const int n_c1 = lc1 ? c1 : c0, n_s1 = ls1 + (lc1 ? z1 : z0);
+            c0 = n_c0; c1 = n_c1; z0 = n_s0; z1 = n_s1;
+        }
+        cur ^= 1;
+        f_c0[cur][t] = c0; f_c1[cur][t] = c1; f_s0[cur][t] = z0; f_s1[cur][t] = z1;
+        __syncthreads();
+    }
+    // a block starts with c = 0: what this thread inherits is the prefix before it applied to 0
+    const int c_in = t ? f_c0[cur][t - 1] : 0, off_in = t ? f_s0[cur][t - 1] : 0;
+    meta[(size_t)b * 1024 + t] = make_int4(s, e, c_in, off_in);
+    if (t == 1023) blk_size[b] = z0;
+}
+
+__global__ void k_bz2_offsets(const BzBlockInfo *info, const int *blk_size, const int *file_first, int nfiles, u64 out_cap,
+                              u64 *blk_off, u64 *out_len, int *file_status) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nfiles) return;
+    u64 off = 0;
+    int st = file_status[f];
+    for (int b = file_first[f]; b < file_first[f + 1]; b++) {
+        if (info[b].status != BZ_OK && st == BZ_OK) st = info[b].status;
+        blk_off[b] = off;
+        off += (u64)blk_size[b];
+    }
+    if (st == BZ_OK && off > out_cap) st = BZ_E_SIZE;
+    out_len[f] = off;
+    file_status[f] = st;
+}
+
+struct BzCrcPow { uint32_t pw[24]; }; // x^(8 * 2^k) mod P
+
+__device__ __forceinline__ uint32_t bz_gf_mul(uint32_t a, uint32_t b) { // a * b mod P, bit i = coefficient of x^i
+    uint32_t r = 0;
+    for (int i = 31; i >= 0; i--) {
+        r = (r << 1) ^ ((r & 0x80000000u) ? 0x04c11db7u : 0u);
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return r;
+}
+
+__global__ void __launch_bounds__(1024)
+k_bz2_expand(const BzBlockInfo *info, const BzBlockDesc *desc, const uint8_t *prebuf, const int4 *meta, const int *blk_size,
+             const u64 *blk_off, uint8_t *out, u64 out_cap, int *file_status, BzCrcPow pows) {
+    const int b = blockIdx.x;
+    const int f = desc[b].file;
+    if (file_status[f] != BZ_OK) return;
+    const uint8_t *pre = prebuf + (size_t)b * BZ_LSTRIDE;
+    __shared__ uint32_t tab[256];
+    __shared__ uint32_t red[16];
+    const int t = threadIdx.x;
+    if (t < 256) tab[t] = bz_crc_table_entry((uint32_t)t);
+    __syncthreads();
+    const int4 m = meta[(size_t)b * 1024 + t];
+    const int total = blk_size[b];
+    BzPacker pk;
+    pk.init(out + (size_t)f * out_cap + blk_off[b] + m.w);
+    uint32_t crc = 0;
+    int p = m.x;
+    const int e = m.y;
+    auto put = [&](uint32_t v) {
+        pk.put(v);
+        crc = (crc << 8) ^ tab[(crc >> 24) ^ v];
+    };
+    if (m.z && p < e) { // the count of the run of four that ended right before this stretch
+        const uint32_t v = pre[p - 1];
+        const int rep = pre[p++];
+        for (int k = 0; k < rep; k++) put(v);
+    }
+    {
+        int k = 0, v = -1;
+        while (p < e) {
+            const int x = pre[p++];
+            if (k > 0 && x == v) {
+                k++;
+                put((uint32_t)x);
+                if (k == 4) {
+                    if (p >= e) break; // (its count is the next stretch's first byte)
+                    const int rep = pre[p++];
+                    for (int j = 0; j < rep; j++) put((uint32_t)x);
+                    k = 0;
+                }
+            } else { v = x; k = 1; put((uint32_t)x); }
+        }
+    }
+    pk.finish();
+    // this stretch's CRC (register started at 0), moved to the end of the block: times x^(8 * bytes after it)
+    const int after = total - (m.w + pk.count);
+    uint32_t pw = 1u;
+    for (int k = 0; k < 24; k++)
+        if ((after >> k) & 1) pw = bz_gf_mul(pw, pows.pw[k]);
+    uint32_t part = bz_gf_mul(crc, pw);
+    if (t == 0) { // the initial register value 0xffffffff, moved across the whole block
+        uint32_t pa = 1u;
+        for (int k = 0; k < 24; k++)
+            if ((total >> k) & 1) pa = bz_gf_mul(pa, pows.pw[k]);
+        part ^= bz_gf_mul(0xffffffffu, pa);
+    }
+    for (int off = 32; off > 0; off >>= 1) part ^= __shfl_xor(part, off);
+    if ((t & 63) == 0) red[t >> 6] = part;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t c = 0;
+        for (int k = 0; k < 16; k++) c ^= red[k];
+        c = ~c;
+        if (c != info[b].crc) atomicCAS(&file_status[f], BZ_OK, BZ_E_CRC);
+    }
+}
+
+// first `head` bytes of every decoded file, side by side (for the caller's header parsing)
+__global__ void k_bz2_heads(const uint8_t *out, u64 out_cap, const u64 *out_len, uint8_t *heads, u64 head) {
+    const int f = blockIdx.y;
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= head) return;
+    heads[(size_t)f * head + i] = i < out_len[f] ? out[(size_t)f * out_cap + i] : 0;
+}
