@@ -1,0 +1,119 @@
+"""bzip2 on the device (lfdmi_bz2_*, lfd_amd/csrc/k_bz2.h): whole files against Python's bz2 module -- the step the reference
+performs with `bunzip2` in front of every compressed frame (detecttrails.py:81-109) -- and the loader that uses it."""
+import bz2
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pack(blobs):
+    off, cur = [], 0
+    for c in blobs:
+        off.append(cur)
+        cur += (len(c) + 7) & ~7
+    src = np.zeros(max(cur, 8), np.uint8)
+    for o, c in zip(off, blobs):
+        src[o:o + len(c)] = np.frombuffer(c, np.uint8)
+    return src, off, [len(c) for c in blobs]
+
+
+def _plains():
+    rng = np.random.default_rng(7)
+    hdr = b"".join(c.ljust(80) for c in (b"SIMPLE  =                    T", b"BITPIX  =                  -32", b"END")).ljust(2880)
+    img = rng.normal(0.0, 0.025, (700, 1024)).astype(">f4")
+    img[100:180, 50:900] = 0.0                                       # long zero runs: the run-length layer and RUNA / RUNB
+    sky = (rng.normal(1000.0, 3.0, (400, 1024)).astype(np.float32)).astype(">f4")    # compressible: few distinct high bytes
+    return {
+        "text": b"the quick brown fox jumps over the lazy dog. " * 40 + b"!",
+        "runs": b"a" * 1000 + b"b" * 5 + bytes(300) + b"xyz" * 7 + b"\xfb" * 2000 + b"q" * 4 + b"r" * 259 + b"ssss",
+        "noise": rng.integers(0, 256, 300000, dtype=np.uint8).tobytes(),
+        "one": b"z",
+        "four": b"zzzz",
+        "five": b"zzzzz",
+        "zeros": bytes(2_500_000),
+        "fits": hdr + img.tobytes(),
+        "sky": hdr + sky.tobytes(),
+        "few_symbols": bytes(rng.integers(0, 3, 50000, dtype=np.uint8)),
+        "count_equals_byte": bytes([5]) * 9 + b"x" + bytes([251]) * 600 + b"y",
+    }
+
+
+@pytest.mark.parametrize("level", [1, 9])
+def test_whole_files_against_python_bz2(level):
+    from lfd_amd import _native as Nv
+    plains = _plains()
+    blobs = [bz2.compress(p, level) for p in plains.values()]
+    src, off, ln = _pack(blobs)
+    with Nv.Bz2Decoder(0) as z:
+        out_len, status, heads = z.decode(src, off, ln, 4 << 20, 2880)
+        for i, (name, p) in enumerate(plains.items()):
+            assert status[i] == 0, (name, int(status[i]), Nv.BZ2_STATUS.get(int(status[i])))
+            assert int(out_len[i]) == len(p), name
+            assert z.fetch(i, 0, len(p)).tobytes() == p, name
+            assert heads[i].tobytes() == p[:2880].ljust(2880, b"\0"), name
+            if len(p) > 5000:
+                assert z.fetch(i, 1234, 3000).tobytes() == p[1234:4234], name
+        # a second batch on the same handle (buffers reused), other order
+        src2, off2, ln2 = _pack(blobs[::-1])
+        out_len2, status2, _ = z.decode(src2, off2, ln2, 4 << 20)
+        assert list(out_len2) == list(out_len[::-1]) and not status2.any()
+
+
+def test_what_the_decoder_declines_is_reported_not_guessed():
+    from lfd_amd import _native as Nv
+    good = bz2.compress(_plains()["noise"], 9)
+    flipped = bytearray(good)
+    flipped[len(flipped) // 2] ^= 0x10
+    periodic = bz2.compress(b"abcd" * 5000)                          # its BWT permutation has cycles shorter than the block
+    blobs = [bz2.compress(b"abc") + bz2.compress(b"def"),            # two streams joined (valid bzip2; host decoder's job)
+             bytes(flipped), b"not bzip2 at all", good + b"\0", good[:len(good) // 2], periodic, good]
+    src, off, ln = _pack(blobs)
+    with Nv.Bz2Decoder(0) as z:
+        out_len, status, _ = z.decode(src, off, ln, 1 << 20)
+        assert all(int(s) != 0 for s in status[:6]), list(status)
+        assert status[6] == 0 and z.fetch(6, 0, int(out_len[6])).tobytes() == _plains()["noise"]
+        with pytest.raises(Nv.NativeError):
+            z.fetch(1, 0, 10)
+        # too small an output buffer: declined as such
+        out_len, status, _ = z.decode(*_pack([good]), 1000)
+        assert int(status[0]) == 9
+
+
+def test_loader_decodes_a_chunk_of_bz2_frames_on_the_device(tmp_path, monkeypatch):
+    from lfd_amd import _native as Nv, synth
+    from lfd_amd.detecttrails import loader, sdssfiles
+    shape, n = (256, 384), 6
+    frames, cats = [], []
+    for k in range(n):
+        img, cat, _ = synth.make_portable_frame(k, shape, n_star=7)
+        frames.append(img)
+        cats.append(cat)
+    hdr = synth.write_boss_tree(tmp_path, frames, cats, field0=100, bz2_fields=set(range(100, 100 + n)))
+    bad = sdssfiles.filename("frame", 94, 1, 103, "r") + ".bz2"     # one damaged file: the host decoder's error, as before
+    data = bytearray(open(bad, "rb").read())
+    data[len(data) // 2] ^= 0x40
+    open(bad, "wb").write(bytes(data))
+    keys = [(94, 1, "r", f) for f in range(100, 100 + n)]
+    with Nv.Context(0, shape[0], shape[1], 8) as ctx:
+        with loader.FrameLoader(ctx, shape, 8, threads=3) as ld:
+            out = ld.load(keys, 0)
+            for i in range(n):
+                if i == 3:
+                    assert isinstance(out.error[i], (OSError, ValueError, EOFError))
+                    continue
+                assert out.error[i] is None and out.slot[i] >= 0
+                assert np.array_equal(out.buffer[out.slot[i]].astype(np.float32), frames[i])
+                assert loader.header_values(out.hdr[i], ["TAI"]) == [hdr["TAI"]]
+            assert ld.bz2_stats["device_frames"] == n - 1 and ld.bz2_stats["host_frames"] == 1
+        monkeypatch.setenv("LFD_BZ2_DEVICE", "0")
+        with loader.FrameLoader(ctx, shape, 8, threads=3) as ld:
+            out2 = ld.load(keys, 0)
+            assert ld.bz2_stats["device_frames"] == 0
+            for i in range(n):
+                if i != 3:
+                    assert np.array_equal(out2.buffer[out2.slot[i]], out.buffer[out.slot[i]])
+                else:
+                    assert type(out2.error[i]) is type(out.error[i]) and str(out2.error[i]) == str(out.error[i])
