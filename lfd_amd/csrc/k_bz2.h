@@ -429,27 +429,63 @@ k_bz2_walk(BzBlockInfo *info, const uint32_t *ttbuf, uint8_t *prebuf) {
 }
 
 // ---- run-length layer ----------------------------------------------------------------------------------------------------------
-// A thread's stretch starts at a position whose byte differs from the one before it, so the only thing it inherits is whether its
-// first byte is the COUNT of a run of four that ended exactly at the stretch's start (c = 1) or not (c = 0).
+// bzip2's first stage: after four equal bytes the next byte is a COUNT of further repeats.  A block's bytes are cut into tiles of
+// 32 kB (a workgroup each) and stretches of ~32 bytes (a thread each).  A stretch starts at a position whose byte differs from
+// the one before it, so the only thing it inherits is whether its first byte is the count of a run of four that ended exactly
+// there (c = 1) or not (c = 0): every stretch is parsed under both assumptions, the resulting functions c -> (c', bytes written)
+// are composed by a scan inside the tile, tile by tile inside the block (k_bz2_rle_blocks), and the expansion then knows every
+// stretch's true entry state and output offset.  Tiles are staged in LDS with coalesced loads (a thread's stretch is strided
+// 36 bytes there: 9 words, no bank conflicts) and the output leaves through an LDS window with aligned word stores.
+#define BZ_RT 32                      // nominal bytes per thread
+#define BZ_TILE (1024 * BZ_RT)        // bytes per tile
+#define BZ_MAX_TILES 28               // 900 000 / 32 768, rounded up
+#define BZ_OUTW (36 * 1024)           // output window of a tile in LDS (what does not fit is stored directly)
+
 struct BzRle { int c_out, size; };
-__device__ __forceinline__ BzRle bz_rle_parse(const uint8_t *pre, int s, int e, int c) {
+struct BzTile { // a tile of the pre-run-length bytes in LDS
+    const uint32_t *sm;
+    const uint8_t *pre;
+    int base, n;
+    __device__ __forceinline__ uint32_t get(int p) const { // 0 <= p < n
+        const int rel = p - base;
+        if (rel >= 0 && rel < BZ_TILE) return (sm[(rel >> 5) * 9 + ((rel & 31) >> 2)] >> ((rel & 3) << 3)) & 0xffu;
+        return pre[p];
+    }
+};
+__device__ __forceinline__ void bz_tile_stage(uint32_t *sm, const uint8_t *pre, int base, int n, int tid) {
+    for (int j = tid; j < BZ_TILE / 16; j += 1024) {
+        const int p = base + 16 * j;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (p < n) v = *(const uint4 *)(pre + p); // (the buffers are padded beyond n: whole 16-byte pieces can be read)
+        uint32_t *d = sm + (j >> 1) * 9 + (j & 1) * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+__device__ __forceinline__ int bz_tile_boundary(const BzTile &t, int from) { // first position >= from where a run of equal bytes starts
+    int p = min(t.n, from);
+    while (p > 0 && p < t.n && t.get(p) == t.get(p - 1)) p++;
+    return p;
+}
+__device__ __forceinline__ BzRle bz_rle_parse(const BzTile &t, int s, int e, int c) {
     BzRle r;
     r.size = 0;
     int p = s;
     if (c) {
         if (p >= e) { r.c_out = 1; return r; } // nothing here: the count is further on
-        r.size += pre[p++];
+        r.size += (int)t.get(p++);
     }
-    int k = 0, v = -1;
+    int k = 0;
+    uint32_t v = 0x100u;
     while (p < e) {
-        const int x = pre[p++];
-        if (k > 0 && x == v) {
+        const uint32_t x = t.get(p++);
+        if (x == v) {
             k++;
             r.size++;
             if (k == 4) {
                 if (p >= e) { r.c_out = 1; return r; }
-                r.size += pre[p++];
+                r.size += (int)t.get(p++);
                 k = 0;
+                v = 0x100u;
             }
         } else { v = x; k = 1; r.size++; }
     }
@@ -457,30 +493,32 @@ __device__ __forceinline__ BzRle bz_rle_parse(const uint8_t *pre, int s, int e, 
     return r;
 }
 
+// per tile: every stretch's transfer function, scanned; meta = what precedes each stretch inside its tile (for c = 0 / 1 at the
+// tile's start: c', bytes), tile_fn = the whole tile
 __global__ void __launch_bounds__(1024)
-k_bz2_rle_scan(const BzBlockInfo *info, const uint8_t *prebuf, int4 *meta, int *blk_size) {
-    const int b = blockIdx.x;
-    if (info[b].status != BZ_OK) { if (threadIdx.x == 0) blk_size[b] = 0; return; }
-    const int n = info[b].nblock;
-    const uint8_t *pre = prebuf + (size_t)b * BZ_LSTRIDE;
+k_bz2_rle_tiles(const BzBlockInfo *info, const uint8_t *prebuf, int4 *meta, int4 *tile_fn) {
+    const int b = blockIdx.y, tile = blockIdx.x;
+    if (info[b].status != BZ_OK) return;
+    const int n = info[b].nblock, base = tile * BZ_TILE;
+    if (base >= n) return;
+    __shared__ uint32_t sm[1024 * 9];
     __shared__ int bnd[1025];
     __shared__ int f_c0[2][1024], f_c1[2][1024], f_s0[2][1024], f_s1[2][1024];
     const int t = threadIdx.x;
-    const int C = (n + 1023) / 1024;
-    int p = min(n, t * C);
-    while (p > 0 && p < n && pre[p] == pre[p - 1]) p++;
-    bnd[t] = p;
-    if (t == 0) bnd[1024] = n;
+    BzTile T;
+    T.sm = sm; T.pre = prebuf + (size_t)b * BZ_LSTRIDE; T.base = base; T.n = n;
+    bz_tile_stage(sm, T.pre, base, n, t);
+    __syncthreads();
+    bnd[t] = bz_tile_boundary(T, base + BZ_RT * t);
+    if (t == 1023) bnd[1024] = bz_tile_boundary(T, base + BZ_TILE);
     __syncthreads();
     const int s = bnd[t], e = bnd[t + 1];
-    const BzRle r0 = bz_rle_parse(pre, s, e, 0), r1 = bz_rle_parse(pre, s, e, 1);
-    // inclusive scan of the stretches' transfer functions c -> (c', bytes), composed left to right
+    const BzRle r0 = bz_rle_parse(T, s, e, 0), r1 = bz_rle_parse(T, s, e, 1);
     int c0 = r0.c_out, c1 = r1.c_out, z0 = r0.size, z1 = r1.size, cur = 0;
     f_c0[0][t] = c0; f_c1[0][t] = c1; f_s0[0][t] = z0; f_s1[0][t] = z1;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-        if (t >= off) {
-            // (left part, then this one): the left part's outcome selects which of this part's two rows applies
+        if (t >= off) { // (left part, then this one): the left part's outcome selects which of this part's two rows applies
             const int lc0 = f_c0[cur][t - off], lc1 = f_c1[cur][t - off], ls0 = f_s0[cur][t - off], ls1 = f_s1[cur][t - off];
             const int n_c0 = lc0 ? c1 : c0, n_s0 = ls0 + (lc0 ? z1 : z0);
             const int n_c1 = lc1 ? c1 : c0, n_s1 = ls1 + (lc1 ? z1 : z0);
@@ -490,10 +528,27 @@ k_bz2_rle_scan(const BzBlockInfo *info, const uint8_t *prebuf, int4 *meta, int *
         f_c0[cur][t] = c0; f_c1[cur][t] = c1; f_s0[cur][t] = z0; f_s1[cur][t] = z1;
         __syncthreads();
     }
-    // a block starts with c = 0: what this thread inherits is the prefix before it applied to 0
-    const int c_in = t ? f_c0[cur][t - 1] : 0, off_in = t ? f_s0[cur][t - 1] : 0;
-    meta[(size_t)b * 1024 + t] = make_int4(s, e, c_in, off_in);
-    if (t == 1023) blk_size[b] = z0;
+    const size_t ti = (size_t)b * BZ_MAX_TILES + tile;
+    meta[ti * 1024 + t] = t ? make_int4(f_c0[cur][t - 1], f_c1[cur][t - 1], f_s0[cur][t - 1], f_s1[cur][t - 1]) : make_int4(0, 1, 0, 0);
+    if (t == 1023) tile_fn[ti] = make_int4(c0, c1, z0, z1);
+}
+
+// per block: the tiles in order -> every tile's entry state and output offset inside the block, and the block's size
+__global__ void k_bz2_rle_blocks(const BzBlockInfo *info, const int4 *tile_fn, int2 *tile_in, int *blk_size, int nblocks) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    int c = 0, off = 0;
+    if (info[b].status == BZ_OK) {
+        const int nt = (info[b].nblock + BZ_TILE - 1) / BZ_TILE;
+        for (int k = 0; k < nt; k++) {
+            const size_t ti = (size_t)b * BZ_MAX_TILES + k;
+            tile_in[ti] = make_int2(c, off);
+            const int4 f = tile_fn[ti];
+            off += c ? f.w : f.z;
+            c = c ? f.y : f.x;
+        }
+    }
+    blk_size[b] = off;
 }
 
 __global__ void k_bz2_offsets(const BzBlockInfo *info, const int *blk_size, const int *file_first, int nfiles, u64 out_cap,
@@ -522,73 +577,108 @@ __device__ __forceinline__ uint32_t bz_gf_mul(uint32_t a, uint32_t b) { // a * b
     }
     return r;
 }
+__device__ __forceinline__ uint32_t bz_x_pow8(const BzCrcPow &pows, int nbytes) { // x^(8 nbytes) mod P
+    uint32_t pw = 1u;
+    for (int k = 0; k < 24; k++)
+        if ((nbytes >> k) & 1) pw = bz_gf_mul(pw, pows.pw[k]);
+    return pw;
+}
 
+// the file's bytes + every stretch's share of its block's CRC (register started at 0, moved to the block's end: times
+// x^(8 * bytes after it) mod P; the shares are xor-ed together in blk_crc, k_bz2_crc_check compares)
 __global__ void __launch_bounds__(1024)
-k_bz2_expand(const BzBlockInfo *info, const BzBlockDesc *desc, const uint8_t *prebuf, const int4 *meta, const int *blk_size,
-             const u64 *blk_off, uint8_t *out, u64 out_cap, int *file_status, BzCrcPow pows) {
-    const int b = blockIdx.x;
+k_bz2_expand(const BzBlockInfo *info, const BzBlockDesc *desc, const uint8_t *prebuf, const int4 *meta, const int4 *tile_fn,
+             const int2 *tile_in, const int *blk_size, const u64 *blk_off, uint8_t *out, u64 out_cap, const int *file_status,
+             uint32_t *blk_crc, BzCrcPow pows) {
+    const int b = blockIdx.y, tile = blockIdx.x;
     const int f = desc[b].file;
     if (file_status[f] != BZ_OK) return;
-    const uint8_t *pre = prebuf + (size_t)b * BZ_LSTRIDE;
+    const int n = info[b].nblock, base = tile * BZ_TILE;
+    if (base >= n) return;
+    __shared__ uint32_t sm[1024 * 9];
+    __shared__ uint32_t ow[BZ_OUTW / 4 + 1];
+    __shared__ int bnd[1025];
     __shared__ uint32_t tab[256];
-    __shared__ uint32_t red[16];
     const int t = threadIdx.x;
+    BzTile T;
+    T.sm = sm; T.pre = prebuf + (size_t)b * BZ_LSTRIDE; T.base = base; T.n = n;
+    bz_tile_stage(sm, T.pre, base, n, t);
     if (t < 256) tab[t] = bz_crc_table_entry((uint32_t)t);
     __syncthreads();
-    const int4 m = meta[(size_t)b * 1024 + t];
+    bnd[t] = bz_tile_boundary(T, base + BZ_RT * t);
+    if (t == 1023) bnd[1024] = bz_tile_boundary(T, base + BZ_TILE);
+    __syncthreads();
+    const size_t ti = (size_t)b * BZ_MAX_TILES + tile;
+    const int2 tin = tile_in[ti];
+    const int4 tf = tile_fn[ti], pm = meta[ti * 1024 + t];
+    const int tile_bytes = tin.x ? tf.w : tf.z;                 // what this tile writes
+    const int c_in = tin.x ? pm.y : pm.x;
+    const int off = tin.y + (tin.x ? pm.w : pm.z);              // this stretch's first output byte inside the block
     const int total = blk_size[b];
-    BzPacker pk;
-    pk.init(out + (size_t)f * out_cap + blk_off[b] + m.w);
+    uint8_t *dst = out + (size_t)f * out_cap + blk_off[b];      // the block's output
+    uint8_t *owb = (uint8_t *)ow;
     uint32_t crc = 0;
-    int p = m.x;
-    const int e = m.y;
+    int o = off - tin.y;                                        // position inside the tile's output
     auto put = [&](uint32_t v) {
-        pk.put(v);
+        if (o < BZ_OUTW) owb[o] = (uint8_t)v;
+        else dst[tin.y + o] = (uint8_t)v;
+        o++;
         crc = (crc << 8) ^ tab[(crc >> 24) ^ v];
     };
-    if (m.z && p < e) { // the count of the run of four that ended right before this stretch
-        const uint32_t v = pre[p - 1];
-        const int rep = pre[p++];
+    int p = bnd[t];
+    const int e = bnd[t + 1];
+    if (c_in && p < e) { // the count of the run of four that ended right before this stretch
+        const uint32_t v = T.get(p - 1);
+        const int rep = (int)T.get(p++);
         for (int k = 0; k < rep; k++) put(v);
     }
     {
-        int k = 0, v = -1;
+        int k = 0;
+        uint32_t v = 0x100u;
         while (p < e) {
-            const int x = pre[p++];
-            if (k > 0 && x == v) {
+            const uint32_t x = T.get(p++);
+            if (x == v) {
                 k++;
-                put((uint32_t)x);
+                put(x);
                 if (k == 4) {
                     if (p >= e) break; // (its count is the next stretch's first byte)
-                    const int rep = pre[p++];
-                    for (int j = 0; j < rep; j++) put((uint32_t)x);
+                    const int rep = (int)T.get(p++);
+                    for (int j = 0; j < rep; j++) put(x);
                     k = 0;
+                    v = 0x100u;
                 }
-            } else { v = x; k = 1; put((uint32_t)x); }
+            } else { v = x; k = 1; put(x); }
         }
     }
-    pk.finish();
-    // this stretch's CRC (register started at 0), moved to the end of the block: times x^(8 * bytes after it)
-    const int after = total - (m.w + pk.count);
-    uint32_t pw = 1u;
-    for (int k = 0; k < 24; k++)
-        if ((after >> k) & 1) pw = bz_gf_mul(pw, pows.pw[k]);
-    uint32_t part = bz_gf_mul(crc, pw);
-    if (t == 0) { // the initial register value 0xffffffff, moved across the whole block
-        uint32_t pa = 1u;
-        for (int k = 0; k < 24; k++)
-            if ((total >> k) & 1) pa = bz_gf_mul(pa, pows.pw[k]);
-        part ^= bz_gf_mul(0xffffffffu, pa);
-    }
-    for (int off = 32; off > 0; off >>= 1) part ^= __shfl_xor(part, off);
-    if ((t & 63) == 0) red[t >> 6] = part;
+    const int after = total - (tin.y + o);
+    uint32_t part = bz_gf_mul(crc, bz_x_pow8(pows, after));
+    if (t == 0 && tile == 0) part ^= bz_gf_mul(0xffffffffu, bz_x_pow8(pows, total)); // the initial register value, moved across the whole block
+    for (int sh = 32; sh > 0; sh >>= 1) part ^= __shfl_xor(part, sh);
+    if ((t & 63) == 0 && part) atomicXor(&blk_crc[b], part);
     __syncthreads();
-    if (t == 0) {
-        uint32_t c = 0;
-        for (int k = 0; k < 16; k++) c ^= red[k];
-        c = ~c;
-        if (c != info[b].crc) atomicCAS(&file_status[f], BZ_OK, BZ_E_CRC);
+    // the window -> memory: bytes up to the first aligned address, whole words, the last bytes
+    const int cnt = min(tile_bytes, BZ_OUTW);
+    uint8_t *d0 = dst + tin.y;
+    const int head = min(cnt, (int)((4 - ((uintptr_t)d0 & 3)) & 3));
+    if (t < head) d0[t] = owb[t];
+    const int nwords = (cnt - head) >> 2;
+    const int sh8 = (head & 3) << 3;
+    uint32_t *dw = (uint32_t *)(d0 + head);
+    for (int k = t; k < nwords; k += 1024) {
+        const int w = (head >> 2) + k; // (head < 4: w = k)
+        const uint32_t lo = ow[w], hi = ow[w + 1];
+        dw[k] = sh8 ? (lo >> sh8) | (hi << (32 - sh8)) : lo;
     }
+    const int done = head + 4 * nwords;
+    if (t < cnt - done) d0[done + t] = owb[done + t];
+}
+
+__global__ void k_bz2_crc_check(const BzBlockInfo *info, const BzBlockDesc *desc, const uint32_t *blk_crc, int *file_status, int nblocks) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const int f = desc[b].file;
+    if (file_status[f] != BZ_OK) return;
+    if (~blk_crc[b] != info[b].crc) atomicCAS(&file_status[f], BZ_OK, BZ_E_CRC);
 }
 
 // first `head` bytes of every decoded file, side by side (for the caller's header parsing)
