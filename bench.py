@@ -650,7 +650,8 @@ def dropin_leg(state, args, dev_index):
     old_env = {k: os.environ.get(k) for k in ("BOSS_PHOTOOBJ", "PHOTO_REDUX", "LFD_DEVICE")}
     try:
         os.environ["LFD_DEVICE"] = str(dev_index)
-        for label, distinct, total, bz in (("plain", n, max(n, args.dropin_frames), False), ("bz2", min(n, args.dropin_bz2), 0, True)):
+        for label, distinct, total, bz in (("plain", n, max(n, args.dropin_frames), False),
+                                           ("bz2", min(n, args.dropin_bz2), args.dropin_bz2_frames, True)):
             if distinct <= 0:
                 continue
             total = max(total, distinct)
@@ -678,20 +679,48 @@ def dropin_leg(state, args, dev_index):
                           "rows": len(rows), "rows_equal_device_resident_run": rows == want, "errors_logged": errs,
                           "tree_write_s": round(t_write, 1)}
             if bz:
-                # a .fits.bz2 is decoded by the host's cores and nothing else: frames/s = usable cores x frames/s per core.  The small
-                # selection (fewer files than cores) is where the blocks of a file are decoded side by side (bz2blocks)
+                # .fits.bz2 frames are decompressed on the GPU, a chunk's files at once (lfdmi_bz2_decode_batch); beside it: what the
+                # host's cores do with the same files (the reference's way: one bunzip2 per frame), measured on a bounded sample
                 from lfd_amd import usable_cores
                 from lfd_amd.detecttrails import bz2blocks, sdssfiles
                 cores = usable_cores()
-                out[label]["usable_cores"] = cores
-                out[label]["frames_per_s_per_core"] = round(total / el / cores, 2)
+                out[label]["decoded_on"] = st.get("bz2", {})
                 blob = open(sdssfiles.filename("frame", run=94, camcol=1, field=100, filter="r") + ".bz2", "rb").read()
+                out[label]["compressed_MB_per_frame"] = round(len(blob) / 1e6, 2)
                 import bz2 as _bz2
                 t0 = time.perf_counter(); a = _bz2.decompress(blob); t_whole = time.perf_counter() - t0
                 bz2blocks.decompress(blob, bz2blocks.shared_pool())
                 t0 = time.perf_counter(); b = bz2blocks.decompress(blob, bz2blocks.shared_pool()); t_blocks = time.perf_counter() - t0
-                out[label]["one_frame_latency_s"] = {"whole_file_one_core": round(t_whole, 3), "blocks_side_by_side": round(t_blocks, 3),
-                                                     "equal": a == b, "threads": min(16, cores)}
+                out[label]["host_decoder"] = {"usable_cores": cores, "frames_per_s_per_core": round(1.0 / t_whole, 2),
+                                              "frames_per_s_all_cores_estimate": round(cores / t_whole, 1),
+                                              "one_frame_latency_s": {"whole_file_one_core": round(t_whole, 3),
+                                                                      "blocks_side_by_side": round(t_blocks, 3), "equal": a == b,
+                                                                      "threads": min(16, cores)}}
+                # the decoder alone, the same files already in host memory (no FITS parsing, no detection)
+                try:
+                    from lfd_amd import _native as Nv
+                    import numpy as np
+                    m = min(256, total)
+                    blobs = [open(sdssfiles.filename("frame", run=94, camcol=1, field=100 + (i % distinct), filter="r") + ".bz2", "rb").read()
+                             for i in range(distinct)]
+                    offs, cur = [], 0
+                    for i in range(m):
+                        offs.append(cur)
+                        cur += (len(blobs[i % distinct]) + 255) & ~255
+                    srcb = np.zeros(cur, np.uint8)
+                    for i in range(m):
+                        srcb[offs[i]:offs[i] + len(blobs[i % distinct])] = np.frombuffer(blobs[i % distinct], np.uint8)
+                    with Nv.Bz2Decoder(dev_index) as z:
+                        lens = [len(blobs[i % distinct]) for i in range(m)]
+                        z.decode(srcb, offs, lens, len(a) + (1 << 20))
+                        t0 = time.perf_counter()
+                        ol, stt, _ = z.decode(srcb, offs, lens, len(a) + (1 << 20))
+                        td = time.perf_counter() - t0
+                        same = z.fetch(m - 1, 0, int(ol[m - 1])).tobytes() == _bz2.decompress(blobs[(m - 1) % distinct])
+                        out[label]["device_decoder_alone"] = {"frames": m, "frames_per_s": round(m / td, 1), "ms": {k: round(v, 1) for k, v in z.timings().items()},
+                                                              "all_ok": bool((stt == 0).all()), "last_file_equals_python_bz2": bool(same)}
+                except Exception as e:  # noqa: BLE001
+                    out[label]["device_decoder_alone"] = {"error": repr(e)}
             shutil.rmtree(tree, ignore_errors=True)
     finally:
         for k, v in old_env.items():
@@ -725,7 +754,8 @@ def main():
     ap.add_argument("--no-host-leg", action="store_true", help="skip the secondary PCIe-inclusive measurement")
     ap.add_argument("--no-secondary", action="store_true", help="skip the sustained / dropin / lsst legs of the default invocation (profiling runs)")
     ap.add_argument("--sustained-s", type=float, default=3.0)
-    ap.add_argument("--dropin-bz2", type=int, default=64, help="frames of the .bz2 sample of the dropin leg (0 = skip)")
+    ap.add_argument("--dropin-bz2", type=int, default=64, help="distinct frames of the .bz2 sample of the dropin leg (0 = skip)")
+    ap.add_argument("--dropin-bz2-frames", type=int, default=1024, help="fields of the .bz2 run (hard links to the distinct files)")
     ap.add_argument("--dropin-frames", type=int, default=4096, help="fields of the plain-FITS run of the dropin leg (hard links of the batch's frames)")
     ap.add_argument("--lsst-distinct", type=int, default=64, help="distinct frames of the secondary lsst leg (each used 256 / this times)")
     args = ap.parse_args()

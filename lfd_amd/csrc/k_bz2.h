@@ -19,7 +19,7 @@
 
 #define BZ_LSTRIDE 900608     // bytes per block of the L / pre-RLE buffers (>= 900 000 + a staging buffer of 256, a multiple of 256)
 #define BZ_TSTRIDE 900096     // words per block of tt
-#define BZ_SEL_STRIDE 18048
+#define BZ_SEL_STRIDE 21248    // per block: 18 002 selectors, then the six tables' perm[] (3 096 bytes)
 #define BZ_SPLIT_LOG 8        // a splitter every 256 positions of tt
 #define BZ_MAX_SPLIT 3520     // 900 000 / 256 + head, rounded up
 #define BZ_MARK_CAP 256       // magics kept per file (a level-1 file of 12.6 MB has 127 blocks)
@@ -211,13 +211,12 @@ k_bz2_huff(const uint32_t *comp, const BzBlockDesc *desc, BzBlockInfo *info, uin
     const int b = blockIdx.x;
     if (b >= nblocks) return;
     __shared__ __attribute__((aligned(16))) uint16_t s_fast[BZ_MAX_GROUPS * BZ_FAST_SIZE];
-    __shared__ uint16_t s_perm[BZ_MAX_GROUPS * BZ_MAX_ALPHA + 4];
     __shared__ int s_limit[BZ_MAX_GROUPS * BZ_NLEN], s_base[BZ_MAX_GROUPS * BZ_NLEN], s_min[8];
     const BzBlockDesc d = desc[b];
     BzDevIO io;
     io.len = (uint8_t *)s_fast; // code lengths: needed only until the tables exist
     io.fast = s_fast;
-    io.perm = s_perm;
+    io.perm = (uint16_t *)(selbuf + (size_t)b * BZ_SEL_STRIDE + 18048); // (only the bit-by-bit path and the table set-up read it)
     io.limit = s_limit;
     io.base = s_base;
     io.min_len = s_min;

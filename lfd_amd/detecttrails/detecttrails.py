@@ -411,7 +411,7 @@ class DetectTrails:
         At most ``batch`` frames go to the GPU per call (same rows, same order as frame by frame; ``batch=1`` is the
         reference's frame-at-a-time loop).  A pool of ``loader_threads`` reader threads (default: one per core, at most 32;
         $LFD_LOADER_THREADS) reads the FITS / .fits.bz2 files of the next chunk straight into page-locked staging memory
-        while the GPU works on the current one (``loader.FrameLoader``; chunks of min(batch, $LFD_LOADER_SLOTS = 64) frames:
+        while the GPU works on the current one (``loader.FrameLoader``; chunks of min(batch, $LFD_LOADER_SLOTS = 64, or 256 for a selection of .fits.bz2 files) frames:
         two 0.8 GB staging buffers keep the link busy, larger ones only cost set-up time); the big-endian floats are swapped
         on the device.  With ``world_size`` > 1 (default: $RANK / $WORLD_SIZE, i.e. one process per GPU under torchrun) every
         rank processes one contiguous block of the selection (``lfd_amd.batch.shard_bounds``: ceil(n / world_size) frames
@@ -479,7 +479,12 @@ class DetectTrails:
                     mark([key])
                 self.last_stats["seconds"] = time.perf_counter() - t_start
                 return
-            slots = max(1, min(batch, int(os.environ.get("LFD_LOADER_SLOTS", 64)), len(keys)))
+            # a chunk = one GPU call: 64 frames keep the link and the GPU busy for plain files; a selection that exists only as
+            # .fits.bz2 is decompressed on the GPU a chunk at a time, and that decoder wants thousands of 900 kB blocks at once
+            # (~14 per frame): 256 frames per chunk
+            first = sdssfiles.filename("frame", run=keys[0][0], camcol=keys[0][1], field=keys[0][3], filter=keys[0][2])
+            compressed = not os.path.exists(first) and os.path.exists(first + ".bz2") and os.environ.get("LFD_BZ2_DEVICE", "1") != "0"
+            slots = max(1, min(batch, int(os.environ.get("LFD_LOADER_SLOTS", 256 if compressed else 64)), len(keys)))
             chunks = [keys[i:i + slots] for i in range(0, len(keys), slots)]
             if not chunks:
                 return
@@ -504,5 +509,6 @@ class DetectTrails:
                             print("[loader] chunk %d: waited %.1f ms for its files, GPU call + rows %.1f ms" %
                                   (i, 1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t1)), flush=True)
             finally:
+                self.last_stats["bz2"] = dict(loader.bz2_stats)
                 loader.close()
                 self.last_stats["seconds"] = time.perf_counter() - t_start

@@ -49,6 +49,8 @@ def csrc_sha():
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "lfd_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "lfd_amd", "csrc", "*.hip")) +
                     glob.glob(os.path.join(ROOT, "lfd_amd", "csrc", "*.inc"))):
+        if os.path.basename(f) in ("k_bz2.h", "bz2_core.h", "bz2dev.hip"):   # the bzip2 decoder: its own translation unit, none of the profiled kernels
+            continue
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()
