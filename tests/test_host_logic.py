@@ -208,6 +208,8 @@ def test_bench_finds_the_committed_traffic_counters():
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(root, "lfd_amd", "csrc", "*.h")) + glob.glob(os.path.join(root, "lfd_amd", "csrc", "*.hip")) +
                     glob.glob(os.path.join(root, "lfd_amd", "csrc", "*.inc"))):
+        if os.path.basename(f) in ("k_bz2.h", "bz2_core.h", "bz2dev.hip"):   # the bzip2 decoder: its own translation unit (as in tools/make_util.py)
+            continue
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     for workload, slots in (("sdss", ("k_dilate_canny", "k_prep_hist", "k_frame_bg", "k_frame_fg", "k_hough_vote", "k_bits_erode", "k_scan_fused")),
