@@ -59,57 +59,61 @@ struct BzDevIO {
     uint8_t *sel;
     uint8_t *L;
     int flushed, cnt, lane;
-    uint32_t stage; // 256 output bytes in flight: lane l holds bytes 4 l .. 4 l + 3
+    uint32_t vz;    // zero, in a vector register the compiler knows nothing about: `x + vz` keeps wave-uniform arithmetic on the
+                    // vector ALUs (four per CU) instead of the one scalar ALU all waves of a CU share, which is what bounds this kernel
+    uint32_t stage; // output bytes in flight, NEWEST FIRST: byte p of the 256 (lane p / 4, bits 8 (p % 4) ..) is the (p + 1)-th youngest
     uint32_t list;  // the move-to-front list (byte values), lane l holds entries 4 l .. 4 l + 3, entry j in bits 8 j ..
     __device__ __forceinline__ void mtf_begin() { list = 0; }
     __device__ __forceinline__ void mtf_add(int k, uint32_t b) {
         list |= lane == (k >> 2) ? b << (8 * (k & 3)) : 0u;
     }
     __device__ __forceinline__ uint32_t mtf_head() { return __builtin_amdgcn_readfirstlane(list) & 0xffu; }
-    __device__ __forceinline__ uint32_t mtf_front(int nn) { // nn >= 1 (position 0 is coded as a run)
-        const int q = nn >> 2, r8 = (nn & 3) << 3;
-        const uint32_t v = ((uint32_t)__builtin_amdgcn_readlane((int)list, q) >> r8) & 0xffu;
-        // every entry below nn moves up by one: a byte shift inside each lane, the top byte of lane l - 1 comes in at the bottom
-        // (lane 0 has no lane below it: it receives v, the new front)
-        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)(v << 24), (int)list, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    // One ordinary symbol: the byte at position nn >= 1 of the list moves to the front and is appended to the output.  Both are
+    // "shift everything below by one byte and put v in front": a byte shift inside each lane with the top byte of lane l - 1
+    // coming in at the bottom (DPP wave_shr; lane 0 has no lane below it and takes v from the instruction's `old` operand).
+    __device__ __forceinline__ void symbol(int nn) {
+        const int q = nn >> 2;
+        const uint32_t wq = (uint32_t)__builtin_amdgcn_readlane((int)list, q);
+        const uint32_t r8 = (((uint32_t)nn + vz) & 3u) << 3;          // (vector registers from here on)
+        const uint32_t v24 = (wq >> r8) << 24;                         // the byte, in the top byte
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)v24, (int)list, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
         const uint32_t sh = (list << 8) | (prev >> 24);
-        const uint32_t mr = (2u << (r8 + 7)) - 1u; // bytes 0 .. r of lane q (r = 3: the shift count wraps to give all ones)
+        const uint32_t mr = ~(0xffffff00u << r8);                      // bytes 0 .. r of lane q
         const uint32_t m = lane < q ? 0xffffffffu : (lane == q ? mr : 0u);
         list = (sh & m) | (list & ~m);
-        return v;
-    }
-    __device__ __forceinline__ void flush_full() {
-        ((uint32_t *)(L + flushed))[lane] = stage;
-        flushed += 256;
-        cnt = 0;
-        stage = 0;
-    }
-    // 256 bytes per store: byte cnt goes to byte cnt & 3 of lane cnt >> 2 (no branch but the one for a full buffer)
-    __device__ __forceinline__ void emit(uint32_t b) {
-        const uint32_t x = b << ((cnt & 3) << 3);
-        stage |= lane == (cnt >> 2) ? x : 0u;
+        const uint32_t sprev = (uint32_t)__builtin_amdgcn_update_dpp((int)v24, (int)stage, 0x138, 0xf, 0xf, false);
+        stage = (stage << 8) | (sprev >> 24);
         cnt++;
-        if (cnt == 256) flush_full();
     }
-    __device__ __forceinline__ void emit_run(uint32_t b, int n) {
-        while (n > 0 && ((cnt & 3) || n < 4)) { emit(b); n--; }
-        const uint32_t bb = b * 0x01010101u;
-        while (n >= 4) { // whole words: lanes cnt / 4 .. cnt / 4 + k - 1
-            const int w0 = cnt >> 2, k = min(n >> 2, 64 - w0);
-            stage = (lane >= w0 && lane < w0 + k) ? bb : stage; // (a select, not a branch: the loop's control flow stays scalar)
-            cnt += 4 * k;
-            n -= 4 * k;
-            if (cnt == 256) flush_full();
+    __device__ __forceinline__ void emit(uint32_t b) { // (a byte that is not a list move: runs)
+        const uint32_t v24 = (b + vz) << 24;
+        const uint32_t sprev = (uint32_t)__builtin_amdgcn_update_dpp((int)v24, (int)stage, 0x138, 0xf, 0xf, false);
+        stage = (stage << 8) | (sprev >> 24);
+        cnt++;
+    }
+    // The cnt <= 256 bytes in flight, oldest first, to L[flushed ..].  Every lane stores all four of its bytes whatever cnt is: the
+    // ones that hold nothing go to L[flushed + p], p >= cnt -- beyond the block's current end, overwritten by what comes next (the
+    // buffer has 256 bytes of slack) -- so that there is no lane-dependent branch here: one inside the symbol loop makes the
+    // compiler treat the whole loop as divergent and keep its counters in vector registers.
+    __device__ __forceinline__ void flush() {
+        for (int j = 0; j < 4; j++) {
+            const int p = 4 * lane + j;
+            L[flushed + (p < cnt ? cnt - 1 - p : p)] = (uint8_t)(stage >> (8 * j));
         }
-        while (n > 0) { emit(b); n--; }
-    }
-    __device__ __forceinline__ void flush_tail() {
-        for (int j = 0; j < 4; j++)
-            if (4 * lane + j < cnt) L[flushed + 4 * lane + j] = (uint8_t)(stage >> (8 * j));
         flushed += cnt;
         cnt = 0;
-        stage = 0;
     }
+    __device__ __forceinline__ void emit_run(uint32_t b, int n) {
+        if (n >= 64) { // long: straight to memory (whole groups of 64 bytes: up to 63 beyond the run's end, see flush)
+            flush();
+            for (int k0 = 0; k0 < n; k0 += 64) L[flushed + k0 + lane] = (uint8_t)b;
+            flushed += n;
+            return;
+        }
+        if (cnt + n > 256) flush();
+        for (int k = 0; k < n; k++) emit(b);
+    }
+    __device__ __forceinline__ void flush_tail() { flush(); }
     __device__ __forceinline__ int emitted() const { return flushed + cnt; }
     __device__ __forceinline__ void build_fast(int t, int mn) {
         __syncthreads(); // (one wave: orders the LDS traffic of the table building before the fast table overwrites `len`)
@@ -128,9 +132,14 @@ struct BzDevIO {
 __device__ __forceinline__ int bz_dev_symbols(BzDevIO &io, const uint32_t *w, uint64_t nwords, uint64_t bit0, const BzHeader &hd,
                                               int max_block, uint64_t &bit_end) {
     const int lane = io.lane;
-    const int eob = hd.n_in_use + 1, n_sel = hd.n_sel;
-    uint64_t base = bit0 >> 5; // first word held in wv
-    int bp = (int)(bit0 & 31); // the cursor, in bits from word `base`
+    // (what the header code hands over is wave-uniform, but the compiler has lost track of that across its lane-parallel table set-up)
+    const int eob = __builtin_amdgcn_readfirstlane(hd.n_in_use) + 1, n_sel = __builtin_amdgcn_readfirstlane(hd.n_sel);
+    const uint32_t b0lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bit0), b0hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bit0 >> 32));
+    const uint64_t bit0u = ((uint64_t)b0hi << 32) | b0lo;
+    uint64_t base = bit0u >> 5; // first word held in wv
+    int bp = (int)(bit0u & 31); // the cursor, in bits from word `base`
+    io.cnt = __builtin_amdgcn_readfirstlane(io.cnt);
+    io.flushed = __builtin_amdgcn_readfirstlane(io.flushed);
     auto loadw = [&](uint64_t b) {
         const uint64_t i = b + (uint64_t)lane;
         return i < nwords ? bz_bswap32(w[i]) : 0u;
@@ -141,6 +150,7 @@ __device__ __forceinline__ int bz_dev_symbols(BzDevIO &io, const uint32_t *w, ui
     const int lsh = lane & 31;
     const bool upper = lane >= 32;
     int st = -1, bad = 0;
+    uint32_t thr = (uint32_t)(eob - 2); // (unsigned)(sym - 2) >= thr: sym is RUNA / RUNB / end-of-block (or anything, while a run is open)
     while (st < 0) {
         if (group_pos == 0) {
             group_no++;
@@ -166,12 +176,26 @@ __device__ __forceinline__ int bz_dev_symbols(BzDevIO &io, const uint32_t *w, ui
         const u64 pair = upper ? (((u64)h1 << 32) | nx) : (((u64)h0 << 32) | h1);
         const uint32_t prefix = (uint32_t)((pair << lsh) >> (64 - BZ_FAST_BITS));
         const uint32_t ev = io.fast[t * BZ_FAST_SIZE + prefix];
+        if (io.cnt > 256 - 64) io.flush(); // (a window holds at most 64 codes: no check per symbol)
         int pos = 0;
         bool done = false;
-        do { // (errors are collected in `bad` and looked at once per window: the loop has one exit besides its end)
-            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ev, pos);
-            int sym = (int)(e >> 4), len = (int)(e & 15u);
-            if (__builtin_expect(e == 0u, 0)) { // a longer code (or none): bit by bit from this position
+        for (;;) { // stretches of ordinary symbols, an exception between two of them (errors are collected in `bad`, looked at once per window)
+            uint32_t e;
+            int sym;
+            bool window_done = false;
+            for (;;) { // the ordinary symbols: nothing in here touches what the exceptions change (run state, thr, flushed)
+                e = (uint32_t)__builtin_amdgcn_readlane((int)ev, pos);
+                sym = (int)(e >> 4);
+                if (__builtin_expect((uint32_t)(sym - 2) >= thr, 0)) break;
+                pos += (int)(e & 15u);
+                io.symbol(sym - 1); // (a block that grows beyond its level's size is caught when a buffer is flushed)
+                if (--group_pos == 0 || pos >= 64) { window_done = true; break; }
+            }
+            if (window_done) break;
+            // the exceptions, all behind that one test: a code longer than the look-up covers (e = 0), RUNA / RUNB, the end-of-block
+            // symbol, and any symbol while a run is being collected (thr = 0 then)
+            int len = (int)(e & 15u);
+            if (e == 0u) {
                 BzBits br;
                 const uint64_t at = base * 32 + (uint64_t)(bp + pos);
                 br.init(w, nwords, at);
@@ -180,21 +204,24 @@ __device__ __forceinline__ int bz_dev_symbols(BzDevIO &io, const uint32_t *w, ui
                 if (sym < 0) { bad = 1; sym = 2; }
             }
             pos += len;
-            if (__builtin_expect(sym <= 1, 0)) {
-                if (run_n == 0) { run_n = 1; run_len = 0; }
+            if (sym <= 1) {
+                if (run_n == 0) { run_n = 1; run_len = 0; thr = 0; }
                 if (run_n >= 2 * 1024 * 1024) { bad = 1; run_n = 1; }
                 run_len += run_n << sym;
                 run_n <<= 1;
             } else {
-                if (__builtin_expect(run_n != 0, 0)) {
+                if (run_n != 0) {
                     if (run_len > max_block - io.emitted()) { bad = 1; run_len = 0; }
                     io.emit_run(io.mtf_head(), run_len);
                     run_n = 0;
+                    thr = (uint32_t)(eob - 2);
+                    if (io.cnt > 256 - 64) io.flush();
                 }
-                if (__builtin_expect(sym == eob, 0)) { done = true; break; }
-                io.emit(io.mtf_front(sym - 1)); // (a block that grows beyond its level's size is caught when a buffer is flushed)
+                if (sym == eob) { done = true; break; }
+                io.symbol(sym - 1);
             }
-        } while (--group_pos != 0 && pos < 64);
+            if (--group_pos == 0 || pos >= 64) break;
+        }
         if (done) {
             bit_end = base * 32 + (uint64_t)(bp + pos);
             st = BZ_OK;
@@ -225,6 +252,7 @@ k_bz2_huff(const uint32_t *comp, const BzBlockDesc *desc, BzBlockInfo *info, uin
     io.flushed = 0;
     io.cnt = 0;
     io.stage = 0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(io.vz));
     io.list = 0;
     io.lane = threadIdx.x;
     BzBlockInfo bi;
