@@ -20,7 +20,7 @@ struct lfdmi_bz2 {
     uint32_t *comp = nullptr; size_t comp_words = 0;
     uint64_t *word_off = nullptr, *nbytes = nullptr; int *nfound = nullptr; u64 *marks = nullptr; size_t files_cap = 0;
     int *file_first = nullptr, *file_status = nullptr; u64 *out_len = nullptr;
-    BzBlockDesc *desc = nullptr; BzBlockInfo *info = nullptr; uint8_t *Lbuf = nullptr, *selbuf = nullptr; uint32_t *tt = nullptr;
+    BzBlockDesc *desc = nullptr; BzBlockInfo *info = nullptr; uint8_t *Lbuf = nullptr, *selbuf = nullptr, *segbuf = nullptr; uint32_t *tt = nullptr;
     int4 *meta = nullptr, *tile_fn = nullptr; int2 *tile_in = nullptr; uint32_t *blk_crc = nullptr;
     int *blk_size = nullptr; u64 *blk_off = nullptr; size_t blocks_cap = 0;
     uint8_t *out = nullptr; size_t out_bytes = 0;
@@ -87,7 +87,7 @@ extern "C" void lfdmi_bz2_destroy(lfdmi_bz2 *z) {
     (void)hipSetDevice(z->device);
     if (z->stream) (void)hipStreamSynchronize(z->stream);
     void *ps[] = {z->comp, z->word_off, z->nbytes, z->nfound, z->marks, z->file_first, z->file_status, z->out_len, z->desc, z->info,
-                  z->Lbuf, z->selbuf, z->tt, z->meta, z->tile_fn, z->tile_in, z->blk_crc, z->blk_size, z->blk_off, z->out, z->heads};
+                  z->Lbuf, z->selbuf, z->segbuf, z->tt, z->meta, z->tile_fn, z->tile_in, z->blk_crc, z->blk_size, z->blk_off, z->out, z->heads};
     for (void *p : ps) if (p) (void)hipFree(p);
     for (int i = 0; i < 6; i++) if (z->ev[i]) (void)hipEventDestroy(z->ev[i]);
     if (z->stream) (void)hipStreamDestroy(z->stream);
@@ -190,7 +190,7 @@ extern "C" int lfdmi_bz2_decode_batch(lfdmi_bz2 *z, const void *src, const uint6
     if (B > z->blocks_cap) {
         const size_t cap = B + B / 8 + 16;
         BCHK(alloc_n(z->desc, cap)); BCHK(alloc_n(z->info, cap)); BCHK(alloc_n(z->Lbuf, cap * BZ_LSTRIDE));
-        BCHK(alloc_n(z->selbuf, cap * BZ_SEL_STRIDE)); BCHK(alloc_n(z->tt, cap * BZ_TSTRIDE)); BCHK(alloc_n(z->meta, cap * BZ_MAX_TILES * 1024));
+        BCHK(alloc_n(z->selbuf, cap * BZ_SEL_STRIDE)); BCHK(alloc_n(z->segbuf, cap * BZ_MAX_SPLIT * BZ_SEG_CAP)); BCHK(alloc_n(z->tt, cap * BZ_TSTRIDE)); BCHK(alloc_n(z->meta, cap * BZ_MAX_TILES * 1024));
         BCHK(alloc_n(z->tile_fn, cap * BZ_MAX_TILES)); BCHK(alloc_n(z->tile_in, cap * BZ_MAX_TILES)); BCHK(alloc_n(z->blk_crc, cap));
         BCHK(alloc_n(z->blk_size, cap)); BCHK(alloc_n(z->blk_off, cap));
         z->blocks_cap = cap;
@@ -209,7 +209,7 @@ extern "C" int lfdmi_bz2_decode_batch(lfdmi_bz2 *z, const void *src, const uint6
         k_bz2_sort<<<(unsigned)B, 1024, 0, z->stream>>>(z->info, z->Lbuf, z->tt);
         BCHK(hipGetLastError());
         BCHK(hipEventRecord(z->ev[3], z->stream));
-        k_bz2_walk<<<(unsigned)B, 1024, 0, z->stream>>>(z->info, z->tt, z->Lbuf);
+        k_bz2_walk<<<(unsigned)B, 1024, 0, z->stream>>>(z->info, z->tt, z->Lbuf, z->segbuf);
         BCHK(hipGetLastError());
         BCHK(hipEventRecord(z->ev[4], z->stream));
         k_bz2_rle_tiles<<<dim3(BZ_MAX_TILES, (unsigned)B), 1024, 0, z->stream>>>(z->info, z->Lbuf, z->meta, z->tile_fn);

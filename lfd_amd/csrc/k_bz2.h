@@ -189,7 +189,8 @@ __device__ __forceinline__ int bz_dev_symbols(BzDevIO &io, const uint32_t *w, ui
                 if (__builtin_expect((uint32_t)(sym - 2) >= thr, 0)) break;
                 pos += (int)(e & 15u);
                 io.symbol(sym - 1); // (a block that grows beyond its level's size is caught when a buffer is flushed)
-                if (--group_pos == 0 || pos >= 64) { window_done = true; break; }
+                group_pos--;
+                if (((group_pos - 1) | (63 - pos)) < 0) { window_done = true; break; } // the table's 50 symbols are used up, or the window is
             }
             if (window_done) break;
             // the exceptions, all behind that one test: a code longer than the look-up covers (e = 0), RUNA / RUNB, the end-of-block
@@ -372,38 +373,50 @@ struct BzPacker { // consecutive bytes to memory, as word stores wherever a whol
     }
 };
 
-#define BZ_CHAINS 4 // splitters per thread, walked side by side (independent loads in flight)
+#define BZ_CHAINS 4      // splitters per thread, walked side by side (independent loads in flight)
+#define BZ_SEG_CAP 2048  // bytes a stretch writes to its scratch area (stretches average 256 steps; e^-8 of them are longer)
+// The permutation is walked ONCE: every splitter's stretch (to the next splitter) leaves its bytes in a scratch area of its own and
+// its length; one thread then puts the stretches in chain order; the scratch areas are copied to their places with coalesced
+// reads.  (A stretch longer than its scratch area remembers where it was after BZ_SEG_CAP steps and walks the rest again.)
+// A permutation whose cycle through orig_ptr is shorter than the block (periodic data) yields that cycle's bytes over and over.
 __global__ void __launch_bounds__(1024)
-k_bz2_walk(BzBlockInfo *info, const uint32_t *ttbuf, uint8_t *prebuf) {
+k_bz2_walk(BzBlockInfo *info, const uint32_t *ttbuf, uint8_t *prebuf, uint8_t *segbuf) {
     const int b = blockIdx.x;
     if (info[b].status != BZ_OK) return;
     const int n = info[b].nblock;
     const uint32_t orig = (uint32_t)info[b].orig_ptr;
     const uint32_t *tt = ttbuf + (size_t)b * BZ_TSTRIDE;
     uint8_t *pre = prebuf + (size_t)b * BZ_LSTRIDE;
+    uint8_t *seg = segbuf + (size_t)b * BZ_MAX_SPLIT * BZ_SEG_CAP;
     __shared__ int nxt[BZ_MAX_SPLIT], slen[BZ_MAX_SPLIT], spos[BZ_MAX_SPLIT];
-    __shared__ int s_ok;
-    const int tid = threadIdx.x;
+    __shared__ uint32_t qcap[BZ_MAX_SPLIT];
+    __shared__ int s_period;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int G = 1 << BZ_SPLIT_LOG;
     const int Ks = (n + G - 1) >> BZ_SPLIT_LOG; // regular splitters 0 .. Ks - 1 at q = s G; splitter Ks is orig_ptr, the head of the chain
     for (int k = tid; k <= Ks; k += 1024) spos[k] = -1;
     uint32_t q[BZ_CHAINS];
     int len[BZ_CHAINS];
     bool on[BZ_CHAINS];
+    BzPacker pk[BZ_CHAINS];
 #pragma unroll
     for (int k = 0; k < BZ_CHAINS; k++) {
         const int s = tid + 1024 * k;
         on[k] = s <= Ks;
         q[k] = s == Ks ? orig : ((uint32_t)s << BZ_SPLIT_LOG);
         len[k] = 0;
+        pk[k].init(seg + (size_t)min(s, BZ_MAX_SPLIT - 1) * BZ_SEG_CAP);
     }
-    for (int step = 0; step < n; step++) { // (a chain ends at the next splitter: ~256 steps on average)
+    for (int step = 0; step < n; step++) { // (a stretch ends at the next splitter: ~256 steps on average)
         bool any = false;
 #pragma unroll
         for (int k = 0; k < BZ_CHAINS; k++)
             if (on[k]) {
-                q[k] = tt[q[k]] >> 8;
+                const uint32_t e = tt[q[k]];
+                if (len[k] < BZ_SEG_CAP) pk[k].put(e & 0xffu);
+                q[k] = e >> 8;
                 len[k]++;
+                if (len[k] == BZ_SEG_CAP) qcap[tid + 1024 * k] = q[k];
                 if ((q[k] & (uint32_t)(G - 1)) == 0u || q[k] == orig) {
                     const int s = tid + 1024 * k;
                     nxt[s] = q[k] == orig ? Ks : (int)(q[k] >> BZ_SPLIT_LOG);
@@ -413,46 +426,45 @@ k_bz2_walk(BzBlockInfo *info, const uint32_t *ttbuf, uint8_t *prebuf) {
             }
         if (!any) break;
     }
+#pragma unroll
+    for (int k = 0; k < BZ_CHAINS; k++) pk[k].finish();
     __syncthreads();
     if (tid == 0) { // the splitters in chain order: where in the output each one's stretch begins
-        int pos = 0, j = Ks, ok = 1;
+        int pos = 0, j = Ks;
         while (pos < n) {
-            if (spos[j] != -1) { ok = 0; break; } // back at a splitter before n steps: the permutation has a shorter cycle
+            if (spos[j] != -1) break; // back at the head before n steps: the cycle through orig_ptr has `pos` elements
             spos[j] = pos;
             pos += slen[j];
             j = nxt[j];
         }
-        if (pos != n) ok = 0;
-        s_ok = ok;
-        if (!ok) info[b].status = BZ_E_CYCLE;
+        s_period = pos; // n, or the length of the cycle through orig_ptr (the stretches of a cycle add up to its length: never more than n)
+        if (pos > n) info[b].status = BZ_E_CYCLE;
     }
     __syncthreads();
-    if (!s_ok) return;
-    BzPacker pk[BZ_CHAINS];
-    int left[BZ_CHAINS];
-#pragma unroll
-    for (int k = 0; k < BZ_CHAINS; k++) {
-        const int s = tid + 1024 * k;
-        const int p0 = s <= Ks ? spos[s] : -1;
-        left[k] = p0 >= 0 ? slen[s] : 0;
-        q[k] = s == Ks ? orig : ((uint32_t)s << BZ_SPLIT_LOG);
-        pk[k].init(pre + (p0 >= 0 ? p0 : 0));
+    const int period = s_period;
+    if (period > n) return;
+    // stretches to their places: a wave per stretch, 64 bytes per step
+    for (int s = wv; s <= Ks; s += 16) {
+        const int p0 = spos[s];
+        if (p0 < 0) continue;
+        const int cnt = min(slen[s], BZ_SEG_CAP);
+        const uint8_t *src = seg + (size_t)s * BZ_SEG_CAP;
+        for (int k = lane; k < cnt; k += 64) pre[p0 + k] = src[k];
     }
-    for (;;) {
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < BZ_CHAINS; k++)
-            if (left[k] > 0) {
-                const uint32_t e = tt[q[k]];
-                pk[k].put(e & 0xffu);
-                q[k] = e >> 8;
-                left[k]--;
-                any = true;
-            }
-        if (!any) break;
+    // the rest of the long ones
+    for (int s = tid; s <= Ks; s += 1024) {
+        if (spos[s] < 0 || slen[s] <= BZ_SEG_CAP) continue;
+        uint32_t qq = qcap[s];
+        for (int c = BZ_SEG_CAP; c < slen[s]; c++) {
+            const uint32_t e = tt[qq];
+            pre[spos[s] + c] = (uint8_t)e;
+            qq = e >> 8;
+        }
     }
-#pragma unroll
-    for (int k = 0; k < BZ_CHAINS; k++) pk[k].finish();
+    if (period < n) { // periodic: the first `period` bytes again and again
+        __syncthreads();
+        for (int i = period + tid; i < n; i += 1024) pre[i] = pre[i % period];
+    }
 }
 
 // ---- run-length layer ----------------------------------------------------------------------------------------------------------
