@@ -141,6 +141,7 @@ class FrameLoader:
         self.ctx = ctx
         self.bz2_device = os.environ.get("LFD_BZ2_DEVICE", "1") != "0" and hasattr(ctx, "device")   # (a real _native.Context)
         self.bz2_out_cap = self.frame_bytes + int(os.environ.get("LFD_BZ2_EXTRA_MB", 4)) * (1 << 20)   # (a frame file = image + three small HDUs)
+        self.bz2_device_min = int(os.environ.get("LFD_BZ2_DEVICE_MIN", 8))   # fewer compressed frames in a chunk than this: the host decodes them
         self._bz2 = None
         self._bz2_pin = None
         self.bz2_stats = {"device_frames": 0, "host_frames": 0, "decode_s": 0.0, "read_s": 0.0, "fetch_s": 0.0}
@@ -323,7 +324,7 @@ class FrameLoader:
         if self.bz2_device:
             todo = [(i, slot, fpaths[slot] + ".bz2") for slot, i in enumerate(order)
                     if int(fstat[slot]) == -1 and not os.path.exists(fpaths[slot]) and os.path.exists(fpaths[slot] + ".bz2")]
-            if todo:
+            if len(todo) >= self.bz2_device_min:             # (a handful of files: their blocks side by side on the host's cores are quicker)
                 rest = self._device_bz2(out, todo, raw)
                 on_device = {i for i, _, _ in todo} - {i for i, _, _ in rest}
                 self.bz2_stats["host_frames"] += len(rest)

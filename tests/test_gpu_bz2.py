@@ -99,6 +99,7 @@ def test_loader_decodes_a_chunk_of_bz2_frames_on_the_device(tmp_path, monkeypatc
     data[len(data) // 2] ^= 0x40
     open(bad, "wb").write(bytes(data))
     keys = [(94, 1, "r", f) for f in range(100, 100 + n)]
+    monkeypatch.setenv("LFD_BZ2_DEVICE_MIN", "2")
     with Nv.Context(0, shape[0], shape[1], 8) as ctx:
         with loader.FrameLoader(ctx, shape, 8, threads=3) as ld:
             out = ld.load(keys, 0)

@@ -7,6 +7,7 @@ from lfd_amd import _native as Nv
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+kind = sys.argv[3] if len(sys.argv) > 3 else "noise"       # noise: float32 Gaussian (barely compressible); counts: integer counts x a calibration vector (2 : 1)
 rng = np.random.default_rng(5)
 small = {
     "text": b"hello hello hello world" * 3,
@@ -22,7 +23,12 @@ hdr = b"".join(c.ljust(80) for c in (b"SIMPLE  =                    T", b"BITPIX
                                     b"NAXIS1  =                 2048", b"NAXIS2  =                 1489", b"END")).ljust(2880)
 def frame(k):
     r = np.random.default_rng(k)
-    img = r.normal(0.0, 0.025, (1489, 2048)).astype(">f4")
+    if kind == "counts":
+        counts = np.rint(r.normal(1100, 6, (1489, 2048))).astype(np.float32)
+        calib = (0.005 * (1 + 0.02 * np.sin(np.arange(2048) / 300))).astype(np.float32)
+        img = (counts * calib[None, :]).astype(">f4")
+    else:
+        img = r.normal(0.0, 0.025, (1489, 2048)).astype(">f4")
     img[200:300, 500:800] = 0.0
     return hdr + img.tobytes()
 plains = list(small.values()) + [frame(k) for k in range(min(n, 4))]
