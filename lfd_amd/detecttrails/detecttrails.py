@@ -482,6 +482,8 @@ class DetectTrails:
             # a chunk = one GPU call: 64 frames keep the link and the GPU busy for plain files; a selection that exists only as
             # .fits.bz2 is decompressed on the GPU a chunk at a time, and that decoder wants thousands of 900 kB blocks at once
             # (~14 per frame): 256 frames per chunk
+            if not keys:
+                return
             first = sdssfiles.filename("frame", run=keys[0][0], camcol=keys[0][1], field=keys[0][3], filter=keys[0][2])
             compressed = not os.path.exists(first) and os.path.exists(first + ".bz2") and os.environ.get("LFD_BZ2_DEVICE", "1") != "0"
             slots = max(1, min(batch, int(os.environ.get("LFD_LOADER_SLOTS", 256 if compressed else 64)), len(keys)))
