@@ -3,6 +3,7 @@
 // chunk's files while another thread drives lfdmi_detect_batch on the same GPU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -186,9 +187,24 @@ extern "C" int lfdmi_bz2_decode_batch(lfdmi_bz2 *z, const void *src, const uint6
         }
     }
     first[n] = (int)desc.size();
-    const size_t B = desc.size();
-    if (B > z->blocks_cap) {
-        const size_t cap = B + B / 8 + 16;
+    // ---- groups of whole files, each with at most max_blocks blocks in flight (12.6 MB of tables and scratch per block): the
+    // files of a chunk of SDSS frames are one group; what is larger (more files, level-1 files of 127 blocks) takes several passes
+    size_t max_blocks = 4096;
+    if (const char *e = getenv("LFDMI_BZ2_MAX_BLOCKS")) max_blocks = (size_t)std::max(1, atoi(e));
+    std::vector<int> gfirst{0}; // first file of every group, and n
+    {
+        size_t inb = 0;
+        for (int i = 0; i < n; i++) {
+            const size_t nb = (size_t)(first[i + 1] - first[i]);
+            if (inb && inb + nb > max_blocks) { gfirst.push_back(i); inb = 0; }
+            inb += nb;
+        }
+        gfirst.push_back(n);
+    }
+    size_t Bmax = 0;
+    for (size_t g = 0; g + 1 < gfirst.size(); g++) Bmax = std::max(Bmax, (size_t)(first[gfirst[g + 1]] - first[gfirst[g]]));
+    if (Bmax > z->blocks_cap) {
+        const size_t cap = Bmax + Bmax / 8 + 16;
         BCHK(alloc_n(z->desc, cap)); BCHK(alloc_n(z->info, cap)); BCHK(alloc_n(z->Lbuf, cap * BZ_LSTRIDE));
         BCHK(alloc_n(z->selbuf, cap * BZ_SEL_STRIDE)); BCHK(alloc_n(z->segbuf, cap * BZ_MAX_SPLIT * BZ_SEG_CAP)); BCHK(alloc_n(z->tt, cap * BZ_TSTRIDE)); BCHK(alloc_n(z->meta, cap * BZ_MAX_TILES * 1024));
         BCHK(alloc_n(z->tile_fn, cap * BZ_MAX_TILES)); BCHK(alloc_n(z->tile_in, cap * BZ_MAX_TILES)); BCHK(alloc_n(z->blk_crc, cap));
@@ -197,51 +213,67 @@ extern "C" int lfdmi_bz2_decode_batch(lfdmi_bz2 *z, const void *src, const uint6
     }
     BCHK(regrow(z->out, z->out_bytes, (size_t)n * out_cap + 256));
     if (head_bytes) BCHK(regrow(z->heads, z->heads_bytes, (size_t)n * head_bytes));
-    BCHK(hipMemcpyAsync(z->file_first, first.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, z->stream));
     BCHK(hipMemcpyAsync(z->file_status, fstat.data(), n * sizeof(int), hipMemcpyHostToDevice, z->stream));
-    std::vector<BzBlockInfo> info(B);
-    if (B) {
-        BCHK(hipMemcpyAsync(z->desc, desc.data(), B * sizeof(BzBlockDesc), hipMemcpyHostToDevice, z->stream));
-        BCHK(hipEventRecord(z->ev[1], z->stream));
-        k_bz2_huff<<<(unsigned)B, 64, 0, z->stream>>>(z->comp, z->desc, z->info, z->Lbuf, z->selbuf, (int)B);
+    std::vector<BzBlockInfo> info(desc.size());
+    float ms_acc[5] = {0, 0, 0, 0, 0};
+    std::vector<std::vector<int>> lfirsts;
+    lfirsts.reserve(gfirst.size());
+    for (size_t g = 0; g + 1 < gfirst.size(); g++) {
+        const int f0 = gfirst[g], nf = gfirst[g + 1] - f0, b0 = first[f0];
+        const size_t B = (size_t)(first[f0 + nf] - b0);
+        lfirsts.emplace_back(nf + 1); // the group's files -> its blocks, counted from the group's first (kept until the stream is idle)
+        std::vector<int> &lfirst = lfirsts.back();
+        for (int i = 0; i <= nf; i++) lfirst[i] = first[f0 + i] - b0;
+        BCHK(hipMemcpyAsync(z->file_first, lfirst.data(), (nf + 1) * sizeof(int), hipMemcpyHostToDevice, z->stream));
+        if (B) {
+            BCHK(hipMemcpyAsync(z->desc, desc.data() + b0, B * sizeof(BzBlockDesc), hipMemcpyHostToDevice, z->stream));
+            BCHK(hipEventRecord(z->ev[1], z->stream));
+            k_bz2_huff<<<(unsigned)B, 64, 0, z->stream>>>(z->comp, z->desc, z->info, z->Lbuf, z->selbuf, (int)B);
+            BCHK(hipGetLastError());
+            BCHK(hipEventRecord(z->ev[2], z->stream));
+            k_bz2_sort<<<(unsigned)B, 1024, 0, z->stream>>>(z->info, z->Lbuf, z->tt);
+            BCHK(hipGetLastError());
+            BCHK(hipEventRecord(z->ev[3], z->stream));
+            k_bz2_walk<<<(unsigned)B, 1024, 0, z->stream>>>(z->info, z->tt, z->Lbuf, z->segbuf);
+            BCHK(hipGetLastError());
+            BCHK(hipEventRecord(z->ev[4], z->stream));
+            k_bz2_rle_tiles<<<dim3(BZ_MAX_TILES, (unsigned)B), 1024, 0, z->stream>>>(z->info, z->Lbuf, z->meta, z->tile_fn);
+            BCHK(hipGetLastError());
+            k_bz2_rle_blocks<<<(unsigned)((B + 63) / 64), 64, 0, z->stream>>>(z->info, z->tile_fn, z->tile_in, z->blk_size, (int)B);
+            BCHK(hipGetLastError());
+            BCHK(hipMemsetAsync(z->blk_crc, 0, B * sizeof(uint32_t), z->stream));
+        } else {
+            for (int k = 1; k <= 4; k++) BCHK(hipEventRecord(z->ev[k], z->stream));
+        }
+        k_bz2_offsets<<<(nf + 63) / 64, 64, 0, z->stream>>>(z->info, z->blk_size, z->file_first, nf, out_cap, z->blk_off, z->out_len + f0, z->file_status + f0);
         BCHK(hipGetLastError());
-        BCHK(hipEventRecord(z->ev[2], z->stream));
-        k_bz2_sort<<<(unsigned)B, 1024, 0, z->stream>>>(z->info, z->Lbuf, z->tt);
-        BCHK(hipGetLastError());
-        BCHK(hipEventRecord(z->ev[3], z->stream));
-        k_bz2_walk<<<(unsigned)B, 1024, 0, z->stream>>>(z->info, z->tt, z->Lbuf, z->segbuf);
-        BCHK(hipGetLastError());
-        BCHK(hipEventRecord(z->ev[4], z->stream));
-        k_bz2_rle_tiles<<<dim3(BZ_MAX_TILES, (unsigned)B), 1024, 0, z->stream>>>(z->info, z->Lbuf, z->meta, z->tile_fn);
-        BCHK(hipGetLastError());
-        k_bz2_rle_blocks<<<(unsigned)((B + 63) / 64), 64, 0, z->stream>>>(z->info, z->tile_fn, z->tile_in, z->blk_size, (int)B);
-        BCHK(hipGetLastError());
-        BCHK(hipMemsetAsync(z->blk_crc, 0, B * sizeof(uint32_t), z->stream));
-    } else {
-        for (int k = 1; k <= 4; k++) BCHK(hipEventRecord(z->ev[k], z->stream));
+        if (B) {
+            k_bz2_expand<<<dim3(BZ_MAX_TILES, (unsigned)B), 1024, 0, z->stream>>>(z->info, z->desc, z->Lbuf, z->meta, z->tile_fn, z->tile_in, z->blk_size,
+                                                                                 z->blk_off, z->out, out_cap, z->file_status, z->blk_crc, z->pows);
+            BCHK(hipGetLastError());
+            k_bz2_crc_check<<<(unsigned)((B + 63) / 64), 64, 0, z->stream>>>(z->info, z->desc, z->blk_crc, z->file_status, (int)B);
+            BCHK(hipGetLastError());
+            BCHK(hipMemcpyAsync(info.data() + b0, z->info, B * sizeof(BzBlockInfo), hipMemcpyDeviceToHost, z->stream));
+        }
+        BCHK(hipEventRecord(z->ev[5], z->stream));
+        BCHK(hipStreamSynchronize(z->stream)); // (the next group reuses the tables)
+        for (int k = 0; k < 5; k++) {
+            float t = 0;
+            (void)hipEventElapsedTime(&t, z->ev[k], z->ev[k + 1]);
+            if (k > 0 || g == 0) ms_acc[k] += t; // (the upload and the magic search happen once, before the first group)
+        }
     }
-    k_bz2_offsets<<<(n + 63) / 64, 64, 0, z->stream>>>(z->info, z->blk_size, z->file_first, n, out_cap, z->blk_off, z->out_len, z->file_status);
-    BCHK(hipGetLastError());
-    if (B) {
-        k_bz2_expand<<<dim3(BZ_MAX_TILES, (unsigned)B), 1024, 0, z->stream>>>(z->info, z->desc, z->Lbuf, z->meta, z->tile_fn, z->tile_in, z->blk_size,
-                                                                             z->blk_off, z->out, out_cap, z->file_status, z->blk_crc, z->pows);
-        BCHK(hipGetLastError());
-        k_bz2_crc_check<<<(unsigned)((B + 63) / 64), 64, 0, z->stream>>>(z->info, z->desc, z->blk_crc, z->file_status, (int)B);
-        BCHK(hipGetLastError());
-    }
+    for (int k = 0; k < 5; k++) z->ms[k] = ms_acc[k];
     if (head_bytes) {
         k_bz2_heads<<<dim3((unsigned)((head_bytes + 255) / 256), n), 256, 0, z->stream>>>(z->out, out_cap, z->out_len, z->heads, head_bytes);
         BCHK(hipGetLastError());
         BCHK(hipMemcpyAsync(head, z->heads, (size_t)n * head_bytes, hipMemcpyDeviceToHost, z->stream));
     }
-    BCHK(hipEventRecord(z->ev[5], z->stream));
     z->h_out_len.assign(n, 0);
     z->h_status.assign(n, 0);
     BCHK(hipMemcpyAsync(z->h_out_len.data(), z->out_len, n * sizeof(u64), hipMemcpyDeviceToHost, z->stream));
     BCHK(hipMemcpyAsync(z->h_status.data(), z->file_status, n * sizeof(int), hipMemcpyDeviceToHost, z->stream));
-    if (B) BCHK(hipMemcpyAsync(info.data(), z->info, B * sizeof(BzBlockInfo), hipMemcpyDeviceToHost, z->stream));
     BCHK(hipStreamSynchronize(z->stream));
-    for (int k = 0; k < 5; k++) (void)hipEventElapsedTime(&z->ms[k], z->ev[k], z->ev[k + 1]);
     for (int i = 0; i < n; i++) {
         if (z->h_status[i] == BZ_OK) { // the stream's own CRC: the blocks' CRCs (each one checked on the device) rotated together
             uint32_t c = 0;

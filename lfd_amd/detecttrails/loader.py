@@ -234,7 +234,13 @@ class FrameLoader:
             return got == sizes[k]
         ok_read = list(self.pool.map(read, range(len(todo))))
         t1 = time.perf_counter()
-        out_len, status, heads = self._bz2.decode(src, offs, sizes, self.bz2_out_cap, HDR_CAP)
+        try:
+            out_len, status, heads = self._bz2.decode(src, offs, sizes, self.bz2_out_cap, HDR_CAP)
+        except _native.NativeError as e:                     # e.g. no room for the decoder's tables on this device: the host's cores from now on
+            import warnings
+            warnings.warn(f"device bzip2 decoder switched off ({e}); .bz2 frames are decompressed on the host")
+            self.bz2_device = False
+            return list(todo)
         t2 = time.perf_counter()
         rest, files, foff, fbytes, dsts = [], [], [], [], []
         whole = []

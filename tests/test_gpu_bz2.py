@@ -65,6 +65,24 @@ def test_whole_files_against_python_bz2(level):
         assert list(out_len2) == list(out_len[::-1]) and not status2.any()
 
 
+def test_more_blocks_than_the_budget_are_decoded_in_passes(monkeypatch):
+    """$LFDMI_BZ2_MAX_BLOCKS bounds the tables: whole files are grouped, every group is a pass of its own."""
+    from lfd_amd import _native as Nv
+    monkeypatch.setenv("LFDMI_BZ2_MAX_BLOCKS", "5")
+    rng = np.random.default_rng(3)
+    plains = [rng.integers(0, 256, 250000 + 50000 * k, dtype=np.uint8).tobytes() for k in range(5)] + [b"", b"tiny"]
+    blobs = [bz2.compress(p, 1) for p in plains]                     # level 1: 100 kB blocks, 3 - 5 per file
+    src, off, ln = _pack(blobs)
+    with Nv.Bz2Decoder(0) as z:
+        out_len, status, heads = z.decode(src, off, ln, 1 << 20, 16)
+        assert not status.any(), list(status)
+        for i, p in enumerate(plains):
+            assert int(out_len[i]) == len(p)
+            if p:
+                assert z.fetch(i, 0, len(p)).tobytes() == p
+            assert heads[i].tobytes() == p[:16].ljust(16, b"\0")
+
+
 def test_what_the_decoder_declines_is_reported_not_guessed():
     from lfd_amd import _native as Nv
     good = bz2.compress(_plains()["noise"], 9)
