@@ -286,8 +286,8 @@ int64_t lfdmi_bz2_find_blocks(const uint8_t *data, uint64_t n, uint64_t *out, in
  *                                  memory (for parsing FITS headers; zero-filled beyond a file's end);
  *   out_len[i], status[i]          decompressed size, and 0 = decoded and checked, or why not (LFDMI_BZ2_*: the caller then
  *                                  decompresses that file on the host, which also produces the reference's error for broken
- *                                  files).  Files that are not one plain stream (several streams joined, trailing bytes,
- *                                  randomised blocks of bzip2 < 0.9.5) are declined, not decoded.
+ *                                  files).  Concatenated streams (`bzip2 -c a b`, pbzip2) are one file.  Trailing bytes, randomised
+ *                                  blocks of bzip2 < 0.9.5 and anything else unexpected: declined, not guessed at.
  * The decompressed files stay on the device until the handle's next lfdmi_bz2_decode_batch; lfdmi_bz2_fetch /
  * lfdmi_bz2_fetch_many copy ranges of them to host (loc LFDMI_HOST / LFDMI_HOST_PINNED) or device (LFDMI_DEVICE) memory. */
 typedef struct lfdmi_bz2 lfdmi_bz2;

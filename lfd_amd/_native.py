@@ -203,14 +203,14 @@ class PinnedBuffer:
 
 BZ2_STATUS = {0: "ok", 1: "no block magic", 2: "randomised block", 3: "bad block header", 4: "bad compressed data",
               5: "block length mismatch", 6: "bad origin pointer", 7: "CRC mismatch", 8: "BWT cycle shorter than the block",
-              9: "larger than out_cap", 10: "not one plain bzip2 stream"}
+              9: "larger than out_cap", 10: "not a sequence of bzip2 streams"}
 
 
 class Bz2Decoder:
     """lfdmi_bz2_*: whole ``.bz2`` files decompressed on the GPU, many at once (include/lfdmi.h).  ``decode`` takes the
     compressed files as one uint8 array + offsets / lengths and returns (out_len, status, heads); the decompressed bytes stay on
     the device until the next ``decode`` and are copied out in ranges by ``fetch`` / ``fetch_many``.  A file whose status is not
-    0 was NOT decoded (several streams joined, a broken block, ...): decompress it on the host, as the reference does."""
+    0 was NOT decoded (a broken block, trailing bytes, ...): decompress it on the host, as the reference does."""
 
     def __init__(self, device=0):
         self._lib = lib()

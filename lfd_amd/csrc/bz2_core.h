@@ -36,7 +36,7 @@ enum {
     BZ_E_CRC = 7,
     BZ_E_CYCLE = 8,      // the BWT permutation does not come back to its start after exactly nblock steps
     BZ_E_SIZE = 9,       // output larger than the caller's buffer
-    BZ_E_STREAM = 10     // not one plain "BZh1-9" stream (several streams, no end mark, ...)
+    BZ_E_STREAM = 10     // not a sequence of "BZh1-9" streams (no end mark, bytes after it, a magic where none belongs, ...)
 };
 
 struct BzBlockInfo {

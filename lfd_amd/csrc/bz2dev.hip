@@ -157,33 +157,57 @@ extern "C" int lfdmi_bz2_decode_batch(lfdmi_bz2 *z, const void *src, const uint6
     // ---- the blocks of every file that is one plain stream
     std::vector<BzBlockDesc> desc;
     std::vector<int> first(n + 1), fstat(n, BZ_OK);
-    std::vector<uint32_t> stream_crc(n, 0);
+    struct Stream { int file, b0, b1; uint32_t crc; }; // a stream's blocks [b0, b1) and its stored CRC
+    std::vector<Stream> streams;
     for (int i = 0; i < n; i++) {
         first[i] = (int)desc.size();
         const uint8_t *d = S + src_off[i];
         const uint64_t len = src_len[i];
-        if (len < 14 || d[0] != 'B' || d[1] != 'Z' || d[2] != 'h' || d[3] < '1' || d[3] > '9' || nfound[i] < 1 || nfound[i] > BZ_MARK_CAP) {
-            fstat[i] = BZ_E_STREAM;
-            continue;
-        }
+        if (len < 14 || nfound[i] < 1 || nfound[i] > BZ_MARK_CAP) { fstat[i] = BZ_E_STREAM; continue; }
         u64 *m = marks.data() + (size_t)i * BZ_MARK_CAP;
-        std::sort(m, m + nfound[i]);
         const int nm = nfound[i];
-        bool ok = (m[0] >> 1) == 32 && (m[nm - 1] & 1);
-        for (int k = 0; k + 1 < nm && ok; k++) ok = !(m[k] & 1); // one end mark, and it is the last magic
-        const uint64_t eos = m[nm - 1] >> 1;
-        if (ok) ok = (eos + 80 + 7) / 8 == len; // the stream ends with the file (no second stream, no trailing bytes)
-        if (!ok) { fstat[i] = BZ_E_STREAM; continue; }
-        stream_crc[i] = bits32(d, len, eos + 48);
-        for (int k = 0; k + 1 < nm; k++) {
-            BzBlockDesc bd;
-            bd.start_bit = m[k] >> 1;
-            bd.end_bit = m[k + 1] >> 1;
-            bd.word_off = woff[i];
-            bd.nwords = (len + 3) / 4 + 2;
-            bd.file = i;
-            bd.max_block = (d[3] - '0') * 100000;
-            desc.push_back(bd);
+        std::sort(m, m + nm);
+        // One or more streams, each "BZh" + level, blocks, end mark + CRC, padded to a byte (bzip2 -c a b, pbzip2).  Every magic
+        // the device found must be where this walk expects one: anything else (bytes that are not bzip2, a magic-like pattern inside
+        // compressed data) declines the file.
+        const size_t desc0 = desc.size(), streams0 = streams.size();
+        uint64_t byte = 0;
+        int k = 0;
+        bool ok = true;
+        while (ok && byte < len) {
+            ok = byte + 14 <= len && d[byte] == 'B' && d[byte + 1] == 'Z' && d[byte + 2] == 'h' && d[byte + 3] >= '1' && d[byte + 3] <= '9' &&
+                 k < nm && (m[k] >> 1) == byte * 8 + 32;
+            if (!ok) break;
+            const int max_block = (d[byte + 3] - '0') * 100000;
+            Stream st;
+            st.file = i;
+            st.b0 = (int)desc.size();
+            while (k < nm && !(m[k] & 1)) { // blocks up to the end mark
+                if (k + 1 >= nm) { ok = false; break; }
+                BzBlockDesc bd;
+                bd.start_bit = m[k] >> 1;
+                bd.end_bit = m[k + 1] >> 1;
+                bd.word_off = woff[i];
+                bd.nwords = (len + 3) / 4 + 2;
+                bd.file = i;
+                bd.max_block = max_block;
+                desc.push_back(bd);
+                k++;
+            }
+            if (!ok || k >= nm) { ok = false; break; }
+            const uint64_t eos = m[k] >> 1;
+            k++;
+            if ((eos + 80 + 7) / 8 > len) { ok = false; break; }
+            st.b1 = (int)desc.size();
+            st.crc = bits32(d, len, eos + 48);
+            streams.push_back(st);
+            byte = (eos + 80 + 7) / 8;
+        }
+        if (ok) ok = byte == len && k == nm;
+        if (!ok) {
+            fstat[i] = BZ_E_STREAM;
+            desc.resize(desc0);
+            streams.resize(streams0);
         }
     }
     first[n] = (int)desc.size();
@@ -274,12 +298,13 @@ extern "C" int lfdmi_bz2_decode_batch(lfdmi_bz2 *z, const void *src, const uint6
     BCHK(hipMemcpyAsync(z->h_out_len.data(), z->out_len, n * sizeof(u64), hipMemcpyDeviceToHost, z->stream));
     BCHK(hipMemcpyAsync(z->h_status.data(), z->file_status, n * sizeof(int), hipMemcpyDeviceToHost, z->stream));
     BCHK(hipStreamSynchronize(z->stream));
+    for (const Stream &st : streams) { // every stream's own CRC: its blocks' CRCs (each one checked on the device) rotated together
+        if (z->h_status[st.file] != BZ_OK) continue;
+        uint32_t c = 0;
+        for (int b = st.b0; b < st.b1; b++) c = ((c << 1) | (c >> 31)) ^ info[b].crc;
+        if (c != st.crc) z->h_status[st.file] = BZ_E_CRC;
+    }
     for (int i = 0; i < n; i++) {
-        if (z->h_status[i] == BZ_OK) { // the stream's own CRC: the blocks' CRCs (each one checked on the device) rotated together
-            uint32_t c = 0;
-            for (int b = first[i]; b < first[i + 1]; b++) c = ((c << 1) | (c >> 31)) ^ info[b].crc;
-            if (c != stream_crc[i]) z->h_status[i] = BZ_E_CRC;
-        }
         status[i] = z->h_status[i];
         out_len[i] = z->h_status[i] == BZ_OK ? z->h_out_len[i] : 0;
     }

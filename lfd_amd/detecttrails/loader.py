@@ -136,7 +136,7 @@ class FrameLoader:
         self.block_pool = ThreadPoolExecutor(max(2, self.threads), thread_name_prefix="lfd-bz2")
         self.split_blocks = True
         # .bz2 frames are decompressed ON THE GPU, all of a chunk's files at once (lfdmi_bz2_decode_batch: hundreds of frames/s
-        # against ~2 per host core); what the decoder declines (joined streams, a broken block: status != 0) goes the host way
+        # against ~2 per host core); what the decoder declines (a broken block, trailing bytes: status != 0) goes the host way
         # above, which also raises what the reference would.  $LFD_BZ2_DEVICE=0: host only.
         self.ctx = ctx
         self.bz2_device = os.environ.get("LFD_BZ2_DEVICE", "1") != "0" and hasattr(ctx, "device")   # (a real _native.Context)

@@ -65,6 +65,22 @@ def test_whole_files_against_python_bz2(level):
         assert list(out_len2) == list(out_len[::-1]) and not status2.any()
 
 
+def test_streams_joined_end_to_end_are_one_file():
+    """`bzip2 -c a b > ab.bz2`, pbzip2: several streams, each with its own level, blocks, end mark and CRC."""
+    from lfd_amd import _native as Nv
+    rng = np.random.default_rng(11)
+    parts = [rng.integers(0, 256, 260000, dtype=np.uint8).tobytes(), b"", b"middle " * 1000, bytes(400000)]
+    joined = b"".join(bz2.compress(p, lvl) for p, lvl in zip(parts, (1, 9, 5, 2)))
+    assert bz2.decompress(joined) == b"".join(parts)
+    damaged = bytearray(joined)
+    damaged[-3] ^= 1                                                 # the last stream's CRC
+    src, off, ln = _pack([joined, bytes(damaged)])
+    with Nv.Bz2Decoder(0) as z:
+        out_len, status, _ = z.decode(src, off, ln, 2 << 20)
+        assert status[0] == 0 and z.fetch(0, 0, int(out_len[0])).tobytes() == b"".join(parts)
+        assert status[1] != 0
+
+
 def test_more_blocks_than_the_budget_are_decoded_in_passes(monkeypatch):
     """$LFDMI_BZ2_MAX_BLOCKS bounds the tables: whole files are grouped, every group is a pass of its own."""
     from lfd_amd import _native as Nv
@@ -88,7 +104,7 @@ def test_what_the_decoder_declines_is_reported_not_guessed():
     good = bz2.compress(_plains()["noise"], 9)
     flipped = bytearray(good)
     flipped[len(flipped) // 2] ^= 0x10
-    blobs = [bz2.compress(b"abc") + bz2.compress(b"def"),            # two streams joined (valid bzip2; host decoder's job)
+    blobs = [bz2.compress(b"abc")[:-1] + b"BZ",                      # ends inside the stream's CRC
              bytes(flipped), b"not bzip2 at all", good + b"\0", good[:len(good) // 2], good]
     src, off, ln = _pack(blobs)
     with Nv.Bz2Decoder(0) as z:
