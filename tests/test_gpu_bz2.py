@@ -154,3 +154,48 @@ def test_loader_decodes_a_chunk_of_bz2_frames_on_the_device(tmp_path, monkeypatc
                     assert np.array_equal(out2.buffer[out2.slot[i]], out.buffer[out.slot[i]])
                 else:
                     assert type(out2.error[i]) is type(out.error[i]) and str(out2.error[i]) == str(out.error[i])
+
+
+def test_damaged_files_never_decode_to_something_else():
+    """Bit flips, truncations, spliced and random bytes: whatever Python's bz2 makes of a damaged file, the device decoder either
+    declines it or produces the same bytes (no wrong data, no fault)."""
+    from lfd_amd import _native as Nv
+    rng = np.random.default_rng(99)
+    base = [bz2.compress(rng.integers(0, 256, 150000, dtype=np.uint8).tobytes(), 1),
+            bz2.compress(bytes(rng.integers(0, 4, 200000, dtype=np.uint8)), 9),
+            bz2.compress(b"".join(bytes([b]) * int(n) for b, n in zip(rng.integers(0, 256, 3000), rng.integers(1, 300, 3000))), 9)]
+    blobs = []
+    for k in range(240):
+        b = bytearray(base[k % 3])
+        kind = k % 4
+        if kind == 0:                                                # one bit
+            i = int(rng.integers(0, len(b)))
+            b[i] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:                                              # a burst of random bytes
+            i = int(rng.integers(0, len(b) - 16))
+            b[i:i + 16] = rng.integers(0, 256, 16, dtype=np.uint8).tobytes()
+        elif kind == 2:                                              # cut short / something appended
+            b = b[:int(rng.integers(4, len(b)))] if k % 8 == 2 else b + bytes(rng.integers(0, 256, 5, dtype=np.uint8))
+        else:                                                        # the header region
+            i = int(rng.integers(0, min(200, len(b))))
+            b[i] = int(rng.integers(0, 256))
+        blobs.append(bytes(b))
+    want = []
+    for b in blobs:
+        try:
+            want.append(bz2.decompress(b))
+        except (OSError, ValueError, EOFError):
+            want.append(None)
+    src, off, ln = _pack(blobs)
+    with Nv.Bz2Decoder(0) as z:
+        out_len, status, _ = z.decode(src, off, ln, 1 << 20)
+        agreed = 0
+        for i, w in enumerate(want):
+            if status[i] == 0:
+                assert w is not None and z.fetch(i, 0, int(out_len[i])).tobytes() == w, i
+                agreed += 1
+        assert agreed <= sum(w is not None for w in want)
+        # and the handle is fine afterwards
+        good = base[0]
+        ol, st, _ = z.decode(*_pack([good]), 1 << 20)
+        assert st[0] == 0 and z.fetch(0, 0, int(ol[0])).tobytes() == bz2.decompress(good)
