@@ -44,7 +44,7 @@ enum lfdmi_status {
 /* LFDMI_HOST_PINNED (lfdmi_detect_batch / _raw only): host memory obtained from lfdmi_host_alloc -- the DMA engines read it in
  * place, without the staging copy ordinary host frames take */
 enum { LFDMI_HOST = 0, LFDMI_DEVICE = 1, LFDMI_HOST_PINNED = 2 };
-/* LFDMI_F32_BE (lfdmi_detect_batch_raw only): big-endian float32, the raw data unit of a BITPIX = -32 FITS image (what
+/* LFDMI_F32_BE (lfdmi_detect_batch_raw only; LFDMI_DEVICE frames of that type are byte-swapped IN PLACE): big-endian float32, the raw data unit of a BITPIX = -32 FITS image (what
  * fitsio hands the reference after its own byte swap, detecttrails.py:113); swapped on the device after the upload */
 enum { LFDMI_U8 = 0, LFDMI_F32 = 1, LFDMI_F64 = 2, LFDMI_F32_BE = 3 };
 /* numpy masking done before cv2.convertScaleAbs */
@@ -243,7 +243,9 @@ int lfdmi_detect_batch(lfdmi_ctx *ctx, float *frames, int n, int h, int w,
  * Big-endian frames are treated as a read-only input: remove_stars' squares are applied inside the library (masked as
  * the bright sweep loads the values; a frame that has to be run again alone takes its own catalogue entry) and the caller's
  * bytes -- a file's data unit -- stay as they are; LFDMI_F32 frames are blotted in place as in lfdmi_detect_batch (complete
- * when the call returns: for device-resident frames the zero fill runs on a side stream during the call). */
+ * when the call returns: for device-resident frames the zero fill runs on a side stream during the call).  LFDMI_F32_BE frames
+ * in DEVICE memory (data units decompressed there: lfdmi_bz2_frames) are working memory of the caller's, not a file's bytes: they are
+ * byte-swapped in place and then treated like any LFDMI_F32 device frames. */
 int lfdmi_detect_batch_raw(lfdmi_ctx *ctx, void *frames, int dtype, int n, int h, int w,
                            const lfdmi_catalog *cat, const lfdmi_rs_params *rs,
                            const lfdmi_params *bright, const lfdmi_params *dim, lfdmi_result *results,
@@ -300,6 +302,10 @@ int lfdmi_bz2_decode_batch(lfdmi_bz2 *z, const void *src, const uint64_t *src_of
                            void *head, uint64_t head_bytes, uint64_t *out_len, int32_t *status);
 int lfdmi_bz2_fetch(lfdmi_bz2 *z, int i, uint64_t off, uint64_t nbytes, void *dst, int loc);
 int lfdmi_bz2_fetch_many(lfdmi_bz2 *z, int n, const int32_t *file, const uint64_t *off, const uint64_t *nbytes, void *const *dst, int loc);
+/* Device memory of the handle's own (two buffers, which = 0 / 1: one chunk is decoded while the previous one is processed) to
+ * gather decoded data units into -- lfdmi_bz2_fetch_many(..., LFDMI_DEVICE) -- and to hand to lfdmi_detect_batch_raw(...,
+ * LFDMI_F32_BE, ..., LFDMI_DEVICE): compressed frames then cross PCIe once, compressed, and never return to the host. */
+int lfdmi_bz2_frames(lfdmi_bz2 *z, int which, uint64_t bytes, void **dev);
 /* milliseconds of the last batch: upload + magic search, Huffman / move-to-front, sort, inverse BWT walks, run-length + CRC + output */
 int lfdmi_bz2_timings(lfdmi_bz2 *z, float *ms5);
 /* Which calls keep the 8-bit stage images (gray, eroded, equalised+dilated: what the reference's debug PNGs show) for

@@ -31,7 +31,7 @@ SYMBOLS = (
     "lfdmi_max_inflight", "lfdmi_prep_u8", "lfdmi_equalize_hist", "lfdmi_dilate", "lfdmi_erode",
     "lfdmi_canny", "lfdmi_gaussian_blur", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
     "lfdmi_hough_dims", "lfdmi_remove_stars", "lfdmi_process_bright", "lfdmi_process_dim",
-    "lfdmi_detect_batch", "lfdmi_detect_batch_raw", "lfdmi_host_alloc", "lfdmi_host_free", "lfdmi_fits_read_frames", "lfdmi_fits_read_photoobj", "lfdmi_bz2_find_blocks", "lfdmi_bz2_create", "lfdmi_bz2_destroy", "lfdmi_bz2_last_error", "lfdmi_bz2_decode_batch", "lfdmi_bz2_fetch", "lfdmi_bz2_fetch_many", "lfdmi_bz2_timings", "lfdmi_set_stage_images", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_timing_select", "lfdmi_get_timing",
+    "lfdmi_detect_batch", "lfdmi_detect_batch_raw", "lfdmi_host_alloc", "lfdmi_host_free", "lfdmi_fits_read_frames", "lfdmi_fits_read_photoobj", "lfdmi_bz2_find_blocks", "lfdmi_bz2_create", "lfdmi_bz2_destroy", "lfdmi_bz2_last_error", "lfdmi_bz2_decode_batch", "lfdmi_bz2_fetch", "lfdmi_bz2_fetch_many", "lfdmi_bz2_frames", "lfdmi_bz2_timings", "lfdmi_set_stage_images", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_timing_select", "lfdmi_get_timing",
     "lfdmi_timing_slots", "lfdmi_timing_name",
 )
 
@@ -119,6 +119,7 @@ def lib():
         _lib.lfdmi_bz2_fetch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
         _lib.lfdmi_bz2_fetch_many.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib.lfdmi_bz2_timings.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.lfdmi_bz2_frames.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]
     return _lib
 
 
@@ -206,6 +207,28 @@ BZ2_STATUS = {0: "ok", 1: "no block magic", 2: "randomised block", 3: "bad block
               9: "larger than out_cap", 10: "not a sequence of bzip2 streams"}
 
 
+class DeviceFrames:
+    """n big-endian float32 frames (the data units of FITS images) in device memory that belongs to a ``Bz2Decoder``: what
+    ``Context.detect_batch`` takes instead of an array when the frames were decompressed on the GPU and never left it."""
+
+    def __init__(self, ptr, shape):
+        self._ptr = int(ptr)
+        self.shape = tuple(int(x) for x in shape)            # (n, h, w)
+
+    def data_ptr(self):
+        return self._ptr
+
+    @property
+    def frame_bytes(self):
+        return self.shape[1] * self.shape[2] * 4
+
+    def address_of(self, k):
+        return self._ptr + int(k) * self.frame_bytes
+
+    def slice(self, a, b):
+        return DeviceFrames(self.address_of(a), (int(b) - int(a), self.shape[1], self.shape[2]))
+
+
 class Bz2Decoder:
     """lfdmi_bz2_*: whole ``.bz2`` files decompressed on the GPU, many at once (include/lfdmi.h).  ``decode`` takes the
     compressed files as one uint8 array + offsets / lengths and returns (out_len, status, heads); the decompressed bytes stay on
@@ -260,15 +283,23 @@ class Bz2Decoder:
         return dst
 
     def fetch_many(self, files, offsets, nbytes, dsts):
-        """One range per entry, all copies queued before one wait.  dsts: numpy arrays (or torch CUDA tensors, all of one kind)."""
+        """One range per entry, all copies queued before one wait.  dsts: numpy arrays, torch CUDA tensors, or plain integers =
+        device addresses (``DeviceFrames.address_of``), all of one kind."""
         n = len(files)
         if n == 0:
             return
         f = np.ascontiguousarray(files, np.int32)
         o = np.ascontiguousarray(offsets, np.uint64)
         b = np.ascontiguousarray(nbytes, np.uint64)
-        ptrs = (C.c_void_p * n)(*[_ptr(d) for d in dsts])
-        self._chk(self._lib.lfdmi_bz2_fetch_many(self._h, n, _ptr(f), _ptr(o), _ptr(b), ptrs, DEVICE if _is_dev(dsts[0]) else HOST))
+        on_dev = isinstance(dsts[0], int) or _is_dev(dsts[0])
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(d) if isinstance(d, int) else _ptr(d) for d in dsts])
+        self._chk(self._lib.lfdmi_bz2_fetch_many(self._h, n, _ptr(f), _ptr(o), _ptr(b), ptrs, DEVICE if on_dev else HOST))
+
+    def frames(self, which, n, h, w):
+        """The handle's device buffer ``which`` (0 / 1), at least n frames of h x w float32 large, as ``DeviceFrames``."""
+        p = C.c_void_p()
+        self._chk(self._lib.lfdmi_bz2_frames(self._h, int(which), C.c_uint64(int(n) * int(h) * int(w) * 4), C.byref(p)))
+        return DeviceFrames(p.value, (n, h, w))
 
     def timings(self):
         ms = np.zeros(5, np.float32)
@@ -602,7 +633,10 @@ class Context:
 
         numpy frames of dtype '>f4' (the raw data unit of a FITS image) are accepted as they are and byte-swapped on the
         device.  ``pinned=True``: the array lives in memory from ``PinnedBuffer`` (DMA'd in place, no staging copy)."""
-        if not _is_dev(frames) and isinstance(frames, np.ndarray) and frames.dtype == np.dtype(">f4"):
+        if isinstance(frames, DeviceFrames):                  # decompressed on the device (Bz2Decoder.frames): swapped in place there
+            n, h, w = frames.shape
+            code = F32_BE
+        elif not _is_dev(frames) and isinstance(frames, np.ndarray) and frames.dtype == np.dtype(">f4"):
             if not frames.flags.c_contiguous:
                 raise ValueError("big-endian frames must be C-contiguous")
             shp = frames.shape

@@ -26,6 +26,7 @@ struct lfdmi_bz2 {
     int *blk_size = nullptr; u64 *blk_off = nullptr; size_t blocks_cap = 0;
     uint8_t *out = nullptr; size_t out_bytes = 0;
     uint8_t *heads = nullptr; size_t heads_bytes = 0;
+    uint8_t *frames[2] = {nullptr, nullptr}; size_t frames_bytes[2] = {0, 0}; // what the caller gathers decoded data units into (lfdmi_bz2_frames)
     // the last batch
     int n_files = 0; uint64_t out_cap = 0;
     std::vector<uint64_t> h_out_len;
@@ -88,7 +89,7 @@ extern "C" void lfdmi_bz2_destroy(lfdmi_bz2 *z) {
     (void)hipSetDevice(z->device);
     if (z->stream) (void)hipStreamSynchronize(z->stream);
     void *ps[] = {z->comp, z->word_off, z->nbytes, z->nfound, z->marks, z->file_first, z->file_status, z->out_len, z->desc, z->info,
-                  z->Lbuf, z->selbuf, z->segbuf, z->tt, z->meta, z->tile_fn, z->tile_in, z->blk_crc, z->blk_size, z->blk_off, z->out, z->heads};
+                  z->Lbuf, z->selbuf, z->segbuf, z->tt, z->meta, z->tile_fn, z->tile_in, z->blk_crc, z->blk_size, z->blk_off, z->out, z->heads, z->frames[0], z->frames[1]};
     for (void *p : ps) if (p) (void)hipFree(p);
     for (int i = 0; i < 6; i++) if (z->ev[i]) (void)hipEventDestroy(z->ev[i]);
     if (z->stream) (void)hipStreamDestroy(z->stream);
@@ -335,5 +336,16 @@ extern "C" int lfdmi_bz2_fetch_many(lfdmi_bz2 *z, int n, const int32_t *file, co
                             loc == LFDMI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, z->stream));
     }
     BCHK(hipStreamSynchronize(z->stream));
+    return 0;
+}
+
+// device memory of the handle's own for the caller to gather decoded ranges into (lfdmi_bz2_fetch_many with LFDMI_DEVICE) and hand to
+// lfdmi_detect_batch_raw(..., LFDMI_F32_BE, ..., LFDMI_DEVICE): two buffers, so that one chunk can be decoded while the previous
+// one is being processed.  A buffer keeps its address until a larger one is asked for under the same index.
+extern "C" int lfdmi_bz2_frames(lfdmi_bz2 *z, int which, uint64_t bytes, void **dev) {
+    if (!z || !dev || which < 0 || which > 1 || bytes == 0) return bfail(z, LFDMI_ERR_ARG, "lfdmi_bz2_frames: bad argument");
+    BCHK(hipSetDevice(z->device));
+    BCHK(regrow(z->frames[which], z->frames_bytes[which], (size_t)bytes));
+    *dev = z->frames[which];
     return 0;
 }

@@ -2320,8 +2320,14 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
     if (!frames || !results) return fail(ctx, LFDMI_ERR_ARG, "NULL argument");
     if (dtype != LFDMI_F32 && dtype != LFDMI_F32_BE) return fail(ctx, LFDMI_ERR_DTYPE, "lfdmi_detect_batch_raw: frames must be LFDMI_F32 or LFDMI_F32_BE");
     if (loc != LFDMI_HOST && loc != LFDMI_DEVICE && loc != LFDMI_HOST_PINNED) return fail(ctx, LFDMI_ERR_ARG, "bad loc");
+    if (dtype == LFDMI_F32_BE && loc == LFDMI_DEVICE) {
+        // big-endian frames already on the device (decoded there: lfdmi_bz2_*): swapped in place, once -- a chunk that is run again
+        // (table growth, general path) must not be swapped again -- and native from here on
+        HIPCHK(hipSetDevice(ctx->device));
+        RET(run_bswap(ctx, frames, (size_t)n * h * w * 4));
+        dtype = LFDMI_F32;
+    }
     const bool be = dtype == LFDMI_F32_BE;
-    if (be && loc == LFDMI_DEVICE) return fail(ctx, LFDMI_ERR_ARG, "big-endian frames must be host frames (they are swapped in the library's device copy)");
     const bool pinned = loc == LFDMI_HOST_PINNED;
     if (pinned) loc = LFDMI_HOST; // (everything below but the upload treats them as host frames)
     if (!hough_fits(ctx, h, w, bright->houghMethod, LFD_PI / 180) || !hough_fits(ctx, h, w, dim->houghMethod, LFD_PI / 180)) {

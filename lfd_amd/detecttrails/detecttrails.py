@@ -257,13 +257,18 @@ def process_loaded(results, errors, loaded, params_bright, params_dim, params_re
             packed["count"] = cats["count"][a:b]
             with use_context(h, w, inflight=min(256, len(idx))) as ctx:
                 t_g = time.perf_counter()
-                recs = ctx.detect_batch(loaded.buffer[a:b], params_bright, params_dim, packed, _rs_struct(flt, params_removestars), pinned=True)
+                if loaded.device is not None:                 # decompressed on the GPU and still there
+                    recs = ctx.detect_batch(loaded.device.slice(a, b), params_bright, params_dim, packed, _rs_struct(flt, params_removestars))
+                else:
+                    recs = ctx.detect_batch(loaded.buffer[a:b], params_bright, params_dim, packed, _rs_struct(flt, params_removestars), pinned=True)
                 t_gpu += time.perf_counter() - t_g
             for i, rec in zip(idx, recs):
                 rows[i] = rec
         except Exception:  # noqa: BLE001 - a call-level failure: every frame of the slice on its own, under its own try
             for sl, i in zip(run_slots, idx):
                 try:
+                    if loaded.device is not None:             # (the frames are wherever the failed call left them: no second source)
+                        raise
                     img = loaded.buffer[sl].astype(_np.float32)
                     rows[i] = process_frame_arrays(img, loaded.cat_of(i), flt, params_bright, params_dim, params_removestars)[2]
                 except Exception as e:  # noqa: BLE001

@@ -93,6 +93,13 @@ class Loaded:
         self.hdr = [None] * n
         self.cat = [None] * n
         self.buffer = None                                   # [slots, h, w] '>f4' view of the pinned memory
+        self.device = None                                   # or: _native.DeviceFrames (the same slots in device memory: frames that
+                                                             # were decompressed on the GPU and stayed there; ``buffer`` is then unused)
+        self.fetch = None                                    # slot -> '>f4' (h, w) host copy of a device frame (valid while the chunk is loaded)
+
+    def frame_host(self, slot):
+        """Slot ``slot`` as a host array, wherever the chunk's frames are."""
+        return self.buffer[slot] if self.device is None else self.fetch(slot)
         self.cats = None                                     # padded catalogue arrays of the buffer's slots + "count"
 
     def cat_of(self, i):
@@ -141,6 +148,7 @@ class FrameLoader:
         self.ctx = ctx
         self.bz2_device = os.environ.get("LFD_BZ2_DEVICE", "1") != "0" and hasattr(ctx, "device")   # (a real _native.Context)
         self.bz2_out_cap = self.frame_bytes + int(os.environ.get("LFD_BZ2_EXTRA_MB", 4)) * (1 << 20)   # (a frame file = image + three small HDUs)
+        self.bz2_keep_on_device = os.environ.get("LFD_BZ2_KEEP_ON_DEVICE", "1") != "0"   # 0: decoded frames travel to the pinned slots and back
         self.bz2_device_min = int(os.environ.get("LFD_BZ2_DEVICE_MIN", 8))   # fewer compressed frames in a chunk than this: the host decodes them
         self._bz2 = None
         self._bz2_pin = None
@@ -210,7 +218,7 @@ class FrameLoader:
         except Exception as e:  # noqa: BLE001 - this frame's errors.txt entry (detecttrails.py:133-139)
             out.error[i] = e
 
-    def _device_bz2(self, out, todo, raw):
+    def _device_bz2(self, out, todo, raw, which, whole_chunk):
         """``todo``: [(i, slot, path + '.bz2')] frames of this chunk that exist only compressed.  Decompresses them on the GPU and
         puts each image's data unit into its pinned slot; returns the entries that still have to go the host way."""
         import time
@@ -242,7 +250,7 @@ class FrameLoader:
             self.bz2_device = False
             return list(todo)
         t2 = time.perf_counter()
-        rest, files, foff, fbytes, dsts = [], [], [], [], []
+        rest, files, foff, fbytes, slots_of = [], [], [], [], []
         whole = []
         for k, (i, slot, path) in enumerate(todo):
             if not ok_read[k] or status[k] != 0:
@@ -253,10 +261,25 @@ class FrameLoader:
             if end < 0 or not self._fast(hdr[:end]) or int(out_len[k]) < end + self.frame_bytes:
                 whole.append((k, i, slot, path))                # a long header, another pixel type, a short file: the general reader
                 continue
-            files.append(k); foff.append(end); fbytes.append(self.frame_bytes)
-            dsts.append(raw[slot * self.frame_bytes:(slot + 1) * self.frame_bytes])
+            files.append(k); foff.append(end); fbytes.append(self.frame_bytes); slots_of.append(slot)
             out.slot[i], out.hdr[i] = slot, hdr[:end]
-        self._bz2.fetch_many(files, foff, fbytes, dsts)
+        # Every frame of the chunk decoded and plain: the data units are gathered in device memory and stay there (the GPU call
+        # takes them as they are: compressed frames cross PCIe once, compressed).  Otherwise -- plain files in the chunk, a frame
+        # for the host decoder or the general reader -- everything meets in the pinned slots as before.
+        if whole_chunk and not rest and not whole and self.bz2_keep_on_device:
+            h, w = self.shape
+            dev = self._bz2.frames(which, self.slots, h, w)
+            self._bz2.fetch_many(files, foff, fbytes, [dev.address_of(sl) for sl in slots_of])
+            out.device = dev
+            src_of = {sl: (k, e) for sl, k, e in zip(slots_of, files, foff)}
+            dec = self._bz2
+
+            def fetch(slot, _src=src_of, _dec=dec, _fb=self.frame_bytes, _shape=self.shape):   # (only inside load(): the next decode reuses the files)
+                k, e = _src[slot]
+                return _dec.fetch(k, e, _fb).view(">f4").reshape(_shape)
+            out.fetch = fetch
+        else:
+            self._bz2.fetch_many(files, foff, fbytes, [raw[sl * self.frame_bytes:(sl + 1) * self.frame_bytes] for sl in slots_of])
         for k, i, slot, path in whole:
             try:
                 self._from_decompressed(out, i, slot, raw[slot * self.frame_bytes:(slot + 1) * self.frame_bytes],
@@ -287,7 +310,7 @@ class FrameLoader:
             else:                                            # more rows than the padded arrays hold: the per-frame path
                 out.cat[i] = {k: np.asarray(cat[k]) for k in _CAT5 + _CAT1}
                 if out.slot[i] >= 0:
-                    out.array[i] = out.buffer[out.slot[i]].astype(np.float32)
+                    out.array[i] = out.frame_host(out.slot[i]).astype(np.float32)
                     out.slot[i] = -1
         except Exception as e:  # noqa: BLE001
             out.error[i] = e
@@ -331,7 +354,7 @@ class FrameLoader:
             todo = [(i, slot, fpaths[slot] + ".bz2") for slot, i in enumerate(order)
                     if int(fstat[slot]) == -1 and not os.path.exists(fpaths[slot]) and os.path.exists(fpaths[slot] + ".bz2")]
             if len(todo) >= self.bz2_device_min:             # (a handful of files: their blocks side by side on the host's cores are quicker)
-                rest = self._device_bz2(out, todo, raw)
+                rest = self._device_bz2(out, todo, raw, which, len(todo) == n)
                 on_device = {i for i, _, _ in todo} - {i for i, _, _ in rest}
                 self.bz2_stats["host_frames"] += len(rest)
         self.split_blocks = int((fstat != 0).sum()) - len(on_device) < self.threads   # (few files for many cores: their blocks side by side)

@@ -145,6 +145,7 @@ def test_loader_decodes_a_chunk_of_bz2_frames_on_the_device(tmp_path, monkeypatc
                 assert np.array_equal(out.buffer[out.slot[i]].astype(np.float32), frames[i])
                 assert loader.header_values(out.hdr[i], ["TAI"]) == [hdr["TAI"]]
             assert ld.bz2_stats["device_frames"] == n - 1 and ld.bz2_stats["host_frames"] == 1
+            assert out.device is None                                # (one frame went the host way: the chunk meets in the pinned slots)
         monkeypatch.setenv("LFD_BZ2_DEVICE", "0")
         with loader.FrameLoader(ctx, shape, 8, threads=3) as ld:
             out2 = ld.load(keys, 0)
@@ -199,3 +200,46 @@ def test_damaged_files_never_decode_to_something_else():
         good = base[0]
         ol, st, _ = z.decode(*_pack([good]), 1 << 20)
         assert st[0] == 0 and z.fetch(0, 0, int(ol[0])).tobytes() == bz2.decompress(good)
+
+
+def test_a_chunk_of_compressed_frames_stays_on_the_device(tmp_path, monkeypatch, oracle):
+    """All frames of a chunk exist only as .fits.bz2: they are decompressed on the GPU, their data units gathered in device memory
+    and handed to the detection kernels there (big-endian, swapped in place); rows equal the oracle's, and equal the run that sends
+    the decoded frames through the pinned slots."""
+    from lfd_amd import results, synth
+    from lfd_amd.detecttrails import DetectTrails, default_params, loader, sdssfiles
+    shape, n = (512, 768), 10
+    frames, cats = [], []
+    for k in range(n):
+        img, cat, _ = synth.make_portable_frame(k, shape)
+        frames.append(img)
+        cats.append(cat)
+    hdr = synth.write_boss_tree(tmp_path, frames, cats, field0=100, bz2_all=True)
+    pb, pd, prs = default_params()
+    rs = oracle.rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
+    want = []
+    for k in range(n):
+        rec = oracle.detect_frame(frames[k].copy(), pb, pd, cats[k], rs)
+        if rec["found"]:
+            want.append(results.format_result_row(94, 1, "r", 100 + k, hdr, rec))
+    assert len(want) >= 3
+    seen = []
+    real_load = loader.FrameLoader.load
+
+    def spy(self, keys, which):
+        out = real_load(self, keys, which)
+        seen.append(out.device is not None)
+        return out
+    monkeypatch.setattr(loader.FrameLoader, "load", spy)
+    rows = {}
+    for keep in ("1", "0"):
+        monkeypatch.setenv("LFD_BZ2_KEEP_ON_DEVICE", keep)
+        save = tmp_path / ("out" + keep)
+        save.mkdir()
+        dt = DetectTrails(run=94, camcol=1, filter="r", savepath=str(save))
+        dt.process(batch=16)
+        rows[keep] = [ln.strip() for ln in open(dt.results) if ln.strip()]
+        assert open(dt.errors).read() == ""
+        assert dt.last_stats["bz2"]["device_frames"] == n
+    assert seen == [True, False]
+    assert rows["1"] == want and rows["0"] == want
