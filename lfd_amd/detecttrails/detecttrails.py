@@ -502,13 +502,13 @@ class DetectTrails:
             try:
                 trace = os.environ.get("LFD_LOADER_TRACE") == "1"
                 with ThreadPoolExecutor(1, thread_name_prefix="lfd-chunk") as coord:
-                    nxt = coord.submit(loader.load, chunks[0], 0)
+                    nxt = coord.submit(loader.load, chunks[0], 0, chunks[1] if len(chunks) > 1 else None)
                     for i, chunk in enumerate(chunks):
                         t0 = time.perf_counter()
                         loaded = nxt.result()
                         t1 = time.perf_counter()
                         # (buffer (i + 1) & 1 held chunk i - 1, whose GPU call has returned: it is free to be refilled)
-                        nxt = coord.submit(loader.load, chunks[i + 1], (i + 1) & 1) if i + 1 < len(chunks) else None
+                        nxt = coord.submit(loader.load, chunks[i + 1], (i + 1) & 1, chunks[i + 2] if i + 2 < len(chunks) else None) if i + 1 < len(chunks) else None
                         process_loaded(results, errors, loaded, self.params_bright, self.params_dim, self.params_removestars)
                         mark(chunk)
                         self.last_stats["chunk_done_s"].append(time.perf_counter() - t_start)

@@ -151,7 +151,8 @@ class FrameLoader:
         self.bz2_keep_on_device = os.environ.get("LFD_BZ2_KEEP_ON_DEVICE", "1") != "0"   # 0: decoded frames travel to the pinned slots and back
         self.bz2_device_min = int(os.environ.get("LFD_BZ2_DEVICE_MIN", 8))   # fewer compressed frames in a chunk than this: the host decodes them
         self._bz2 = None
-        self._bz2_pin = None
+        self._bz2_pins = [None, None]                        # compressed bytes of a chunk: this chunk's, and the next one's being read ahead
+        self._bz2_ahead = None                               # (paths, sizes, offsets, futures, buffer index) of the read-ahead
         self.bz2_stats = {"device_frames": 0, "host_frames": 0, "decode_s": 0.0, "read_s": 0.0, "fetch_s": 0.0}
 
     def close(self):
@@ -160,9 +161,14 @@ class FrameLoader:
         if self._bz2 is not None:
             self._bz2.close()
             self._bz2 = None
-        if self._bz2_pin is not None:
-            self._bz2_pin.close()
-            self._bz2_pin = None
+        if self._bz2_ahead is not None:
+            for f in self._bz2_ahead[3]:
+                f.cancel() or f.exception()
+            self._bz2_ahead = None
+        for k, p in enumerate(self._bz2_pins):
+            if p is not None:
+                p.close()
+                self._bz2_pins[k] = None
         self.views = None
         for p in self.pins:
             p.close()
@@ -218,29 +224,52 @@ class FrameLoader:
         except Exception as e:  # noqa: BLE001 - this frame's errors.txt entry (detecttrails.py:133-139)
             out.error[i] = e
 
-    def _device_bz2(self, out, todo, raw, which, whole_chunk):
-        """``todo``: [(i, slot, path + '.bz2')] frames of this chunk that exist only compressed.  Decompresses them on the GPU and
-        puts each image's data unit into its pinned slot; returns the entries that still have to go the host way."""
-        import time
-        t0 = time.perf_counter()
-        sizes = [os.path.getsize(p) for _, _, p in todo]
+    def _read_compressed(self, paths, pin_k):
+        """Starts reading ``paths`` into compressed-bytes buffer ``pin_k`` on the loader's pool: (sizes, offsets, futures)."""
+        sizes = [os.path.getsize(p) if os.path.exists(p) else 0 for p in paths]
         offs, cur = [], 0
         for z in sizes:
             offs.append(cur)
             cur += (z + 255) & ~255
-        if self._bz2 is None:
-            self._bz2 = _native.Bz2Decoder(self.ctx.device)
-        if self._bz2_pin is None or self._bz2_pin.nbytes < cur:
-            if self._bz2_pin is not None:
-                self._bz2_pin.close()
-            self._bz2_pin = self.ctx.pinned_buffer(max(cur + cur // 4, 1 << 20))
-        src = self._bz2_pin.array
+        pin = self._bz2_pins[pin_k]
+        if pin is None or pin.nbytes < cur:
+            if pin is not None:
+                pin.close()
+            pin = self._bz2_pins[pin_k] = self.ctx.pinned_buffer(max(cur + cur // 4, 1 << 20))
+        src = pin.array
 
         def read(k):
-            with open(todo[k][2], "rb", buffering=0) as f:
-                got = f.readinto(memoryview(src)[offs[k]:offs[k] + sizes[k]])
-            return got == sizes[k]
-        ok_read = list(self.pool.map(read, range(len(todo))))
+            try:
+                with open(paths[k], "rb", buffering=0) as f:
+                    got = f.readinto(memoryview(src)[offs[k]:offs[k] + sizes[k]])
+                return got == sizes[k]
+            except OSError:                                  # (the host path meets the same error and reports it)
+                return False
+        return sizes, offs, [self.pool.submit(read, k) for k in range(len(paths))]
+
+    def _device_bz2(self, out, todo, raw, which, whole_chunk, next_paths=None):
+        """``todo``: [(i, slot, path + '.bz2')] frames of this chunk that exist only compressed.  Decompresses them on the GPU and
+        puts each image's data unit into its pinned slot; returns the entries that still have to go the host way."""
+        import time
+        t0 = time.perf_counter()
+        paths = [p for _, _, p in todo]
+        if self._bz2 is None:
+            self._bz2 = _native.Bz2Decoder(self.ctx.device)
+        ahead, self._bz2_ahead = self._bz2_ahead, None
+        if ahead is not None and ahead[0] == paths:           # read while the previous chunk was being decoded
+            _, sizes, offs, futs, pin_k = ahead
+            ok_read = [f.result() for f in futs]
+        else:
+            if ahead is not None:
+                for f in ahead[3]:
+                    f.result()
+            pin_k = 0 if ahead is None else ahead[4] ^ 1
+            sizes, offs, futs = self._read_compressed(paths, pin_k)
+            ok_read = [f.result() for f in futs]
+        src = self._bz2_pins[pin_k].array
+        if next_paths:                                        # the next chunk's files: into the other buffer, while this chunk is on the GPU
+            s2, o2, f2 = self._read_compressed(next_paths, pin_k ^ 1)
+            self._bz2_ahead = (list(next_paths), s2, o2, f2, pin_k ^ 1)
         t1 = time.perf_counter()
         try:
             out_len, status, heads = self._bz2.decode(src, offs, sizes, self.bz2_out_cap, HDR_CAP)
@@ -317,10 +346,25 @@ class FrameLoader:
             out.slot[i] = -1
             out.array[i] = None
 
+    def _compressed_only(self, keys):
+        """The .bz2 paths of ``keys`` (the chunk after this one) if every frame of it exists only compressed, else None."""
+        if not keys or not self.bz2_device or len(keys) < self.bz2_device_min:
+            return None
+        paths = []
+        for i in sorted(range(len(keys)), key=lambda i: keys[i][2]):     # (the order load() gives the slots in)
+            run, camcol, flt, field = keys[i]
+            p = sdssfiles.filename("frame", run=run, camcol=camcol, field=field, filter=flt)
+            if os.path.exists(p) or not os.path.exists(p + ".bz2"):
+                return None
+            paths.append(p + ".bz2")
+        return paths
+
     # -- a chunk --------------------------------------------------------------------------------------------------
-    def load(self, keys, which):
+    def load(self, keys, which, next_keys=None):
         """Read ``keys`` (at most ``slots``) into pinned buffer ``which`` (0 / 1).  Frames of one filter get neighbouring slots
-        (remove_stars' magnitude cap depends on the filter, so a GPU call takes one filter's frames: a contiguous slice)."""
+        (remove_stars' magnitude cap depends on the filter, so a GPU call takes one filter's frames: a contiguous slice).
+        ``next_keys``: the chunk that will be asked for next; if it exists only as .fits.bz2 its files are read ahead while
+        this chunk is being decompressed."""
         n = len(keys)
         if n > self.slots:
             raise ValueError("chunk larger than the loader's buffers")
@@ -354,7 +398,7 @@ class FrameLoader:
             todo = [(i, slot, fpaths[slot] + ".bz2") for slot, i in enumerate(order)
                     if int(fstat[slot]) == -1 and not os.path.exists(fpaths[slot]) and os.path.exists(fpaths[slot] + ".bz2")]
             if len(todo) >= self.bz2_device_min:             # (a handful of files: their blocks side by side on the host's cores are quicker)
-                rest = self._device_bz2(out, todo, raw, which, len(todo) == n)
+                rest = self._device_bz2(out, todo, raw, which, len(todo) == n, self._compressed_only(next_keys))
                 on_device = {i for i, _, _ in todo} - {i for i, _, _ in rest}
                 self.bz2_stats["host_frames"] += len(rest)
         self.split_blocks = int((fstat != 0).sum()) - len(on_device) < self.threads   # (few files for many cores: their blocks side by side)
