@@ -71,8 +71,8 @@ struct BzDevIO {
     // One ordinary symbol: the byte at position nn >= 1 of the list moves to the front and is appended to the output.  Both are
     // "shift everything below by one byte and put v in front": a byte shift inside each lane with the top byte of lane l - 1
     // coming in at the bottom (DPP wave_shr; lane 0 has no lane below it and takes v from the instruction's `old` operand).
-    __device__ __forceinline__ void symbol(int nn) {
-        const int q = nn >> 2;
+    __device__ __forceinline__ void symbol(int nn, int q) { // q = nn >> 2 (the caller has it from the table entry); cnt is the caller's to count
+
         const uint32_t wq = (uint32_t)__builtin_amdgcn_readlane((int)list, q);
         const uint32_t r8 = (((uint32_t)nn + vz) & 3u) << 3;          // (vector registers from here on)
         const uint32_t v24 = (wq >> r8) << 24;                         // the byte, in the top byte
@@ -83,7 +83,6 @@ struct BzDevIO {
         list = (sh & m) | (list & ~m);
         const uint32_t sprev = (uint32_t)__builtin_amdgcn_update_dpp((int)v24, (int)stage, 0x138, 0xf, 0xf, false);
         stage = (stage << 8) | (sprev >> 24);
-        cnt++;
     }
     __device__ __forceinline__ void emit(uint32_t b) { // (a byte that is not a list move: runs)
         const uint32_t v24 = (b + vz) << 24;
@@ -119,7 +118,10 @@ struct BzDevIO {
         __syncthreads(); // (one wave: orders the LDS traffic of the table building before the fast table overwrites `len`)
         for (int k = 0; k < BZ_FAST_SIZE / 64; k++) {
             const uint32_t x = (uint32_t)(lane + 64 * k);
-            fast[t * BZ_FAST_SIZE + x] = bz_fast_entry(*this, t, mn, x);
+            // (the kernel's own encoding: position in the move-to-front list = symbol - 1, mod 512, in front of the code length:
+            // RUNA 511, RUNB 0, end of block n_in_use: the exceptions are `entry's position - 1 >= n_in_use - 1`, unsigned)
+            const uint32_t e0 = bz_fast_entry(*this, t, mn, x);
+            fast[t * BZ_FAST_SIZE + x] = (uint16_t)(e0 ? ((((e0 >> 4) - 1u) & 0x1ffu) << 4) | (e0 & 15u) : 0u);
         }
         __syncthreads();
     }
@@ -181,20 +183,21 @@ __device__ __forceinline__ int bz_dev_symbols(BzDevIO &io, const uint32_t *w, ui
         bool done = false;
         for (;;) { // stretches of ordinary symbols, an exception between two of them (errors are collected in `bad`, looked at once per window)
             uint32_t e;
-            int sym;
-            bool window_done = false;
-            for (;;) { // the ordinary symbols: nothing in here touches what the exceptions change (run state, thr, flushed)
+            const int gp0 = group_pos;
+            for (;;) { // the ordinary symbols: nothing in here touches what the exceptions change (run state, thr, flushed, cnt)
                 e = (uint32_t)__builtin_amdgcn_readlane((int)ev, pos);
-                sym = (int)(e >> 4);
-                if (__builtin_expect((uint32_t)(sym - 2) >= thr, 0)) break;
+                const int nn = (int)(e >> 4);
+                if (__builtin_expect((uint32_t)(nn - 1) >= thr, 0)) break;
                 pos += (int)(e & 15u);
-                io.symbol(sym - 1); // (a block that grows beyond its level's size is caught when a buffer is flushed)
+                io.symbol(nn, (int)(e >> 6)); // (a block that grows beyond its level's size is caught when a buffer is flushed)
                 group_pos--;
-                if (((group_pos - 1) | (63 - pos)) < 0) { window_done = true; break; } // the table's 50 symbols are used up, or the window is
+                if (((group_pos - 1) | (63 - pos)) < 0) break; // the table's 50 symbols are used up, or the window is
             }
-            if (window_done) break;
+            io.cnt += gp0 - group_pos; // one byte per ordinary symbol
+            if (((group_pos - 1) | (63 - pos)) < 0) break; // (which of the two exits it was: this one cannot hold when an exception ended the loop)
             // the exceptions, all behind that one test: a code longer than the look-up covers (e = 0), RUNA / RUNB, the end-of-block
             // symbol, and any symbol while a run is being collected (thr = 0 then)
+            int sym = (int)(((e >> 4) + 1u) & 0x1ffu);
             int len = (int)(e & 15u);
             if (e == 0u) {
                 BzBits br;
@@ -219,7 +222,8 @@ __device__ __forceinline__ int bz_dev_symbols(BzDevIO &io, const uint32_t *w, ui
                     if (io.cnt > 256 - 64) io.flush();
                 }
                 if (sym == eob) { done = true; break; }
-                io.symbol(sym - 1);
+                io.symbol(sym - 1, (sym - 1) >> 2);
+                io.cnt++;
             }
             if (--group_pos == 0 || pos >= 64) break;
         }
