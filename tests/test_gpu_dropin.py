@@ -157,3 +157,24 @@ def test_mixed_filters_in_one_chunk_and_resume(tmp_path, oracle):
     assert got == want and open(dt.errors).read() == ""
     dt.process(batch=4, resume=True)
     assert dt.last_stats["skipped_by_resume"] == 5 and [ln.strip() for ln in open(dt.results) if ln.strip()] == want
+
+
+def test_jobs_two_workers_equal_one_process(tmp_path, oracle):
+    """lfd_amd.jobs.Jobs: two worker processes (both on the test box's one GPU) over one selection -- a mix of plain and
+    compressed frames, one field without a catalogue -- leave the results.txt / errors.txt a single process leaves."""
+    from lfd_amd.detecttrails import DetectTrails
+    from lfd_amd.jobs import Jobs
+    fields = list(range(0, 9))
+    truth = build_tree(tmp_path, fields)
+    want = expected_rows(oracle, truth, skip={fields[2]})
+    one = tmp_path / "one"
+    two = tmp_path / "two"
+    one.mkdir()
+    two.mkdir()
+    dt = DetectTrails(run=94, camcol=1, filter="r", savepath=str(one))
+    dt.process(batch=4)
+    results, errors = Jobs(2, devices=[0, 0], run=94, camcol=1, filter="r", savepath=str(two)).launch(batch=4, timeout=600)
+    got = [l.strip() for l in open(results) if l.strip()]
+    assert got == want == [l.strip() for l in open(dt.results) if l.strip()]
+    assert open(errors).read() == open(dt.errors).read() != ""
+    assert not os.path.exists(results + ".rank0") and not os.path.exists(results + ".rank1")

@@ -290,3 +290,24 @@ def test_progress_marks_of_an_earlier_run_never_leak_into_a_later_resume(tmp_pat
     os.rename(dt.results + ".rank0.progress", dt.results + ".rank1.progress")
     with pytest.raises(ValueError, match="another selection"):
         dt.process(batch=1, rank=1, world_size=2, resume=True)        # rank 0's marks are not rank 1's
+
+
+def test_jobs_merges_the_workers_files_in_selection_order(tmp_path):
+    """lfd_amd.jobs: the node-level replacement of the reference's PBS fan-out (createjobs/createjobs.py:173-202): one worker per
+    GPU over contiguous blocks of the selection, their files joined in rank order = selection order."""
+    from lfd_amd import jobs
+    res = tmp_path / "results.txt"
+    (tmp_path / "results.txt.rank0").write_text("94 1 r 100 a\n94 1 r 101 b\n")
+    (tmp_path / "results.txt.rank2").write_text("94 1 r 105 c\n")          # (rank 1 found nothing: no file)
+    n = jobs.merge_rank_files(str(res), 3, remove=True)
+    assert res.read_text() == "94 1 r 100 a\n94 1 r 101 b\n94 1 r 105 c\n" and n == len(res.read_text())
+    assert not (tmp_path / "results.txt.rank0").exists() and not (tmp_path / "results.txt.rank2").exists()
+    assert jobs.merge_rank_files(str(res), 1) == 0
+    j = jobs.Jobs(3, devices=[4, 5, 6], run=94, camcol=1)
+    cmds = j.commands("/tmp/spec")
+    assert [c[1]["RANK"] for c in cmds] == ["0", "1", "2"] and [c[1]["LFD_DEVICE"] for c in cmds] == ["4", "5", "6"]
+    assert all(c[1]["WORLD_SIZE"] == "3" and c[1]["LOCAL_WORLD_SIZE"] == "3" and c[0][-2:] == ["--worker", "/tmp/spec"] for c in cmds)
+    assert jobs._parse_value("94") == 94 and jobs._parse_value("r") == "r" and jobs._parse_value("94,125") == [94, 125]
+    import pytest
+    with pytest.raises(ValueError):
+        jobs.Jobs(2, devices=[0])
