@@ -755,7 +755,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the sustained / dropin / lsst legs of the default invocation (profiling runs)")
     ap.add_argument("--sustained-s", type=float, default=3.0)
     ap.add_argument("--dropin-bz2", type=int, default=64, help="distinct frames of the .bz2 sample of the dropin leg (0 = skip)")
-    ap.add_argument("--dropin-bz2-frames", type=int, default=2048, help="fields of the .bz2 run (hard links to the distinct files)")
+    ap.add_argument("--dropin-bz2-frames", type=int, default=4096, help="fields of the .bz2 run (hard links to the distinct files)")
     ap.add_argument("--dropin-frames", type=int, default=4096, help="fields of the plain-FITS run of the dropin leg (hard links of the batch's frames)")
     ap.add_argument("--lsst-distinct", type=int, default=64, help="distinct frames of the secondary lsst leg (each used 256 / this times)")
     args = ap.parse_args()

@@ -306,6 +306,9 @@ int lfdmi_bz2_fetch_many(lfdmi_bz2 *z, int n, const int32_t *file, const uint64_
  * gather decoded data units into -- lfdmi_bz2_fetch_many(..., LFDMI_DEVICE) -- and to hand to lfdmi_detect_batch_raw(...,
  * LFDMI_F32_BE, ..., LFDMI_DEVICE): compressed frames then cross PCIe once, compressed, and never return to the host. */
 int lfdmi_bz2_frames(lfdmi_bz2 *z, int which, uint64_t bytes, void **dev);
+/* optional: allocate now what a batch of n_files files / n_blocks blocks (out_cap bytes of output each, compressed_bytes in all) will
+ * need, instead of inside the first lfdmi_bz2_decode_batch (tens of GB for a chunk of frames; can run beside the first reads) */
+int lfdmi_bz2_reserve(lfdmi_bz2 *z, int n_files, int64_t n_blocks, uint64_t out_cap, uint64_t compressed_bytes);
 /* milliseconds of the last batch: upload + magic search, Huffman / move-to-front, sort, inverse BWT walks, run-length + CRC + output */
 int lfdmi_bz2_timings(lfdmi_bz2 *z, float *ms5);
 /* Which calls keep the 8-bit stage images (gray, eroded, equalised+dilated: what the reference's debug PNGs show) for

@@ -31,7 +31,7 @@ SYMBOLS = (
     "lfdmi_max_inflight", "lfdmi_prep_u8", "lfdmi_equalize_hist", "lfdmi_dilate", "lfdmi_erode",
     "lfdmi_canny", "lfdmi_gaussian_blur", "lfdmi_fit_min_area_rect", "lfdmi_hough_lines", "lfdmi_hough_accum",
     "lfdmi_hough_dims", "lfdmi_remove_stars", "lfdmi_process_bright", "lfdmi_process_dim",
-    "lfdmi_detect_batch", "lfdmi_detect_batch_raw", "lfdmi_host_alloc", "lfdmi_host_free", "lfdmi_fits_read_frames", "lfdmi_fits_read_photoobj", "lfdmi_bz2_find_blocks", "lfdmi_bz2_create", "lfdmi_bz2_destroy", "lfdmi_bz2_last_error", "lfdmi_bz2_decode_batch", "lfdmi_bz2_fetch", "lfdmi_bz2_fetch_many", "lfdmi_bz2_frames", "lfdmi_bz2_timings", "lfdmi_set_stage_images", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_timing_select", "lfdmi_get_timing",
+    "lfdmi_detect_batch", "lfdmi_detect_batch_raw", "lfdmi_host_alloc", "lfdmi_host_free", "lfdmi_fits_read_frames", "lfdmi_fits_read_photoobj", "lfdmi_bz2_find_blocks", "lfdmi_bz2_create", "lfdmi_bz2_destroy", "lfdmi_bz2_last_error", "lfdmi_bz2_decode_batch", "lfdmi_bz2_fetch", "lfdmi_bz2_fetch_many", "lfdmi_bz2_frames", "lfdmi_bz2_reserve", "lfdmi_bz2_timings", "lfdmi_set_stage_images", "lfdmi_get_stage", "lfdmi_get_counters", "lfdmi_enable_timing", "lfdmi_timing_select", "lfdmi_get_timing",
     "lfdmi_timing_slots", "lfdmi_timing_name",
 )
 
@@ -120,6 +120,7 @@ def lib():
         _lib.lfdmi_bz2_fetch_many.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib.lfdmi_bz2_timings.argtypes = [C.c_void_p, C.c_void_p]
         _lib.lfdmi_bz2_frames.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]
+        _lib.lfdmi_bz2_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint64]
     return _lib
 
 
@@ -300,6 +301,10 @@ class Bz2Decoder:
         p = C.c_void_p()
         self._chk(self._lib.lfdmi_bz2_frames(self._h, int(which), C.c_uint64(int(n) * int(h) * int(w) * 4), C.byref(p)))
         return DeviceFrames(p.value, (n, h, w))
+
+    def reserve(self, n_files, n_blocks, out_cap, compressed_bytes=0):
+        """Allocate the decoder's tables now (optional; otherwise inside the first ``decode``)."""
+        self._chk(self._lib.lfdmi_bz2_reserve(self._h, int(n_files), int(n_blocks), C.c_uint64(int(out_cap)), C.c_uint64(int(compressed_bytes))))
 
     def timings(self):
         ms = np.zeros(5, np.float32)

@@ -69,6 +69,31 @@ static uint32_t gf_mul_host(uint32_t a, uint32_t b) {
     return r;
 }
 
+static int reserve_blocks(lfdmi_bz2 *z, size_t B) { // tables and scratch for B blocks in flight (contents are not kept)
+    if (B <= z->blocks_cap) return 0;
+    const size_t cap = B + B / 8 + 16;
+    BCHK(alloc_n(z->desc, cap)); BCHK(alloc_n(z->info, cap)); BCHK(alloc_n(z->Lbuf, cap * BZ_LSTRIDE));
+    BCHK(alloc_n(z->selbuf, cap * BZ_SEL_STRIDE)); BCHK(alloc_n(z->segbuf, cap * BZ_MAX_SPLIT * BZ_SEG_CAP)); BCHK(alloc_n(z->tt, cap * BZ_TSTRIDE)); BCHK(alloc_n(z->meta, cap * BZ_MAX_TILES * 1024));
+    BCHK(alloc_n(z->tile_fn, cap * BZ_MAX_TILES)); BCHK(alloc_n(z->tile_in, cap * BZ_MAX_TILES)); BCHK(alloc_n(z->blk_crc, cap));
+    BCHK(alloc_n(z->blk_size, cap)); BCHK(alloc_n(z->blk_off, cap));
+    z->blocks_cap = cap;
+    return 0;
+}
+
+// Allocates ahead of the first lfdmi_bz2_decode_batch what a batch of n_files files with n_blocks blocks in all, out_cap bytes of
+// output each, will need (tens of GB for a chunk of frames: half a second of hipMalloc that can run beside the first reads).
+extern "C" int lfdmi_bz2_reserve(lfdmi_bz2 *z, int n_files, int64_t n_blocks, uint64_t out_cap, uint64_t compressed_bytes) {
+    if (!z || n_files <= 0 || n_blocks < 0) return bfail(z, LFDMI_ERR_ARG, "lfdmi_bz2_reserve: bad argument");
+    BCHK(hipSetDevice(z->device));
+    size_t max_blocks = 4096;
+    if (const char *e = getenv("LFDMI_BZ2_MAX_BLOCKS")) max_blocks = (size_t)std::max(1, atoi(e));
+    { int rc_ = reserve_blocks(z, std::min((size_t)n_blocks, max_blocks)); if (rc_) return rc_; }
+    out_cap = (out_cap + 255) & ~(uint64_t)255;
+    BCHK(regrow(z->out, z->out_bytes, (size_t)n_files * out_cap + 256));
+    if (compressed_bytes) BCHK(regrow(z->comp, z->comp_words, (size_t)(compressed_bytes / 4) + (size_t)n_files * 128 + 64));
+    return 0;
+}
+
 extern "C" int lfdmi_bz2_create(int device, lfdmi_bz2 **out) {
     if (!out) return LFDMI_ERR_ARG;
     *out = nullptr;
@@ -228,14 +253,7 @@ extern "C" int lfdmi_bz2_decode_batch(lfdmi_bz2 *z, const void *src, const uint6
     }
     size_t Bmax = 0;
     for (size_t g = 0; g + 1 < gfirst.size(); g++) Bmax = std::max(Bmax, (size_t)(first[gfirst[g + 1]] - first[gfirst[g]]));
-    if (Bmax > z->blocks_cap) {
-        const size_t cap = Bmax + Bmax / 8 + 16;
-        BCHK(alloc_n(z->desc, cap)); BCHK(alloc_n(z->info, cap)); BCHK(alloc_n(z->Lbuf, cap * BZ_LSTRIDE));
-        BCHK(alloc_n(z->selbuf, cap * BZ_SEL_STRIDE)); BCHK(alloc_n(z->segbuf, cap * BZ_MAX_SPLIT * BZ_SEG_CAP)); BCHK(alloc_n(z->tt, cap * BZ_TSTRIDE)); BCHK(alloc_n(z->meta, cap * BZ_MAX_TILES * 1024));
-        BCHK(alloc_n(z->tile_fn, cap * BZ_MAX_TILES)); BCHK(alloc_n(z->tile_in, cap * BZ_MAX_TILES)); BCHK(alloc_n(z->blk_crc, cap));
-        BCHK(alloc_n(z->blk_size, cap)); BCHK(alloc_n(z->blk_off, cap));
-        z->blocks_cap = cap;
-    }
+    { int rc_ = reserve_blocks(z, Bmax); if (rc_) return rc_; }
     BCHK(regrow(z->out, z->out_bytes, (size_t)n * out_cap + 256));
     if (head_bytes) BCHK(regrow(z->heads, z->heads_bytes, (size_t)n * head_bytes));
     BCHK(hipMemcpyAsync(z->file_status, fstat.data(), n * sizeof(int), hipMemcpyHostToDevice, z->stream));

@@ -496,19 +496,32 @@ class DetectTrails:
             if not chunks:
                 return
             shape = _frame_shape(keys)
+            # chunks loading at once: one for plain files (the link is the limit), two for selections decompressed on the GPU (two
+            # decoders side by side: one chunk's Huffman stage overlaps the other's inverse BWT, loader.FrameLoader)
+            depth = max(1, min(int(os.environ.get("LFD_LOADER_DEPTH", 2 if compressed else 1)), len(chunks)))
             with use_context(*shape, inflight=slots) as ctx:
-                loader = FrameLoader(ctx, shape, slots, loader_threads)
+                loader = FrameLoader(ctx, shape, slots, loader_threads, depth=depth, expect_bz2=compressed)
             self.last_stats.update(chunk_frames=slots, setup_s=time.perf_counter() - t_start)
             try:
                 trace = os.environ.get("LFD_LOADER_TRACE") == "1"
-                with ThreadPoolExecutor(1, thread_name_prefix="lfd-chunk") as coord:
-                    nxt = coord.submit(loader.load, chunks[0], 0, chunks[1] if len(chunks) > 1 else None)
+                from collections import deque
+                with ThreadPoolExecutor(depth, thread_name_prefix="lfd-chunk") as coord:
+                    pending, nxt_i = deque(), 0
+
+                    def submit():
+                        nonlocal nxt_i
+                        j = nxt_i
+                        nxt_i += 1
+                        pending.append(coord.submit(loader.load, chunks[j], j % (depth + 1), chunks[j + 1] if j + 1 < len(chunks) else None, j))
+                    for _ in range(depth):
+                        submit()
                     for i, chunk in enumerate(chunks):
                         t0 = time.perf_counter()
-                        loaded = nxt.result()
+                        loaded = pending.popleft().result()
                         t1 = time.perf_counter()
-                        # (buffer (i + 1) & 1 held chunk i - 1, whose GPU call has returned: it is free to be refilled)
-                        nxt = coord.submit(loader.load, chunks[i + 1], (i + 1) & 1, chunks[i + 2] if i + 2 < len(chunks) else None) if i + 1 < len(chunks) else None
+                        # (chunk i sits in buffer i % (depth + 1); the loads in flight fill the other `depth` buffers)
+                        if nxt_i < len(chunks):
+                            submit()
                         process_loaded(results, errors, loaded, self.params_bright, self.params_dim, self.params_removestars)
                         mark(chunk)
                         self.last_stats["chunk_done_s"].append(time.perf_counter() - t_start)

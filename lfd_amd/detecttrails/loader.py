@@ -114,7 +114,7 @@ class Loaded:
 class FrameLoader:
     """``threads`` native reader threads, two pinned buffers of ``slots`` frames of ``shape`` (allocated through ``ctx``)."""
 
-    def __init__(self, ctx, shape, slots, threads=None, max_obj=MAX_OBJ):
+    def __init__(self, ctx, shape, slots, threads=None, max_obj=MAX_OBJ, depth=1, expect_bz2=False):
         self.shape = tuple(shape)
         self.slots = int(slots)
         self.max_obj = int(max_obj)
@@ -126,15 +126,20 @@ class FrameLoader:
         share = max(1, cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", 1))))
         self.threads = int(threads or os.environ.get("LFD_LOADER_THREADS", 0) or max(2, min(64, share)))
         self.lib = _native.lib()
-        self.pins = [ctx.pinned_buffer(self.slots * self.frame_bytes) for _ in range(2)]
+        # depth chunks can be loading at once while one more is being processed: depth + 1 sets of buffers.  depth = 2 is for
+        # selections that are decompressed on the GPU (two decoders: the Huffman stage of one chunk -- bound by the CUs' scalar
+        # units -- overlaps the inverse BWT of the previous one -- bound by HBM's random-access rate)
+        self.depth = max(1, int(depth))
+        self.nbuf = self.depth + 1
+        self.pins = [ctx.pinned_buffer(self.slots * self.frame_bytes) for _ in range(self.nbuf)]
         self.views = [p.array.view(">f4").reshape(self.slots, h, w) for p in self.pins]
         self.cats = []
-        for _ in range(2):
+        for _ in range(self.nbuf):
             c = {k: np.zeros((self.slots, self.max_obj, 5), np.float32) for k in _CAT5}
             c.update({k: np.zeros((self.slots, self.max_obj), np.int32) for k in _CAT1})
             c["count"] = np.zeros(self.slots, np.int32)
             self.cats.append(c)
-        self.hdrs = [np.zeros((self.slots, HDR_CAP), np.uint8) for _ in range(2)]
+        self.hdrs = [np.zeros((self.slots, HDR_CAP), np.uint8) for _ in range(self.nbuf)]
         # .bz2 frames and other exceptions to the fast path, one thread per usable core (libbz2 releases the interpreter lock).  A
         # chunk with at least as many .bz2 frames as threads decodes whole files, one per thread (nothing is cheaper per frame);
         # a smaller selection has the ~14 bzip2 blocks of each file decoded side by side (bz2blocks), so that one frame does not
@@ -150,25 +155,45 @@ class FrameLoader:
         self.bz2_out_cap = self.frame_bytes + int(os.environ.get("LFD_BZ2_EXTRA_MB", 4)) * (1 << 20)   # (a frame file = image + three small HDUs)
         self.bz2_keep_on_device = os.environ.get("LFD_BZ2_KEEP_ON_DEVICE", "1") != "0"   # 0: decoded frames travel to the pinned slots and back
         self.bz2_device_min = int(os.environ.get("LFD_BZ2_DEVICE_MIN", 8))   # fewer compressed frames in a chunk than this: the host decodes them
-        self._bz2 = None
-        self._bz2_pins = [None, None]                        # compressed bytes of a chunk: this chunk's, and the next one's being read ahead
-        self._bz2_ahead = None                               # (paths, sizes, offsets, futures, buffer index) of the read-ahead
+        import threading
+        self._lock = threading.Lock()
+        self._bz2s = [None] * self.depth                     # a decoder per chunk that can be loading at once
+        self._bz2_pins = [[None, None] for _ in range(self.depth)]   # per decoder: compressed bytes of its chunk, and of the one read ahead
+        self._bz2_aheads = [None] * self.depth               # (paths, sizes, offsets, futures, buffer index) of a decoder's read-ahead
         self.bz2_stats = {"device_frames": 0, "host_frames": 0, "decode_s": 0.0, "read_s": 0.0, "fetch_s": 0.0}
+        self._warm = [None] * self.depth
+        if expect_bz2 and self.bz2_device and self.slots >= self.bz2_device_min:
+            # the selection is known to be compressed: the decoders' tables (tens of GB each) are allocated while the first files are read
+            def warm(lane):
+                try:
+                    bz = _native.Bz2Decoder(self.ctx.device)
+                    blocks = self.slots * (self.frame_bytes // 900000 + 2)        # (900 kB blocks: the image's, the header's, the small HDUs')
+                    bz.reserve(self.slots, blocks, self.bz2_out_cap, self.slots * self.frame_bytes)
+                    self._bz2s[lane] = bz
+                except _native.NativeError:
+                    pass                                     # (the first decode tries again and reports)
+            for lane in range(self.depth):
+                self._warm[lane] = threading.Thread(target=warm, args=(lane,), daemon=True)
+                self._warm[lane].start()
 
     def close(self):
         self.pool.shutdown(wait=True)
         self.block_pool.shutdown(wait=True)
-        if self._bz2 is not None:
-            self._bz2.close()
-            self._bz2 = None
-        if self._bz2_ahead is not None:
-            for f in self._bz2_ahead[3]:
-                f.cancel() or f.exception()
-            self._bz2_ahead = None
-        for k, p in enumerate(self._bz2_pins):
-            if p is not None:
-                p.close()
-                self._bz2_pins[k] = None
+        for lane in range(self.depth):
+            if self._warm[lane] is not None:
+                self._warm[lane].join()
+                self._warm[lane] = None
+            if self._bz2_aheads[lane] is not None:
+                for f in self._bz2_aheads[lane][3]:
+                    f.cancel() or f.exception()
+                self._bz2_aheads[lane] = None
+            if self._bz2s[lane] is not None:
+                self._bz2s[lane].close()
+                self._bz2s[lane] = None
+            for k, p in enumerate(self._bz2_pins[lane]):
+                if p is not None:
+                    p.close()
+                    self._bz2_pins[lane][k] = None
         self.views = None
         for p in self.pins:
             p.close()
@@ -224,18 +249,18 @@ class FrameLoader:
         except Exception as e:  # noqa: BLE001 - this frame's errors.txt entry (detecttrails.py:133-139)
             out.error[i] = e
 
-    def _read_compressed(self, paths, pin_k):
+    def _read_compressed(self, paths, lane, pin_k):
         """Starts reading ``paths`` into compressed-bytes buffer ``pin_k`` on the loader's pool: (sizes, offsets, futures)."""
         sizes = [os.path.getsize(p) if os.path.exists(p) else 0 for p in paths]
         offs, cur = [], 0
         for z in sizes:
             offs.append(cur)
             cur += (z + 255) & ~255
-        pin = self._bz2_pins[pin_k]
+        pin = self._bz2_pins[lane][pin_k]
         if pin is None or pin.nbytes < cur:
             if pin is not None:
                 pin.close()
-            pin = self._bz2_pins[pin_k] = self.ctx.pinned_buffer(max(cur + cur // 4, 1 << 20))
+            pin = self._bz2_pins[lane][pin_k] = self.ctx.pinned_buffer(max(cur + cur // 4, 1 << 20))
         src = pin.array
 
         def read(k):
@@ -247,15 +272,19 @@ class FrameLoader:
                 return False
         return sizes, offs, [self.pool.submit(read, k) for k in range(len(paths))]
 
-    def _device_bz2(self, out, todo, raw, which, whole_chunk, next_paths=None):
+    def _device_bz2(self, out, todo, raw, lane, devbuf, whole_chunk, next_paths=None):
         """``todo``: [(i, slot, path + '.bz2')] frames of this chunk that exist only compressed.  Decompresses them on the GPU and
         puts each image's data unit into its pinned slot; returns the entries that still have to go the host way."""
         import time
         t0 = time.perf_counter()
         paths = [p for _, _, p in todo]
-        if self._bz2 is None:
-            self._bz2 = _native.Bz2Decoder(self.ctx.device)
-        ahead, self._bz2_ahead = self._bz2_ahead, None
+        if self._warm[lane] is not None:
+            self._warm[lane].join()
+            self._warm[lane] = None
+        if self._bz2s[lane] is None:
+            self._bz2s[lane] = _native.Bz2Decoder(self.ctx.device)
+        bz = self._bz2s[lane]
+        ahead, self._bz2_aheads[lane] = self._bz2_aheads[lane], None
         if ahead is not None and ahead[0] == paths:           # read while the previous chunk was being decoded
             _, sizes, offs, futs, pin_k = ahead
             ok_read = [f.result() for f in futs]
@@ -264,15 +293,15 @@ class FrameLoader:
                 for f in ahead[3]:
                     f.result()
             pin_k = 0 if ahead is None else ahead[4] ^ 1
-            sizes, offs, futs = self._read_compressed(paths, pin_k)
+            sizes, offs, futs = self._read_compressed(paths, lane, pin_k)
             ok_read = [f.result() for f in futs]
-        src = self._bz2_pins[pin_k].array
-        if next_paths:                                        # the next chunk's files: into the other buffer, while this chunk is on the GPU
-            s2, o2, f2 = self._read_compressed(next_paths, pin_k ^ 1)
-            self._bz2_ahead = (list(next_paths), s2, o2, f2, pin_k ^ 1)
+        src = self._bz2_pins[lane][pin_k].array
+        if next_paths and self.depth == 1:                    # the next chunk's files: into the other buffer, while this chunk is on the GPU
+            s2, o2, f2 = self._read_compressed(next_paths, lane, pin_k ^ 1)           # (depth 2: the next chunk is being loaded beside this one anyway)
+            self._bz2_aheads[lane] = (list(next_paths), s2, o2, f2, pin_k ^ 1)
         t1 = time.perf_counter()
         try:
-            out_len, status, heads = self._bz2.decode(src, offs, sizes, self.bz2_out_cap, HDR_CAP)
+            out_len, status, heads = bz.decode(src, offs, sizes, self.bz2_out_cap, HDR_CAP)
         except _native.NativeError as e:                     # e.g. no room for the decoder's tables on this device: the host's cores from now on
             import warnings
             warnings.warn(f"device bzip2 decoder switched off ({e}); .bz2 frames are decompressed on the host")
@@ -297,30 +326,31 @@ class FrameLoader:
         # for the host decoder or the general reader -- everything meets in the pinned slots as before.
         if whole_chunk and not rest and not whole and self.bz2_keep_on_device:
             h, w = self.shape
-            dev = self._bz2.frames(which, self.slots, h, w)
-            self._bz2.fetch_many(files, foff, fbytes, [dev.address_of(sl) for sl in slots_of])
+            dev = bz.frames(devbuf, self.slots, h, w)
+            bz.fetch_many(files, foff, fbytes, [dev.address_of(sl) for sl in slots_of])
             out.device = dev
             src_of = {sl: (k, e) for sl, k, e in zip(slots_of, files, foff)}
-            dec = self._bz2
+            dec = bz
 
             def fetch(slot, _src=src_of, _dec=dec, _fb=self.frame_bytes, _shape=self.shape):   # (only inside load(): the next decode reuses the files)
                 k, e = _src[slot]
                 return _dec.fetch(k, e, _fb).view(">f4").reshape(_shape)
             out.fetch = fetch
         else:
-            self._bz2.fetch_many(files, foff, fbytes, [raw[sl * self.frame_bytes:(sl + 1) * self.frame_bytes] for sl in slots_of])
+            bz.fetch_many(files, foff, fbytes, [raw[sl * self.frame_bytes:(sl + 1) * self.frame_bytes] for sl in slots_of])
         for k, i, slot, path in whole:
             try:
                 self._from_decompressed(out, i, slot, raw[slot * self.frame_bytes:(slot + 1) * self.frame_bytes],
-                                        self._bz2.fetch(k, 0, int(out_len[k])).tobytes(), path)
+                                        bz.fetch(k, 0, int(out_len[k])).tobytes(), path)
             except Exception as e:  # noqa: BLE001 - this frame's errors.txt entry (detecttrails.py:133-139)
                 out.error[i] = e
         t3 = time.perf_counter()
-        st = self.bz2_stats
-        st["device_frames"] += len(todo) - len(rest)
-        st["read_s"] += t1 - t0
-        st["decode_s"] += t2 - t1
-        st["fetch_s"] += t3 - t2
+        with self._lock:
+            st = self.bz2_stats
+            st["device_frames"] += len(todo) - len(rest)
+            st["read_s"] += t1 - t0
+            st["decode_s"] += t2 - t1
+            st["fetch_s"] += t3 - t2
         return rest
 
     def _slow_catalog(self, out, i, slot, cats, status, path):
@@ -360,7 +390,7 @@ class FrameLoader:
         return paths
 
     # -- a chunk --------------------------------------------------------------------------------------------------
-    def load(self, keys, which, next_keys=None):
+    def load(self, keys, which, next_keys=None, seq=None):
         """Read ``keys`` (at most ``slots``) into pinned buffer ``which`` (0 / 1).  Frames of one filter get neighbouring slots
         (remove_stars' magnitude cap depends on the filter, so a GPU call takes one filter's frames: a contiguous slice).
         ``next_keys``: the chunk that will be asked for next; if it exists only as .fits.bz2 its files are read ahead while
@@ -368,6 +398,8 @@ class FrameLoader:
         n = len(keys)
         if n > self.slots:
             raise ValueError("chunk larger than the loader's buffers")
+        seq = which if seq is None else int(seq)              # the chunk's number: which decoder, which of its device buffers
+        lane, devbuf = seq % self.depth, (seq // self.depth) % 2
         out = Loaded(keys)
         out.buffer = self.views[which]
         out.cats = cats = self.cats[which]
@@ -398,7 +430,7 @@ class FrameLoader:
             todo = [(i, slot, fpaths[slot] + ".bz2") for slot, i in enumerate(order)
                     if int(fstat[slot]) == -1 and not os.path.exists(fpaths[slot]) and os.path.exists(fpaths[slot] + ".bz2")]
             if len(todo) >= self.bz2_device_min:             # (a handful of files: their blocks side by side on the host's cores are quicker)
-                rest = self._device_bz2(out, todo, raw, which, len(todo) == n, self._compressed_only(next_keys))
+                rest = self._device_bz2(out, todo, raw, lane, devbuf, len(todo) == n, self._compressed_only(next_keys))
                 on_device = {i for i, _, _ in todo} - {i for i, _, _ in rest}
                 self.bz2_stats["host_frames"] += len(rest)
         self.split_blocks = int((fstat != 0).sum()) - len(on_device) < self.threads   # (few files for many cores: their blocks side by side)
