@@ -237,7 +237,7 @@ extern "C" int lfdmi_bz2_decode_batch(lfdmi_bz2 *z, const void *src, const uint6
         }
     }
     first[n] = (int)desc.size();
-    // ---- groups of whole files, each with at most max_blocks blocks in flight (12.6 MB of tables and scratch per block): the
+    // ---- groups of whole files, each with at most max_blocks blocks in flight (8.6 MB of tables and scratch per block): the
     // files of a chunk of SDSS frames are one group; what is larger (more files, level-1 files of 127 blocks) takes several passes
     size_t max_blocks = 4096;
     if (const char *e = getenv("LFDMI_BZ2_MAX_BLOCKS")) max_blocks = (size_t)std::max(1, atoi(e));
