@@ -245,7 +245,7 @@ def process_loaded(results, errors, loaded, params_bright, params_dim, params_re
         if j == len(slots) or slots[j] != slots[j - 1] + 1 or loaded.keys[by_slot[slots[j]]][2] != loaded.keys[by_slot[slots[start]]][2]:
             runs.append(slots[start:j])
             start = j
-    h, w = loaded.buffer.shape[1:] if loaded.buffer is not None else (0, 0)
+    h, w = loaded.shape if getattr(loaded, "shape", None) else (loaded.buffer.shape[1:] if loaded.buffer is not None else (0, 0))
     for run_slots in runs:
         idx = [by_slot[sl] for sl in run_slots]
         flt = loaded.keys[idx[0]][2]

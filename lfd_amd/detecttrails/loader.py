@@ -93,6 +93,7 @@ class Loaded:
         self.hdr = [None] * n
         self.cat = [None] * n
         self.buffer = None                                   # [slots, h, w] '>f4' view of the pinned memory
+        self.shape = None                                    # (h, w) of the chunk's frames
         self.device = None                                   # or: _native.DeviceFrames (the same slots in device memory: frames that
                                                              # were decompressed on the GPU and stayed there; ``buffer`` is then unused)
         self.fetch = None                                    # slot -> '>f4' (h, w) host copy of a device frame (valid while the chunk is loaded)
@@ -129,10 +130,14 @@ class FrameLoader:
         # depth chunks can be loading at once while one more is being processed: depth + 1 sets of buffers.  depth = 2 is for
         # selections that are decompressed on the GPU (two decoders: the Huffman stage of one chunk -- bound by the CUs' scalar
         # units -- overlaps the inverse BWT of the previous one -- bound by HBM's random-access rate)
+        self.ctx = ctx
         self.depth = max(1, int(depth))
         self.nbuf = self.depth + 1
-        self.pins = [ctx.pinned_buffer(self.slots * self.frame_bytes) for _ in range(self.nbuf)]
-        self.views = [p.array.view(">f4").reshape(self.slots, h, w) for p in self.pins]
+        self.pins = [None] * self.nbuf                       # page-locked chunk buffers, made when a chunk first needs one (a selection that
+        self.views = [None] * self.nbuf                      # is decompressed on the GPU and stays there never does)
+        if not expect_bz2:
+            for k in range(self.nbuf):
+                self._ensure(k)
         self.cats = []
         for _ in range(self.nbuf):
             c = {k: np.zeros((self.slots, self.max_obj, 5), np.float32) for k in _CAT5}
@@ -176,6 +181,14 @@ class FrameLoader:
                 self._warm[lane] = threading.Thread(target=warm, args=(lane,), daemon=True)
                 self._warm[lane].start()
 
+    def _ensure(self, which):
+        """Chunk buffer ``which`` as (uint8 array, '>f4' [slots, h, w] view)."""
+        if self.pins[which] is None:
+            h, w = self.shape
+            self.pins[which] = self.ctx.pinned_buffer(self.slots * self.frame_bytes)
+            self.views[which] = self.pins[which].array.view(">f4").reshape(self.slots, h, w)
+        return self.pins[which].array, self.views[which]
+
     def close(self):
         self.pool.shutdown(wait=True)
         self.block_pool.shutdown(wait=True)
@@ -196,7 +209,8 @@ class FrameLoader:
                     self._bz2_pins[lane][k] = None
         self.views = None
         for p in self.pins:
-            p.close()
+            if p is not None:
+                p.close()
         self.pins = []
 
     def __enter__(self):
@@ -272,7 +286,7 @@ class FrameLoader:
                 return False
         return sizes, offs, [self.pool.submit(read, k) for k in range(len(paths))]
 
-    def _device_bz2(self, out, todo, raw, lane, devbuf, whole_chunk, next_paths=None):
+    def _device_bz2(self, out, todo, which, lane, devbuf, whole_chunk, next_paths=None):
         """``todo``: [(i, slot, path + '.bz2')] frames of this chunk that exist only compressed.  Decompresses them on the GPU and
         puts each image's data unit into its pinned slot; returns the entries that still have to go the host way."""
         import time
@@ -337,9 +351,11 @@ class FrameLoader:
                 return _dec.fetch(k, e, _fb).view(">f4").reshape(_shape)
             out.fetch = fetch
         else:
+            raw, out.buffer = self._ensure(which)
             bz.fetch_many(files, foff, fbytes, [raw[sl * self.frame_bytes:(sl + 1) * self.frame_bytes] for sl in slots_of])
         for k, i, slot, path in whole:
             try:
+                raw, out.buffer = self._ensure(which)
                 self._from_decompressed(out, i, slot, raw[slot * self.frame_bytes:(slot + 1) * self.frame_bytes],
                                         bz.fetch(k, 0, int(out_len[k])).tobytes(), path)
             except Exception as e:  # noqa: BLE001 - this frame's errors.txt entry (detecttrails.py:133-139)
@@ -401,9 +417,8 @@ class FrameLoader:
         seq = which if seq is None else int(seq)              # the chunk's number: which decoder, which of its device buffers
         lane, devbuf = seq % self.depth, (seq // self.depth) % 2
         out = Loaded(keys)
-        out.buffer = self.views[which]
+        out.shape = self.shape
         out.cats = cats = self.cats[which]
-        raw = self.pins[which].array
         hdrs = self.hdrs[which]
         order = sorted(range(n), key=lambda i: keys[i][2])          # stable: the caller's order inside a filter
         fpaths, ppaths = [], []
@@ -416,9 +431,13 @@ class FrameLoader:
         hlen = np.zeros(n, np.int32)
         pstat = np.zeros(n, np.int32)
         P = _native._ptr
-        rc = self.lib.lfdmi_fits_read_frames(_paths(fpaths), n, h, w, P(raw), self.threads, P(fstat), P(hdrs), HDR_CAP, P(hlen))
-        if rc:
-            raise _native.NativeError(rc, "lfdmi_fits_read_frames")
+        if self._compressed_only(keys) is not None:
+            fstat[:] = -1                                     # no plain file among them: nothing for the native reader, and no chunk buffer yet
+        else:
+            raw, out.buffer = self._ensure(which)
+            rc = self.lib.lfdmi_fits_read_frames(_paths(fpaths), n, h, w, P(raw), self.threads, P(fstat), P(hdrs), HDR_CAP, P(hlen))
+            if rc:
+                raise _native.NativeError(rc, "lfdmi_fits_read_frames")
         rc = self.lib.lfdmi_fits_read_photoobj(_paths(ppaths), n, self.max_obj, P(cats["ROWC"]), P(cats["COLC"]), P(cats["PSFMAG"]),
                                                P(cats["PETROTH90"]), P(cats["NOBSERVE"]), P(cats["NDETECT"]), P(cats["count"]),
                                                self.threads, P(pstat))
@@ -430,7 +449,7 @@ class FrameLoader:
             todo = [(i, slot, fpaths[slot] + ".bz2") for slot, i in enumerate(order)
                     if int(fstat[slot]) == -1 and not os.path.exists(fpaths[slot]) and os.path.exists(fpaths[slot] + ".bz2")]
             if len(todo) >= self.bz2_device_min:             # (a handful of files: their blocks side by side on the host's cores are quicker)
-                rest = self._device_bz2(out, todo, raw, lane, devbuf, len(todo) == n, self._compressed_only(next_keys))
+                rest = self._device_bz2(out, todo, which, lane, devbuf, len(todo) == n, self._compressed_only(next_keys))
                 on_device = {i for i, _, _ in todo} - {i for i, _, _ in rest}
                 self.bz2_stats["host_frames"] += len(rest)
         self.split_blocks = int((fstat != 0).sum()) - len(on_device) < self.threads   # (few files for many cores: their blocks side by side)
@@ -446,6 +465,7 @@ class FrameLoader:
                     with open(fpaths[slot], "rb") as f:
                         out.hdr[i] = f.read(int(hlen[slot]))
             else:
+                raw, out.buffer = self._ensure(which)
                 dst = raw[slot * self.frame_bytes:(slot + 1) * self.frame_bytes]
                 futs.append(self.pool.submit(self._slow_frame, out, i, slot, dst, st))
         for f in futs:
