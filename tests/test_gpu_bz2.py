@@ -243,3 +243,33 @@ def test_a_chunk_of_compressed_frames_stays_on_the_device(tmp_path, monkeypatch,
         assert dt.last_stats["bz2"]["device_frames"] == n
     assert seen == [True, False]
     assert rows["1"] == want and rows["0"] == want
+
+
+def test_two_chunks_loading_at_once_over_compressed_mixed_and_plain_chunks(tmp_path, monkeypatch, oracle):
+    """LFD_LOADER_DEPTH=2 (two decoders, three sets of chunk buffers): a selection whose chunks are all-compressed (stay on the device),
+    mixed (meet in the pinned slots) and all-plain, in that order and back; rows equal the oracle's, in the selection's order."""
+    from lfd_amd import results, synth
+    from lfd_amd.detecttrails import DetectTrails, default_params, fitslite, sdssfiles
+    shape, n = (512, 768), 40
+    frames, cats = [], []
+    for k in range(n):
+        img, cat, _ = synth.make_portable_frame(k % 12, shape)
+        frames.append(img)
+        cats.append(cat)
+    compressed = set(range(100, 110)) | {112, 113, 114, 115, 116, 118} | set(range(130, 140))   # chunks: all, mixed, none, all
+    hdr = synth.write_boss_tree(tmp_path, frames, cats, field0=100, bz2_fields=compressed)
+    pb, pd, prs = default_params()
+    rs = oracle.rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
+    want = []
+    for k in range(n):
+        rec = oracle.detect_frame(frames[k].copy(), pb, pd, cats[k], rs)
+        if rec["found"]:
+            want.append(results.format_result_row(94, 1, "r", 100 + k, hdr, rec))
+    assert len(want) >= 10
+    monkeypatch.setenv("LFD_BZ2_DEVICE_MIN", "4")
+    monkeypatch.setenv("LFD_LOADER_DEPTH", "2")
+    dt = DetectTrails(run=94, camcol=1, filter="r", savepath=str(tmp_path))
+    dt.process(batch=10)
+    assert [ln.strip() for ln in open(dt.results) if ln.strip()] == want
+    assert open(dt.errors).read() == ""
+    assert dt.last_stats["bz2"]["device_frames"] == 26 and dt.last_stats["bz2"]["host_frames"] == 0
