@@ -2,16 +2,20 @@
 // frame-*.fits.bz2; the reference decompresses every one with `bunzip2` before it reads it, detecttrails.py:81-109, at ~0.4 s
 // per frame and core).  A frame is ~14 independent blocks of 900 kB; a chunk of 256 frames is ~3 600 blocks.
 //
-//   k_bz2_magics   every 48-bit block / end-of-stream magic of every file, at any bit offset        (bandwidth, trivial)
-//   k_bz2_huff     a WAVE per block: header, coding tables, Huffman + RUNA/RUNB + move-to-front     (sequential per block: a
-//                  -> the block's BWT column L                                                        chain of LDS look-ups)
-//   k_bz2_sort     a workgroup per block: stable counting sort of L -> tt[q] = (T[q] << 8) | byte    (LDS histograms)
-//   k_bz2_walk     inverse BWT as list ranking: ~3 500 splitters per block walk to the next          (random 4-byte loads:
-//                  splitter, one thread ranks the splitters, the walks are repeated writing bytes     HBM / L2 latency)
-//   k_bz2_rle_scan the run-length layer (4 equal bytes + count): per-thread parse under both          (LDS scan)
-//                  possible entry states, composed by a scan -> output offset of every thread
-//   k_bz2_offsets  output offset of every block inside its file
-//   k_bz2_expand   writes the file's bytes, CRC of every block (per-thread CRCs combined with x^(8 len) mod P)
+//   k_bz2_magics     every 48-bit block / end-of-stream magic of every file, at any bit offset      (bandwidth, trivial)
+//   k_bz2_huff       a WAVE per block: header, coding tables, Huffman + RUNA/RUNB + move-to-front   (one wave, 900 000 symbols one
+//                    -> the block's BWT column L                                                      after the other: bound by the
+//                                                                                                     CU's scalar ALU at 14 waves)
+//   k_bz2_sort       a workgroup per block: stable counting sort of L -> tt[q] = (T[q] << 8) | byte  (LDS histograms, ballots)
+//   k_bz2_walk       inverse BWT as list ranking: ~3 500 splitters per block walk to the next        (random 4-byte loads: HBM's
+//                    splitter leaving their bytes in scratch, one thread orders the splitters,        random-access rate)
+//                    the scratch stretches are copied to their places
+//   k_bz2_rle_tiles  the run-length layer (4 equal bytes + count) in 32 kB tiles: every ~32-byte     (LDS scan)
+//   k_bz2_rle_blocks stretch parsed under both possible entry states, the functions composed by a
+//                    scan inside the tile, tile by tile inside the block
+//   k_bz2_offsets    output offset of every block inside its file
+//   k_bz2_expand     writes the file's bytes through an LDS window; every stretch's share of its block's CRC
+//   k_bz2_crc_check  (moved to the block's end with x^(8 len) mod P, xor-ed) against the stored one
 // All integer / byte work: bit-exact by construction, and every block's stored CRC is checked on the device.
 #pragma once
 #include "common.h"
