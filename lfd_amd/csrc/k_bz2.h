@@ -187,18 +187,25 @@ __device__ __forceinline__ int bz_dev_symbols(BzDevIO &io, const uint32_t *w, ui
         bool done = false;
         for (;;) { // stretches of ordinary symbols, an exception between two of them (errors are collected in `bad`, looked at once per window)
             uint32_t e;
-            const int gp0 = group_pos;
+            // position in the window and symbols left under this table in ONE register: bits 0 .. 7 = pos (a code is at most 9 bits
+            // here: < 73), bits 8 .. 14 = 64 - group_pos; every ordinary symbol adds its length + 256, and the loop is over when pos
+            // reaches 64 (bit 6) or the count reaches 64 (bit 14)
+            uint32_t key = (uint32_t)pos | ((uint32_t)(64 - group_pos) << 8);
             for (;;) { // the ordinary symbols: nothing in here touches what the exceptions change (run state, thr, flushed, cnt)
-                e = (uint32_t)__builtin_amdgcn_readlane((int)ev, pos);
+                e = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)(key & 63u));
                 const int nn = (int)(e >> 4);
                 if (__builtin_expect((uint32_t)(nn - 1) >= thr, 0)) break;
-                pos += (int)(e & 15u);
+                key += (e & 15u) + 256u;
                 io.symbol(nn, (int)(e >> 6)); // (a block that grows beyond its level's size is caught when a buffer is flushed)
-                group_pos--;
-                if (((group_pos - 1) | (63 - pos)) < 0) break; // the table's 50 symbols are used up, or the window is
+                if (key & 0x40c0u) break; // the table's 50 symbols are used up, or the window is
             }
-            io.cnt += gp0 - group_pos; // one byte per ordinary symbol
-            if (((group_pos - 1) | (63 - pos)) < 0) break; // (which of the two exits it was: this one cannot hold when an exception ended the loop)
+            pos = (int)(key & 0xffu);
+            {
+                const int left = 64 - (int)((key >> 8) & 0x7fu);
+                io.cnt += group_pos - left; // one byte per ordinary symbol
+                group_pos = left;
+            }
+            if (key & 0x40c0u) break; // (which of the two exits it was: this one cannot hold when an exception ended the loop)
             // the exceptions, all behind that one test: a code longer than the look-up covers (e = 0), RUNA / RUNB, the end-of-block
             // symbol, and any symbol while a run is being collected (thr = 0 then)
             int sym = (int)(((e >> 4) + 1u) & 0x1ffu);
