@@ -273,3 +273,27 @@ def test_two_chunks_loading_at_once_over_compressed_mixed_and_plain_chunks(tmp_p
     assert [ln.strip() for ln in open(dt.results) if ln.strip()] == want
     assert open(dt.errors).read() == ""
     assert dt.last_stats["bz2"]["device_frames"] == 26 and dt.last_stats["bz2"]["host_frames"] == 0
+
+
+def test_files_written_by_the_bzip2_program(tmp_path):
+    """The reference's own tool chain: files compressed by the `bzip2` program (as SDSS serves them) and what `bunzip2` makes of them
+    (detecttrails.py:88-109 runs exactly that), single files and `bzip2 -c a b`."""
+    import shutil
+    import subprocess
+    from lfd_amd import _native as Nv
+    if shutil.which("bzip2") is None or shutil.which("bunzip2") is None:
+        pytest.skip("no bzip2 program")
+    plains = _plains()
+    a, b = tmp_path / "a.fits", tmp_path / "b.fits"
+    a.write_bytes(plains["fits"])
+    b.write_bytes(plains["sky"])
+    blobs = [subprocess.run(["bzip2", "-9", "-c", str(a)], check=True, capture_output=True).stdout,
+             subprocess.run(["bzip2", "-1", "-c", str(b)], check=True, capture_output=True).stdout,
+             subprocess.run(["bzip2", "-c", str(a), str(b)], check=True, capture_output=True).stdout]
+    want = [subprocess.run(["bunzip2", "-c"], input=x, check=True, capture_output=True).stdout for x in blobs]
+    assert want[0] == plains["fits"] and want[2] == plains["fits"] + plains["sky"]
+    src, off, ln = _pack(blobs)
+    with Nv.Bz2Decoder(0) as z:
+        out_len, status, _ = z.decode(src, off, ln, 8 << 20)
+        for i in range(3):
+            assert status[i] == 0 and z.fetch(i, 0, int(out_len[i])).tobytes() == want[i], i
