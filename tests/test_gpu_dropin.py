@@ -178,3 +178,21 @@ def test_jobs_two_workers_equal_one_process(tmp_path, oracle):
     assert got == want == [l.strip() for l in open(dt.results) if l.strip()]
     assert open(errors).read() == open(dt.errors).read() != ""
     assert not os.path.exists(results + ".rank0") and not os.path.exists(results + ".rank1")
+
+
+def test_jobs_resume_continues_where_a_launch_stopped(tmp_path, oracle):
+    """A launch that died after worker 0 had finished (its results.rank0 and progress file are there, worker 1 never ran):
+    ``launch(resume=True)`` lets worker 0 skip its block, runs worker 1's, and the joined file is the complete one."""
+    from lfd_amd.detecttrails import DetectTrails
+    from lfd_amd.jobs import Jobs
+    fields = list(range(0, 9))
+    truth = build_tree(tmp_path, fields)
+    want = expected_rows(oracle, truth, skip={fields[2]})
+    out = tmp_path / "out"
+    out.mkdir()
+    dt = DetectTrails(run=94, camcol=1, filter="r", savepath=str(out))
+    dt.process(batch=4, rank=0, world_size=2)                          # what worker 0 of the interrupted launch left behind
+    assert os.path.exists(dt.results + ".rank0") and not os.path.exists(dt.results + ".rank1")
+    results, errors = Jobs(2, devices=[0, 0], run=94, camcol=1, filter="r", savepath=str(out)).launch(batch=4, resume=True, timeout=600)
+    assert [l.strip() for l in open(results) if l.strip()] == want
+    assert open(errors).read().count("\n\n") == 1
