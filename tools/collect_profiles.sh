@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence bench.py's roofline refers to (run on the GPU box through gpurun; results under gpurun_out/<tag>/):
 #   bench lines, kernel trace + stats of the profiled command, FETCH_SIZE / WRITE_SIZE passes, four SQ / GRBM counter passes
 #   (all separate, --kernel-trace only), for the sdss and the lsst workload; tools/make_traffic.py and tools/make_util.py turn them
-#   into <tag>_traffic_<w>.json and <tag>_util_<w>.json.  The program follows `--` directly (no env / sh wrappers: the profiler's
+#   into <tag>_traffic_<w>.json and <tag>_util_<w>.json; with `both`, tools/bz2_counters.sh follows (-> gpurun_out/<tag>bz2/).  The program follows `--` directly (no env / sh wrappers: the profiler's
 #   preloaded library has initialised the GPU by then).  usage: collect_profiles.sh <tag> [sdss|lsst|both]
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -31,4 +31,6 @@ for w in sdss lsst; do
   # keep what is committed small: drop the raw per-dispatch traces
   rm -rf $O/kt_$w $O/pmc_fetch_$w $O/pmc_write_$w $O/pmc_a_$w $O/pmc_b_$w $O/pmc_c_$w $O/pmc_d_$w
 done
+# the device bzip2 decoder's kernels (its own translation unit): rocprofv3 averages + SQ counters -> gpurun_out/${R}bz2/
+if [ "$WHICH" = both ]; then bash tools/bz2_counters.sh ${R}bz2 > $O/bz2_counters.log 2>&1 || echo "bz2 counters failed"; fi
 ls -la $O
