@@ -113,7 +113,7 @@ struct lfdmi_ctx {
     bool rs_fold_on = true;            // LFDMI_RS_FOLD=0: lfdmi_detect_batch zero-fills remove_stars' squares before the sweep instead of masking them in it
     bool rs_fold = false;              // (this chunk: the sweep masks the squares of rs_boxes; rs_count_dev / rs_max_obj describe them)
     const int *rs_count_dev = nullptr; int rs_max_obj = 0;
-    int rs_fill_at = 3;                // LFDMI_RS_FILL_AT: where the deferred zero fill of device-resident frames is enqueued: 3 = before k_frame_fg
+    int rs_fill_at = 13;               // LFDMI_RS_FILL_AT: where the deferred zero fill of device-resident frames is enqueued: 10 x pass + stage; 13 = before the DIM pass's k_frame_fg (3: the bright pass's)
                                        // (round 4: k_frame_contours alone, point 4, has become shorter than the fill, whose tail then hit the rectangle kernels)
     float *rs_fill_frames = nullptr;   // (pending deferred fill: frames, nc, h, w)
     int rs_fill_nc = 0, rs_fill_h = 0, rs_fill_w = 0;
