@@ -63,8 +63,8 @@ k_rs_boxes(int h, int w, int max_obj, const int *count, const float *rowc, const
 }
 
 __global__ void __launch_bounds__(256)
-k_rs_fill(float *frames, int h, int w, int max_obj, const int *count, const int4 *boxes) {
-    int f = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+k_rs_fill(float *frames, int h, int w, int max_obj, const int *count, const int4 *boxes, int bx0) { // bx0: first block of objects (the fill can be launched in parts)
+    int f = blockIdx.y, i = (blockIdx.x + bx0) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= max_obj) return;
     const int4 bx = boxes[(size_t)f * max_obj + i]; // (one address per wave: a broadcast load)
     const int r0 = __builtin_amdgcn_readfirstlane(bx.x), r1 = __builtin_amdgcn_readfirstlane(bx.y);

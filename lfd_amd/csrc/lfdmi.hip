@@ -115,6 +115,7 @@ struct lfdmi_ctx {
     const int *rs_count_dev = nullptr; int rs_max_obj = 0;
     int rs_fill_at = 13;               // LFDMI_RS_FILL_AT: where the deferred zero fill of device-resident frames is enqueued: 10 x pass + stage; 13 = before the DIM pass's k_frame_fg (3: the bright pass's)
                                        // (round 4: k_frame_contours alone, point 4, has become shorter than the fill, whose tail then hit the rectangle kernels)
+    int rs_fill_at0 = 3, rs_fill_part = 0;  // LFDMI_RS_FILL_AT0: an earlier point for the first half of the objects (3: the bright pass's k_frame_fg; -1: one launch)
     float *rs_fill_frames = nullptr;   // (pending deferred fill: frames, nc, h, w)
     int rs_fill_nc = 0, rs_fill_h = 0, rs_fill_w = 0;
     hipEvent_t ev_rsfill = nullptr;
@@ -423,6 +424,7 @@ static int create_impl(int device, int max_h, int max_w, int max_inflight, const
     if (const char *e = getenv("LFDMI_SCAN_SPIN")) ctx->scan_spin = std::max(0, atoi(e));
     if (const char *e = getenv("LFDMI_SCAN_EPOCH0")) ctx->scan_epoch = atoi(e) & ((1 << 22) - 1); // (tests: start next to the 22-bit wrap)
     if (const char *e = getenv("LFDMI_RS_FILL_AT")) ctx->rs_fill_at = atoi(e);
+    if (const char *e = getenv("LFDMI_RS_FILL_AT0")) ctx->rs_fill_at0 = atoi(e);
     if (const char *e = getenv("LFDMI_PERM")) ctx->use_perm = atoi(e) != 0;
     RET(dmalloc(ctx, &ctx->fb_fg, G));
     RET(dmalloc(ctx, &ctx->fg_keys, G));
@@ -770,11 +772,15 @@ static int sync(lfdmi_ctx *ctx, int nc = 0, const int *n_act = nullptr, const in
 // side[1], started at stage k of the bright pass (LFDMI_RS_FILL_AT; -1: whatever is still pending), joined before the
 // chunk's results are fetched.  It is 0.63 GB of partial-line stores and next to no instructions.
 static int rs_fill_point(lfdmi_ctx *ctx, int k) {
-    if (!ctx->rs_fill_frames || (k >= 0 && k != ctx->rs_fill_at)) return 0;
+    if (!ctx->rs_fill_frames) return 0;
+    // the fill can go in two parts (half of the objects each) at two points of the step: rs_fill_at0 (first half; -1: no split) and
+    // rs_fill_at (the rest); k < 0: whatever is still pending
+    const bool first = k >= 0 && k == ctx->rs_fill_at0 && ctx->rs_fill_part == 0 && !ctx->rs_sorted;
+    const bool rest = k < 0 || k == ctx->rs_fill_at;
+    if (!first && !rest) return 0;
     float *fr = ctx->rs_fill_frames;
     static const int side_i = getenv("LFDMI_RS_FILL_SIDE") ? (atoi(getenv("LFDMI_RS_FILL_SIDE")) & 1) : 1; // developer
     hipStream_t sd = ctx->side[side_i];
-    ctx->rs_fill_frames = nullptr;
     HIPCHK(hipEventRecord(ctx->ev_rsfill, ctx->stream));
     HIPCHK(hipStreamWaitEvent(sd, ctx->ev_rsfill, 0));
     {
@@ -782,13 +788,20 @@ static int rs_fill_point(lfdmi_ctx *ctx, int k) {
         if (ctx->rs_sorted)
             k_rs_fill_bands<<<dim3((ctx->rs_fill_h + RS_BAND_ROWS - 1) / RS_BAND_ROWS, ctx->rs_fill_nc), 256, 0, sd>>>(
                 fr, ctx->rs_fill_h, ctx->rs_fill_w, ctx->rs_max_obj, ctx->rs_sboxes, ctx->rs_rowstart, ctx->rs_hmax);
-        else
-            k_rs_fill<<<dim3((ctx->rs_max_obj + 3) / 4, ctx->rs_fill_nc), 256, 0, sd>>>(fr, ctx->rs_fill_h, ctx->rs_fill_w, ctx->rs_max_obj,
-                                                                                            ctx->rs_count_dev, ctx->rs_boxes);
+        else {
+            static const double frac = getenv("LFDMI_RS_FILL_FRAC") ? atof(getenv("LFDMI_RS_FILL_FRAC")) : 0.5; // developer: the first part's share of the objects
+            const int nblk = (ctx->rs_max_obj + 3) / 4, half = std::max(0, std::min(nblk, (int)(nblk * frac)));
+            const int b0 = ctx->rs_fill_part ? half : 0, b1 = first ? half : nblk;
+            if (b1 > b0)
+                k_rs_fill<<<dim3(b1 - b0, ctx->rs_fill_nc), 256, 0, sd>>>(fr, ctx->rs_fill_h, ctx->rs_fill_w, ctx->rs_max_obj,
+                                                                          ctx->rs_count_dev, ctx->rs_boxes, b0);
+        }
         KCHK("k_rs_fill");
     }
     HIPCHK(hipEventRecord(ctx->ev_rsfill, sd));
     ctx->rs_fill_inflight = true;
+    if (first) ctx->rs_fill_part = 1;
+    else { ctx->rs_fill_frames = nullptr; ctx->rs_fill_part = 0; }
     return 0;
 }
 
@@ -1880,7 +1893,7 @@ static int run_removestars(lfdmi_ctx *ctx, float *frames_dev, int f0, int nc, in
                 k_rs_fill_bands<<<dim3((h + RS_BAND_ROWS - 1) / RS_BAND_ROWS, nc), 256, 0, ctx->stream>>>(frames_dev, h, w, cat->max_obj, ctx->rs_sboxes,
                                                                                                      ctx->rs_rowstart, ctx->rs_hmax);
             else
-                k_rs_fill<<<dim3((cat->max_obj + 3) / 4, nc), 256, 0, ctx->stream>>>(frames_dev, h, w, cat->max_obj, dev.count, boxes);
+                k_rs_fill<<<dim3((cat->max_obj + 3) / 4, nc), 256, 0, ctx->stream>>>(frames_dev, h, w, cat->max_obj, dev.count, boxes, 0);
             KCHK("k_rs_fill");
         }
     }
@@ -2424,12 +2437,12 @@ static int detect_impl(lfdmi_ctx *ctx, void *frames_v, int dtype, int n, int h, 
             lfdmi_ctx *c;
             ~FoldState() {
                 if (c->rs_fill_inflight) { (void)hipStreamSynchronize(c->side[0]); (void)hipStreamSynchronize(c->side[1]); c->rs_fill_inflight = false; }
-                c->rs_fold = false; c->rs_fill_frames = nullptr;
+                c->rs_fold = false; c->rs_fill_frames = nullptr; c->rs_fill_part = 0;
             }
         } fold_guard{ctx};
         if (cat) {
             RET(run_removestars(ctx, (float *)d, cat_f0 + c0, nc, h, w, cat, rs, host_blot ? &boxes : nullptr, !ctx->rs_fold));
-            if (ctx->rs_fold && loc == LFDMI_DEVICE) { ctx->rs_fill_frames = (float *)d; ctx->rs_fill_nc = nc; ctx->rs_fill_h = h; ctx->rs_fill_w = w; }
+            if (ctx->rs_fold && loc == LFDMI_DEVICE) { ctx->rs_fill_frames = (float *)d; ctx->rs_fill_part = 0; ctx->rs_fill_nc = nc; ctx->rs_fill_h = h; ctx->rs_fill_w = w; }
             if (copy_back) RET(out_copy(ctx, frames, (size_t)c0 * N * 4, d, (size_t)nc * N * 4, loc));
             if (host_blot) {
                 double t0_ = feed && getenv("LFDMI_FEED_TRACE") ? feed_now() : 0;
