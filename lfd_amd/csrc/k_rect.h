@@ -597,7 +597,9 @@ __device__ __forceinline__ void wave_edges(const int2 *P, float *E, int n) {
 
 __global__ void __launch_bounds__(64)
 k_rects_big(const int4 *keys, const int *bigkeys, int cidx, const int2 *rowext, int *quads, int *counters, int h, int w,
-            int key_cap, int slot_cap, int cap, double minLen, double lwTresh, const int *active, int wave_prep) {
+            int key_cap, int slot_cap, int cap, double minLen, double lwTresh, const int *active, int wave_prep, int ext_lo, int skip_above) {
+    // (ext_lo, skip_above: the tall keys go in two launches over the same list -- up to `cap` rows with a small LDS footprint and
+    // many workgroups per CU, the few taller ones with the full-height footprint -- each skipping the other's keys)
     int g = blockIdx.y;
     if (slot_off(active, counters, g)) return;
     extern __shared__ int2 lds_pts[]; // 4 x cap
@@ -609,7 +611,8 @@ k_rects_big(const int4 *keys, const int *bigkeys, int cidx, const int2 *rowext, 
     for (int bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
         int4 key = kg[bigkeys[(size_t)g * key_cap + bi]];
         int extent = key.y & ~KEY_HOLE_BIT, ymin = key.z, base = key.w;
-        if (extent > cap) { if (lane == 0) cnt[C_OVERFLOW] = 1; continue; }
+        if (extent <= ext_lo) continue;
+        if (extent > cap) { if (!skip_above && lane == 0) cnt[C_OVERFLOW] = 1; continue; }
         int2 *P0 = lds_pts, *P1 = lds_pts + cap, *P2 = lds_pts + 2 * cap, *P3 = lds_pts + 3 * cap;
         __syncthreads();
         // the key's rows into P3 first, eight loads per lane in flight (a tall key is 24 rounds of 64 rows; one dependent

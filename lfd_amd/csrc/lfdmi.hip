@@ -1184,10 +1184,10 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     if (!rects_side) { // all three on the launch stream, one after the other (to see what the side streams buy)
         k_rects_big<<<dim3(med_grid, nc), 64, (size_t)BIG_KEY_ROWS * 4 * sizeof(int2), ctx->stream>>>(
             ctx->keys, ctx->medkeys, C_NMED, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, BIG_KEY_ROWS,
-            minLen, lwTresh, active, wave_prep);
+            minLen, lwTresh, active, wave_prep, 0, 0);
         k_rects_big<<<dim3(big_grid, nc), 64, (size_t)cap * 4 * sizeof(int2), ctx->stream>>>(
             ctx->keys, ctx->bigkeys, C_NBIG, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, cap,
-            minLen, lwTresh, active, wave_prep);
+            minLen, lwTresh, active, wave_prep, 0, 0);
         k_rects<<<dim3(rects_grid, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, nullptr, ctx->quads, ctx->counters, h, w,
                                                         ctx->key_cap, ctx->slot_cap, minLen, lwTresh, active);
         KCHK("k_rects");
@@ -1196,13 +1196,25 @@ static int run_rects(lfdmi_ctx *ctx, int nc, int h, int w, int mode, int method,
     HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0));
     k_rects_big<<<dim3(med_grid, nc), 64, (size_t)BIG_KEY_ROWS * 4 * sizeof(int2), ctx->side[0]>>>(
         ctx->keys, ctx->medkeys, C_NMED, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, BIG_KEY_ROWS,
-        minLen, lwTresh, active, wave_prep);
+        minLen, lwTresh, active, wave_prep, 0, 0);
     KCHK("k_rects_med");
     HIPCHK(hipEventRecord(ctx->ev_join[0], ctx->side[0]));
     HIPCHK(hipStreamWaitEvent(ctx->side[1], ctx->ev_fork, 0));
+    // the tall keys (more than BIG_KEY_ROWS rows) in two launches over one list: the few that are taller than tall_mid rows with the
+    // full-height LDS footprint (48 KB for one wave: three per CU), the others with a tenth of it and four times the workgroups
+    static const int tall_mid = getenv("LFDMI_RECTS_TALL_MID") ? std::max(0, atoi(getenv("LFDMI_RECTS_TALL_MID"))) : 320; // (0: one launch)
+    static const int tall_grid = getenv("LFDMI_RECTS_TALL_GRID") ? std::max(1, atoi(getenv("LFDMI_RECTS_TALL_GRID"))) : 32;
+    if (tall_mid > BIG_KEY_ROWS && tall_mid < cap) {
+        k_rects_big<<<dim3(big_grid, nc), 64, (size_t)cap * 4 * sizeof(int2), ctx->side[1]>>>(
+            ctx->keys, ctx->bigkeys, C_NBIG, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, cap,
+            minLen, lwTresh, active, wave_prep, tall_mid, 0);
+        k_rects_big<<<dim3(tall_grid, nc), 64, (size_t)tall_mid * 4 * sizeof(int2), ctx->side[1]>>>(
+            ctx->keys, ctx->bigkeys, C_NBIG, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, tall_mid,
+            minLen, lwTresh, active, wave_prep, 0, 1);
+    } else
     k_rects_big<<<dim3(big_grid, nc), 64, (size_t)cap * 4 * sizeof(int2), ctx->side[1]>>>(
         ctx->keys, ctx->bigkeys, C_NBIG, ctx->rowext, ctx->quads, ctx->counters, h, w, ctx->key_cap, ctx->slot_cap, cap,
-        minLen, lwTresh, active, wave_prep);
+        minLen, lwTresh, active, wave_prep, 0, 0);
     KCHK("k_rects_big");
     HIPCHK(hipEventRecord(ctx->ev_join[1], ctx->side[1]));
     k_rects<<<dim3(rects_grid, nc), 64, 0, ctx->stream>>>(ctx->keys, ctx->rowext, nullptr, ctx->quads, ctx->counters, h, w,
