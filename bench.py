@@ -358,7 +358,8 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
 
     # Per-launch HIP events cost ~6 % of a step when every one of its ~40 launches is bracketed, so inside
     # the timed region only the few largest kernels are (those that move pixels; the warm-up steps, fully
-    # bracketed, nominate four -- a cold first launch can distort a single winner); the dominant one is then
+    # bracketed, nominate two -- a cold first launch can distort a single winner, and four candidates' brackets measured
+    # 0.06-0.09 ms of a 4.2 ms step against an unbracketed run, profiles/README.md round-4 log); the dominant one is then
     # chosen from the timed region's own sums.  The per-kernel table of the JSON line comes from one extra,
     # fully bracketed step AFTER the timed region.
     res = None
@@ -367,8 +368,8 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
         res = step()
     torch.cuda.synchronize()
     warm = det.get_timing()
-    cands = sorted((k for k, v in warm.items() if v[1] and KERNEL_BYTES_PER_PX.get(k, 0.0) != 0.0), key=lambda k: -warm[k][0])[:4]
-    det.timing_select(cands or ["k_dilate_canny", "k_prep_hist", "k_hough_vote", "k_prep_erode"])
+    cands = sorted((k for k, v in warm.items() if v[1] and KERNEL_BYTES_PER_PX.get(k, 0.0) != 0.0), key=lambda k: -warm[k][0])[:2]
+    det.timing_select(cands or ["k_dilate_canny", "k_prep_hist"])
     det.enable_timing(not args.no_kernel_timing)  # (re-arms and clears the sums)
     fence()
     t0 = time.perf_counter()

@@ -132,6 +132,28 @@ def test_fit_min_area_rect_dense_nested_contours(gpu_ctx, oracle):
         assert (det_g, nb_g) == (det_o, nb_o) and np.array_equal(box_g, box_o)
 
 
+def test_fit_min_area_rect_key_heights_around_the_launch_boundaries(gpu_ctx, oracle):
+    """Keys go to one of four launches by their height in rows (k_rect.h: a lane per key up to 16 rows, a wave with a 64-row
+    footprint up to 64, a wave with a 320-row footprint, a wave with the full-height footprint): slanted bars whose contours are
+    15..18, 62..67, 317..324 and 600 rows tall, several per image, with and without a hole."""
+    heights = list(range(13, 19)) + list(range(60, 68)) + list(range(315, 325)) + [600]
+    for k0 in range(0, len(heights), 3):
+        img = np.zeros((700, 640), np.uint8)
+        for j, hh in enumerate(heights[k0:k0 + 3]):
+            x0 = 20 + 200 * j
+            for r in range(hh):
+                x = x0 + (r * 60) // max(hh, 1)                 # a bar leaning to the right, 9 px wide
+                img[40 + r, x:x + 9] = 230
+                if j == 1 and 3 < r < hh - 3:
+                    img[40 + r, x + 3:x + 6] = 0                 # ... the middle one hollow: a hole border of nearly the same height
+        for min_len, lw in ((1, 5), (0, 1.5)):
+            det_o, box_o, nb_o = oracle.fit_min_area_rect(img, 1, 1, min_len, lw)
+            det_g, box_g, nb_g = gpu_ctx.fit_min_area_rect(img, 1, 1, min_len, lw)
+            assert (det_g, nb_g) == (det_o, nb_o), heights[k0:k0 + 3]
+            assert np.array_equal(box_g, box_o), heights[k0:k0 + 3]
+        assert nb_g >= 1
+
+
 def test_device_libm_agrees_with_the_host_on_the_rectangle_path(gpu_ctx, oracle):
     """minAreaRect's angle (atan2 in double, rounded to float32, in degrees) and boxPoints' cos / sin of it are the only
     libm calls on the accept / reject path; the device evaluates them with its own libm, the oracle with glibc.  Both are
