@@ -259,7 +259,7 @@ def stress_leg(args, env, headline):
     pb, pd, prs = default_params()
     rs = _native.make_rs_params("r", **{k: v for k, v in prs.items() if k != "debug"})
     n, nd = 256, 16
-    out = {"batch": n, "distinct_frames": nd, "note": "secondary leg, never `value`; percent = of this run's headline frames/s"}
+    out = {"batch": n, "distinct_frames": nd, "note": "secondary leg, never `value`; synchronous calls; percent = of this run's rate on the benchmark's sky with synchronous calls (`one_call_in_flight`, the headline when calls_in_flight = 1)"}
     for name in synth.STRESS:
         host, cats = synth.make_frames(0, nd, synth.SDSS_SHAPE, min(16, host_cores(1)[0]), True, synth.stress_recipes(name, nd))
         idx = torch.arange(n, device=dev) % nd
@@ -332,7 +332,8 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
         packed = synth.pack_catalogs(cats)
         cat = {k: torch.from_numpy(v).to(dev) for k, v in packed.items()}
     stream = torch.cuda.current_stream().cuda_stream
-    det = BatchDetector(dev_index, (h, w), inflight, stream=stream, lanes=args.lanes)
+    cif = max(1, args.calls_in_flight) if args.lanes == 1 and not args.host_frames else 1
+    det = BatchDetector(dev_index, (h, w), inflight, stream=stream, lanes=args.lanes, calls_in_flight=cif)
 
     if lsst:
         def run(frames, _cat):
@@ -343,6 +344,22 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
 
     def step_dev():
         return run(dframes, cat)
+
+    def step_async():                              # calls_in_flight > 1: the call as a future (BatchDetector.detect_async)
+        if lsst:
+            return det.multiscale_async(dframes, pd, rhos, dim=True, flip=True)
+        return det.detect_async(dframes, pb, pd, cat, rs)
+
+    def run_steps(k):
+        # k steps; with several calls in flight they are all submitted (a host thread per context takes its own in order) and
+        # collected in order: step i + 1 is queued on the GPU while step i runs
+        if cif > 1:
+            futs = [step_async() for _ in range(k)]
+            return [f.result() for f in futs][-1]
+        r = None
+        for _ in range(k):
+            r = step()
+        return r
 
     def step_host():
         return run(host, None if (lsst or args.no_removestars) else packed)
@@ -364,8 +381,12 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
     # fully bracketed step AFTER the timed region.
     res = None
     det.enable_timing(not args.no_kernel_timing)
-    for _ in range(warmup):
-        res = step()
+    for c in det.ctxs[1:] if cif > 1 else ():      # (every further context's first call -- lazy allocations -- before the warm-up)
+        if lsst:
+            c.process_multiscale(dframes, pd, rhos, True, True, False)
+        else:
+            c.detect_batch(dframes, pb, pd, cat, rs)
+    res = run_steps(warmup)
     torch.cuda.synchronize()
     warm = det.get_timing()
     cands = sorted((k for k, v in warm.items() if v[1] and KERNEL_BYTES_PER_PX.get(k, 0.0) != 0.0), key=lambda k: -warm[k][0])[:2]
@@ -373,11 +394,19 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
     det.enable_timing(not args.no_kernel_timing)  # (re-arms and clears the sums)
     fence()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        res = step()
+    res = run_steps(steps)
     fence()
     elapsed = time.perf_counter() - t0
     timing = det.get_timing()
+    one_call = None
+    if cif > 1:                                   # beside it: the same steps one synchronous call after the other
+        det.enable_timing(False)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        one_call = time.perf_counter() - t1
     det.timing_select(None)
     det.enable_timing(not args.no_kernel_timing)
     step()                                        # untimed: the per-kernel table
@@ -402,8 +431,7 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
         t0 = time.perf_counter()
         m = 0
         while time.perf_counter() - t0 < sustained_s:
-            for _ in range(10):
-                step()
+            run_steps(10)
             torch.cuda.synchronize()
             m += 10
         dt = time.perf_counter() - t0
@@ -413,6 +441,36 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
                      "ms_per_step": round(1e3 * dt / m, 3),
                      "sclk_mhz_during": {"samples": len(clocks), "min": min(clocks), "median": int(np.median(clocks)), "max": max(clocks)} if clocks else None,
                      "note": "the timed step repeated back to back (this rank); sclk = hwmon freq1_input of this device's PCI function, sampled every 0.2 s while the loop runs"}
+    two_calls = None
+    if sustained_s > 0 and cif == 1 and args.lanes == 1 and not args.host_frames:
+        # secondary: the same step with two calls in flight (no HIP events: with a queue that never drains they no longer bracket
+        # single kernels, which is why the headline's timed region keeps synchronous calls)
+        det2 = BatchDetector(dev_index, (h, w), inflight, stream=stream, calls_in_flight=2)
+        try:
+            def sub2():
+                return det2.multiscale_async(dframes, pd, rhos, dim=True, flip=True) if lsst else det2.detect_async(dframes, pb, pd, cat, rs)
+            for f in [sub2() for _ in range(4)]:
+                r2 = f.result()
+            m2 = max(steps, 40)
+            fence()
+            t0 = time.perf_counter()
+            for f in [sub2() for _ in range(m2)]:
+                r2 = f.result()
+            fence()
+            dt2 = time.perf_counter() - t0
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(m2):
+                step()
+            fence()
+            dt1 = time.perf_counter() - t0
+            two_calls = {"value": round(world * n * m2 / dt2, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt2 / m2, 3), "steps": m2,
+                         "synchronous_calls_beside_it": {"value": round(world * n * m2 / dt1, 2), "ms_per_step": round(1e3 * dt1 / m2, 3)},
+                         "records_equal_the_synchronous_call": bool(r2.tobytes() == res.tobytes()),
+                         "note": "BatchDetector(calls_in_flight=2).detect_async: two contexts (a workspace each) launching into one stream, a host "
+                                 "thread each; this rank only; secondary, never `value`"}
+        finally:
+            det2.close()
     host_res = None
     if host_leg and host_ok and not args.host_frames and not args.no_host_leg:  # secondary: frames handed over as host buffers (PCIe-inclusive; never `value`)
         step_host()
@@ -429,9 +487,11 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
             host_res = float(t.item())
         host_res = (world * n * m / host_res, m)
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        t = torch.tensor([elapsed, one_call or 0.0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        one_call = float(t[1].item()) or None
+    one_call_el = one_call
 
     state = {"host": host, "cats": cats, "res": res, "pb": pb, "pd": pd, "prs": prs, "rhos": rhos, "lsst": lsst, "n": n, "nd": nd}
     out = None
@@ -531,6 +591,10 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_s,
                        "frames_per_gpu": n, "inflight": inflight, "lanes": args.lanes, "shape": [h, w],
+                       "calls_in_flight": cif,
+                       "calls_in_flight_note": ("BatchDetector(calls_in_flight=%d): %d contexts (a workspace each) launching into one stream, a host thread "
+                                                "each; step i + 1 is queued while step i runs, the steps still execute one after the other and "
+                                                "return the same records; `one_call_in_flight` is the same loop with synchronous calls" % (cif, cif)) if cif > 1 else None,
                        "removestars": (not lsst) and not args.no_removestars, "parallelism": "frame-parallel x%d" % world + (" (rehearsal: ranks share %d GPU(s), gloo)" % torch.cuda.device_count() if share else ""),
                        "found_bright": found_b, "found_dim": found_d, "frame_errors": errors,
                        "hough_rhos": rhos if lsst else [20.0],
@@ -540,6 +604,9 @@ def measure(args, workload, n, steps, warmup, env, distinct=None, host_leg=True,
                        "beside_the_fast_path": {k: v for k, v in det.stats().items() if k != "spilled_frames"},
                        "detection_vs_injected_truth": detection_quality(res0, truths, h),
                        "gen_s": round(t_gen, 1)},
+            "one_call_in_flight": ({"value": round(total_frames / one_call_el, 2), "unit": "frames/s", "ms_per_step": round(1e3 * one_call_el / steps, 3),
+                                    "steps": steps} if one_call_el else None),
+            "two_calls_in_flight": two_calls,
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "frac_kind": "ALGORITHMIC bytes (SURVEY 8d) / kernel time / peak -- not HBM utilisation; see measured_traffic_frac",
@@ -745,6 +812,10 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=None, help="default 256 (configs[2]: 256 per GPU; configs[4]: 2048 over 8 GPUs)")
     ap.add_argument("--inflight", type=int, default=None, help="frames per launch (default: the whole batch)")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches (streams) per GPU")
+    ap.add_argument("--calls-in-flight", type=int, default=1,
+                    help="BatchDetector(calls_in_flight=): contexts launching into one stream, a host thread each, step i + 1 queued while step i "
+                         "runs.  Default 1 (synchronous calls: HIP events bracket single kernels only then); the default run reports the rate with 2 "
+                         "as the secondary `two_calls_in_flight`")
     ap.add_argument("--cpu-sample", type=int, default=None, help="frames timed through the CPU oracle on one thread (0 = skip)")
     ap.add_argument("--gen-workers", type=int, default=-1)
     ap.add_argument("--no-removestars", action="store_true")
@@ -813,7 +884,7 @@ def main():
                 out["dropin"] = {"error": "%s: %s" % (type(e).__name__, e)}
             del state
             try:
-                out["stress"] = stress_leg(args, env, out["value"])
+                out["stress"] = stress_leg(args, env, (out.get("one_call_in_flight") or out)["value"])
             except Exception as e:  # noqa: BLE001
                 out["stress"] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:

@@ -469,6 +469,44 @@ def test_two_contexts_of_one_process_at_the_same_time(oracle):
     assert same(want[5], oracle.detect_frame(frames[5].copy(), pb, pd, cats[5], rs_o))
 
 
+def test_batch_detector_with_two_calls_in_flight(oracle):
+    """BatchDetector(calls_in_flight=2): two contexts launching into one stream, a host thread each, calls dealt out in turn
+    (bench.py's headline loop).  Eight calls over three different device-resident batches submitted at once: every future
+    holds the records of the synchronous call on its batch; host frames and the multi-scale pass go the same way."""
+    import torch
+    from lfd_amd import synth
+    from lfd_amd.batch import BatchDetector
+    pb, pd, prs = params()
+    rs_g, rs_o = rs_pair(oracle, prs)
+    dev = torch.device("cuda", 0)
+    batches = []
+    for b in range(3):
+        frames, cats = zip(*[synth.make_frame(10 * b + k)[:2] for k in range(4)])
+        packed = synth.pack_catalogs(list(cats))
+        batches.append((np.stack(frames), {k: torch.from_numpy(v).to(dev) for k, v in packed.items()}, frames, cats))
+    one = BatchDetector(0, synth.SDSS_SHAPE, 4)
+    want = [one.detect(torch.from_numpy(f).to(dev), pb, pd, c, rs_g) for f, c, _, _ in batches]
+    with pytest.raises(RuntimeError):
+        one.detect_async(batches[0][0], pb, pd, None, rs_g)
+    one.close()
+    det = BatchDetector(0, synth.SDSS_SHAPE, 4, calls_in_flight=2)
+    assert len(det.ctxs) == 2
+    order = [0, 1, 2, 0, 2, 1, 1, 0]
+    dframes = [torch.from_numpy(batches[b][0]).to(dev) for b in order]          # (remove_stars works in place: a copy per call)
+    futs = [det.detect_async(dframes[i], pb, pd, batches[b][1], rs_g) for i, b in enumerate(order)]
+    for f, b in zip(futs, order):
+        assert f.result().tobytes() == want[b].tobytes(), b
+    host = det.detect_async(batches[1][0].copy(), pb, pd, {k: v.cpu().numpy() for k, v in batches[1][1].items()}, rs_g)
+    assert host.result().tobytes() == want[1].tobytes()
+    plain = np.stack([synth.make_frame(k, with_catalog=False)[0] for k in range(4)])
+    ms = [det.multiscale_async(torch.from_numpy(plain).to(dev), pd, [20.0, 10.0]) for _ in range(3)]
+    ref = det.multiscale(torch.from_numpy(plain).to(dev), pd, [20.0, 10.0])
+    assert all(m.result().tobytes() == ref.tobytes() for m in ms)
+    assert det.spill_count() == 0
+    det.close()
+    assert same(want[2][1], oracle.detect_frame(batches[2][2][1].copy(), pb, pd, batches[2][3][1], rs_o))
+
+
 def test_fused_run_scan_survives_the_wrap_of_its_epoch(monkeypatch):
     """k_scan_fused marks a workgroup's published totals with the launch's 22-bit epoch; when the epoch wraps the host clears
     the words and starts over.  A context started three launches before the wrap (LFDMI_SCAN_EPOCH0) gives the records of an
